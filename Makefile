@@ -1,0 +1,46 @@
+# Builds everything in-tree (the .so files travel to the GPU box with gpurun; they are git-ignored):
+#   montecarlooptionspricer_amd/lib/libmcgpu.so  -- the product: HIP kernels + C ABI + C++ drop-in classes
+#   oracle/libmcgoracle.so, oracle/_ref/libmcref.so -- the parity oracle (test infrastructure)
+HIPCC   ?= /opt/rocm/bin/hipcc
+ARCH    ?= gfx950
+PKG     := montecarlooptionspricer_amd
+OBJDIR  := build/obj
+LIB     := $(PKG)/lib/libmcgpu.so
+
+HIPFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Iinclude -Wall -Wno-unused-function
+# host-only TUs: no FMA contraction so the estimators match the reference bit for bit
+HOSTFLAGS := -O2 -std=c++17 -fPIC -ffp-contract=off -Iinclude -Wall -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include
+
+HIP_SRCS  := $(wildcard $(PKG)/csrc/*.hip)
+HOST_SRCS := $(wildcard $(PKG)/host/*.cpp) $(wildcard $(PKG)/csrc/*.cpp)
+OBJS := $(patsubst %,$(OBJDIR)/%.o,$(notdir $(HIP_SRCS) $(HOST_SRCS)))
+HDRS := $(wildcard $(PKG)/csrc/*.hpp) $(wildcard include/*.h) $(wildcard include/mcgpu/*.hpp)
+
+all: lib oracle
+
+lib: $(LIB)
+
+$(LIB): $(OBJS)
+	@mkdir -p $(dir $@)
+	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $(OBJS) -ldl
+
+$(OBJDIR)/%.hip.o: $(PKG)/csrc/%.hip $(HDRS)
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(OBJDIR)/%.cpp.o: $(PKG)/host/%.cpp $(HDRS)
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HOSTFLAGS) -x c++ -c $< -o $@
+
+$(OBJDIR)/%.cpp.o: $(PKG)/csrc/%.cpp $(HDRS)
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HOSTFLAGS) -x c++ -c $< -o $@
+
+oracle:
+	$(MAKE) -C oracle
+
+clean:
+	rm -rf build $(PKG)/lib
+	$(MAKE) -C oracle clean
+
+.PHONY: all lib oracle clean

@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mpaths/s at 252 steps (BASELINE.json metric).
+
+Workload (BASELINE.json configs[1], "C2"): European call, GBM, 10M paths x 252 steps per GPU,
+S0 = K = 100, r = 0.04, sigma = 0.2, dt = 1/252, Philox seed 20251031.  One "step" = one full pass
+of the hot path: Philox normals -> GBM stepping -> the (253 x 10M) fp64 matrix written to HBM ->
+per-path payoff -> wavefront-shuffle reduction -> (N>1: one all-reduce of 3 doubles) -> price.
+Inputs are parameters only, so everything is resident when the timed region starts.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Weak scaling: every rank owns `--paths` global path ids [rank*paths, (rank+1)*paths) of ONE Philox
+stream; no data-path collective except the 3-double payoff all-reduce.  Prints ONE JSON line on
+rank 0 with the driver's contract fields plus "roofline" and "cpu_baseline" (N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
+
+
+def bs_call(S0, K, r, sigma, T):
+    d1 = (math.log(S0 / K) + (r + 0.5 * sigma * sigma) * T) / (sigma * math.sqrt(T))
+    d2 = d1 - sigma * math.sqrt(T)
+    N = lambda x: 0.5 * math.erfc(-x / math.sqrt(2.0))  # noqa: E731
+    return S0 * N(d1) - K * math.exp(-r * T) * N(d2)
+
+
+def cpu_baseline(n_steps: int, budget_s: float = 15.0) -> dict:
+    """The reference generator on this host's cores (oracle/_ref = the compiled reference,
+    "reference"; else our restatement in reference-faithful mode, "port"), parallelised the way the
+    reference's driver does (omp parallel for schedule(dynamic) over independent generator calls,
+    src/core/PredictionGen.cpp:542-546; 250 paths per call, :719).  Bounded sample."""
+    import numpy as np  # noqa: F401
+
+    from oracle.binding import Oracle, Reference, have_ref, synthetic_history
+    hist = synthetic_history(1001, seed=42)
+    chunk = 250
+    if have_ref():
+        ref = Reference()
+        kind = "reference"
+        run = lambda n: ref.generate_paths_omp(hist, n_steps, n, chunk)  # noqa: E731
+    else:
+        orc = Oracle()
+        p = orc.estimate_params(hist)
+        kind = "port"
+        run = lambda n: orc.generate_paths_mt_omp(p["S0"], 0.04, p["xi"], p["H"], p["eta"], p["rho"], n_steps,  # noqa: E731
+                                                  n, chunk, 1)
+    t0 = time.perf_counter()
+    cores, _ = run(8000)
+    pilot = time.perf_counter() - t0
+    rate = 8000 / max(pilot, 1e-6)
+    n = int(min(max(rate * budget_s, 20_000), 5_000_000)) // chunk * chunk
+    t0 = time.perf_counter()
+    cores, sum_st = run(n)
+    dt = time.perf_counter() - t0
+    return {"value": n / dt / 1e6, "unit": "Mpaths/s", "cores": int(cores), "kind": kind,
+            "sample": f"{n} paths x {n_steps} steps via RoughVolatility::GenerateStockPricePaths "
+                      f"(rBergomi, 1001-point synthetic history), omp dynamic, {chunk} paths/call, {dt:.1f} s"}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10, help="timed passes of the hot path")
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--paths", type=int, default=10_000_000, help="paths per GPU (C2: 10M)")
+    ap.add_argument("--time-steps", type=int, default=252)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--collective", default=os.environ.get("MCG_COLLECTIVE", "torch"), choices=["torch", "rccl"])
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch
+
+    import montecarlooptionspricer_amd as mc
+    from montecarlooptionspricer_amd import _native as N
+    from montecarlooptionspricer_amd.sharding import shard_range
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+
+    S0, K, r, sigma, dt = 100.0, 100.0, 0.04, 0.2, 1.0 / 252.0
+    n_steps, seed = args.time_steps, 20251031
+    T = n_steps * dt
+    total_paths = args.paths * world
+    begin, count = shard_range(total_paths, rank, world)
+
+    stream = torch.cuda.current_stream().cuda_stream if world > 1 else None
+    eng = mc.PathEngine(local_rank, stream=stream)
+    if world > 1:
+        if args.collective == "rccl":
+            def bcast(uid):
+                box = [uid]
+                dist.broadcast_object_list(box, src=0)
+                return box[0]
+            eng.init_rccl(rank, world, bcast)
+        else:
+            eng.use_torch_distributed()
+
+    def one_pass():
+        P = eng.gbm(seed, S0, r, sigma, dt, n_steps, count, path_begin=begin, payoff=(K, True))
+        price, se = eng.price_european(P, K, r, T, True)
+        P.free()
+        return price, se
+
+    def fence():
+        eng.synchronize()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        eng.synchronize()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_pass()
+    eng.timing_enable(True)
+    eng.timing_reset()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        price, se = one_pass()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    k_ms, k_n = eng.timing_get(N.K_GBM)
+    eng.timing_enable(False)
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = total_paths * args.steps / elapsed / 1e6
+        alg_bytes = 8.0 * (n_steps + 1) * count          # 8*(steps+1) B written per path
+        k_avg_ms = k_ms / max(k_n, 1)
+        achieved = alg_bytes / (k_avg_ms * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                j = json.load(open(pmc))
+                if j.get("paths") == count and j.get("time_steps") == n_steps:
+                    traffic = j.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        ref = bs_call(S0, K, r, sigma, T)
+        out = {
+            "metric": "Mpaths/sec at 252 steps", "value": value, "unit": "Mpaths/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "C2: European call, GBM, 10M paths x 252 steps per GPU, fp64 matrix written",
+                       "paths_per_gpu": args.paths, "time_steps": n_steps, "global_paths": total_paths,
+                       "sharding": f"contiguous path ids over {world} rank(s); one 3-double all-reduce",
+                       "S0": S0, "K": K, "r": r, "sigma": sigma, "seed": seed},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_gbm_paths",
+                         "kernel_avg_ms": k_avg_ms, "launches": int(k_n),
+                         "algorithmic_bytes_per_launch": alg_bytes},
+            "parity": {"price": price, "std_err": se, "black_scholes": ref,
+                       "abs_err_over_std_err": abs(price - ref) / se if se > 0 else None},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(n_steps)
+            except Exception as e:  # the baseline is reported, never required for the GPU number
+                out["cpu_baseline"] = {"value": None, "unit": "Mpaths/s", "cores": 0, "kind": "port",
+                                       "sample": f"failed: {e}"}
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,155 @@
+/* mcgpu.h -- C ABI of the MI355X-native Monte Carlo path engine (libmcgpu.so).
+ *
+ * This is the drop-in boundary for the hot path of bcosm/MonteCarloOptionsPricer
+ * (RNG -> GBM / rBergomi time-stepping -> per-path payoff -> Longstaff-Schwartz sweep).
+ * Plain pointers and sizes only; no C++ or torch types cross it.  The host-side C++ classes with
+ * the reference's exact signatures (include/models/RoughVolatility.h, include/models/LSMPricer.h)
+ * are thin shims over these entry points; INTEGRATION.md shows the reference-side binding.
+ *
+ * Conventions
+ *   - every function returns an int status (MCG_OK == 0); nothing throws across the ABI;
+ *     mcg_last_error() returns a thread-local message for the last non-zero status on this thread.
+ *   - all arithmetic and storage is IEEE binary64, like the reference.
+ *   - a path matrix lives on the device, STEP-MAJOR: element (step j, path p) at data[j*ld + p],
+ *     j = 0..n_steps (column 0 = S0, like RoughVolatility.cpp:344,:354), p = 0..n_paths-1.
+ *     The reference's host layout (path-major vector<vector<double>>) is produced/consumed by
+ *     mcg_paths_to_host / mcg_paths_from_host.
+ *   - RNG contract: Philox4x32-10, key = seed, counter = (global path id, block, stream); a path's
+ *     values depend only on (seed, global path id), never on how paths are sharded over GPUs.
+ *   - re-entrant: one mcg_ctx per host thread (or per GPU); a ctx owns its stream and workspace.
+ */
+#ifndef MCGPU_H
+#define MCGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mcg_ctx mcg_ctx;     /* device, stream, workspace, optional collective */
+typedef struct mcg_paths mcg_paths; /* device-resident (n_steps+1) x n_paths matrix      */
+
+enum mcg_status {
+    MCG_OK = 0,
+    MCG_ERR_INVALID = 1,           /* bad argument                                        */
+    MCG_ERR_NO_DEVICE = 2,         /* no usable MI355X / HIP runtime                      */
+    MCG_ERR_HIP = 3,               /* a HIP call failed (message has the HIP error)       */
+    MCG_ERR_OOM = 4,               /* device allocation failed                            */
+    MCG_ERR_HISTORY_TOO_SMALL = 5, /* == RoughVolatility.cpp:317-319                      */
+    MCG_ERR_EMPTY_PATHS = 6,       /* == LSMPricer.cpp:28-30                              */
+    MCG_ERR_COMM = 7               /* collective failed                                   */
+};
+
+/* kernels whose device time mcg_timing_get reports */
+enum mcg_kernel {
+    MCG_K_GBM = 0,        /* GBM path generation (+ fused payoff partials)  */
+    MCG_K_RBERGOMI = 1,   /* rBergomi path generation                       */
+    MCG_K_PAYOFF = 2,     /* terminal payoff reduction over a stored matrix */
+    MCG_K_LSM_SWEEP = 3,  /* LSM per-date update+moments kernels            */
+    MCG_K_LSM_SOLVE = 4,  /* LSM per-date reduce+solve kernels              */
+    MCG_K_TRANSPOSE = 5,  /* layout change for the host class API           */
+    MCG_K_COUNT = 6
+};
+
+const char* mcg_last_error(void);
+const char* mcg_version(void);
+int mcg_device_count(int* count);
+
+/* ---- context ---------------------------------------------------------------------------- */
+/* external_stream: a hipStream_t to launch on (e.g. torch's current stream), or NULL to let the
+ * ctx create its own non-blocking stream. */
+int mcg_init(mcg_ctx** ctx, int device, void* external_stream);
+int mcg_finalize(mcg_ctx* ctx);
+int mcg_synchronize(mcg_ctx* ctx);
+int mcg_trim(mcg_ctx* ctx); /* release cached device buffers */
+
+/* Optional sum-all-reduce used when paths are sharded over several GPUs (one process per GPU).
+ * fn must sum `count` doubles at device pointer `buf` in place over all ranks, ordered on
+ * `stream` (a hipStream_t).  With a collective installed, mcg_price_european / mcg_price_lsm
+ * return the GLOBAL price on every rank.  Payloads are 3 doubles (European) or 3p+2 doubles per
+ * exercise date (LSM regression moments). */
+typedef int (*mcg_allreduce_fn)(void* user, double* buf, int count, void* stream);
+int mcg_set_allreduce(mcg_ctx* ctx, mcg_allreduce_fn fn, void* user);
+
+/* Built-in RCCL collective (librccl is dlopen'ed on first use).  The 128-byte id comes from rank
+ * 0's mcg_comm_unique_id and is broadcast by the launcher (torch.distributed store, MPI, ...). */
+int mcg_comm_unique_id(unsigned char id[128]);
+int mcg_comm_init_rank(mcg_ctx* ctx, const unsigned char id[128], int n_ranks, int rank);
+
+/* ---- path generation (replaces RoughVolatility.cpp:346-365, device side) ---------------- */
+/* GBM: the stepping loop of RoughVolatility.cpp:354-364 with v == sigma^2.
+ * Paths [path_begin, path_begin + n_paths) of the global Philox stream `seed`. */
+int mcg_paths_gbm(mcg_ctx* ctx, uint64_t seed, double S0, double r, double sigma, double dt,
+                  int n_steps, uint64_t path_begin, int64_t n_paths, mcg_paths** out);
+
+/* rBergomi as the reference simulates it (RoughVolatility.cpp:342-364) with explicit parameters.
+ * rho is accepted for interface parity; it does not change the law. */
+int mcg_paths_rbergomi(mcg_ctx* ctx, uint64_t seed, double S0, double r, double xi, double H,
+                       double eta, double rho, double dt, int n_steps, uint64_t path_begin,
+                       int64_t n_paths, mcg_paths** out);
+
+/* Fused GBM generation + terminal payoff reduction in one kernel (the measured headline path):
+ * writes the full matrix AND leaves {sum payoff, sum payoff^2, n} for mcg_price_european to reuse
+ * when called with the same (K, is_call). */
+int mcg_paths_gbm_payoff(mcg_ctx* ctx, uint64_t seed, double S0, double r, double sigma, double dt,
+                         int n_steps, uint64_t path_begin, int64_t n_paths, double K, int is_call,
+                         mcg_paths** out);
+int mcg_paths_rbergomi_payoff(mcg_ctx* ctx, uint64_t seed, double S0, double r, double xi, double H,
+                              double eta, double rho, double dt, int n_steps, uint64_t path_begin,
+                              int64_t n_paths, double K, int is_call, mcg_paths** out);
+
+/* Upload a host matrix in the reference's layout: row_major[p*n_cols + j], n_cols = n_steps+1. */
+int mcg_paths_from_host(mcg_ctx* ctx, const double* row_major, int64_t n_paths, int n_cols,
+                        mcg_paths** out);
+/* Download into the reference's layout (path-major, what GenerateStockPricePaths returns). */
+int mcg_paths_to_host(const mcg_paths* paths, double* row_major_out);
+/* Download as stored: out[j*n_paths + p]. */
+int mcg_paths_to_host_step_major(const mcg_paths* paths, double* step_major_out);
+int mcg_paths_info(const mcg_paths* paths, int64_t* n_paths, int* n_steps, int64_t* ld,
+                   void** device_ptr);
+int mcg_paths_free(mcg_paths* paths);
+
+/* ---- pricing ---------------------------------------------------------------------------- */
+/* e^{-rT} * mean(PayoffFunction(S_T)) (include/core/common.h:8-14 on the last column) and its
+ * Monte Carlo standard error.  sums3 (optional) receives {sum, sum^2, n} before discounting. */
+int mcg_price_european(mcg_ctx* ctx, const mcg_paths* paths, double K, double r, double T,
+                       int is_call, double* mean, double* std_err);
+
+/* LSM::PredictOptionPrice (src/models/LSMPricer.cpp:19-102) on a device-resident matrix.
+ * Returns mean_i V[i][0]; std_err is an addition (the reference returns a bare mean).
+ * poly_order in [0, 8]. */
+int mcg_price_lsm(mcg_ctx* ctx, const mcg_paths* paths, double r, double K, double maturity,
+                  double dt, int is_call, int poly_order, double* mean, double* std_err);
+
+/* ---- host-side pieces of the class-level API (a2/a3 of SURVEY.md section 8) --------------- */
+/* RoughVolatility.cpp:324-331: out5 = {xi, H, eta, rho, S0}. */
+int mcg_estimate_params(const double* hist, size_t n, double out5[5]);
+/* Real Volterra weights kappa[0..Mz) and compensator comp[0..n_steps) staged in LDS by the
+ * rBergomi kernel; Mz = nextpow2(n_steps). */
+int mcg_rbergomi_weights(double H, double eta, double dt, int n_steps, double* kappa, double* comp,
+                         int* Mz);
+
+/* The reference's class API through the C ABI (what the C++ shims in include/models call):
+ * GenerateStockPricePaths(hist, steps, paths) -> out[paths][steps+1], and
+ * LSM::PredictOptionPrice(pricePaths, r, strike, maturity, dt, isCall, polyOrder).
+ * Both use a lazily created per-thread ctx on device 0 (MCG_DEVICE overrides). */
+int mcg_compat_set_seed(uint64_t seed, int enabled); /* default: std::random_device per call */
+int mcg_compat_generate_paths(const double* hist, size_t n, int forward_steps, int path_num,
+                              double* row_major_out);
+int mcg_compat_lsm_price(const double* row_major, int64_t n_paths, int n_cols, double r,
+                         double strike, double maturity, double dt, int is_call, int poly_order,
+                         double* price);
+
+/* ---- measurement ------------------------------------------------------------------------ */
+/* When enabled, every kernel launch is bracketed by HIP events on the ctx stream. */
+int mcg_timing_enable(mcg_ctx* ctx, int on);
+int mcg_timing_reset(mcg_ctx* ctx);
+int mcg_timing_get(mcg_ctx* ctx, int kernel /* enum mcg_kernel */, double* total_ms,
+                   int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MCGPU_H */

@@ -1,0 +1,85 @@
+"""ctypes binding of libmcgpu.so (the C ABI declared in include/mcgpu.h)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "lib", "libmcgpu.so")
+
+MCG_OK = 0
+K_GBM, K_RBERGOMI, K_PAYOFF, K_LSM_SWEEP, K_LSM_SOLVE, K_TRANSPOSE = range(6)
+KERNEL_NAMES = {K_GBM: "gbm", K_RBERGOMI: "rbergomi", K_PAYOFF: "payoff", K_LSM_SWEEP: "lsm_sweep",
+                K_LSM_SOLVE: "lsm_solve", K_TRANSPOSE: "transpose"}
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p)
+
+
+class McgError(RuntimeError):
+    """A non-zero status from libmcgpu (message = mcg_last_error()) or a missing library."""
+
+    def __init__(self, msg: str, status: int = -1):
+        super().__init__(msg)
+        self.status = status
+
+
+_lib = None
+
+
+def lib_path() -> str:
+    return _LIB
+
+
+def load_library():
+    """Load libmcgpu.so; fail loudly if it has not been built (no fallback exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB):
+        raise McgError(f"{_LIB} not found: build it with `make lib` (or __graft_entry__.build()); "
+                       "this package has no CPU fallback")
+    L = C.CDLL(_LIB)
+    dp = C.POINTER(C.c_double)
+    vp = C.c_void_p
+    L.mcg_last_error.restype = C.c_char_p
+    L.mcg_version.restype = C.c_char_p
+    L.mcg_device_count.argtypes = [C.POINTER(C.c_int)]
+    L.mcg_init.argtypes = [C.POINTER(vp), C.c_int, vp]
+    L.mcg_finalize.argtypes = [vp]
+    L.mcg_synchronize.argtypes = [vp]
+    L.mcg_trim.argtypes = [vp]
+    L.mcg_set_allreduce.argtypes = [vp, ALLREDUCE_FN, vp]
+    L.mcg_comm_unique_id.argtypes = [C.c_char_p]
+    L.mcg_comm_init_rank.argtypes = [vp, C.c_char_p, C.c_int, C.c_int]
+    L.mcg_paths_gbm.argtypes = [vp, C.c_uint64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int,
+                                C.c_uint64, C.c_int64, C.POINTER(vp)]
+    L.mcg_paths_gbm_payoff.argtypes = [vp, C.c_uint64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int,
+                                       C.c_uint64, C.c_int64, C.c_double, C.c_int, C.POINTER(vp)]
+    L.mcg_paths_rbergomi.argtypes = [vp, C.c_uint64] + [C.c_double] * 7 + [C.c_int, C.c_uint64, C.c_int64,
+                                                                          C.POINTER(vp)]
+    L.mcg_paths_rbergomi_payoff.argtypes = [vp, C.c_uint64] + [C.c_double] * 7 + [C.c_int, C.c_uint64, C.c_int64,
+                                                                                 C.c_double, C.c_int, C.POINTER(vp)]
+    L.mcg_paths_from_host.argtypes = [vp, dp, C.c_int64, C.c_int, C.POINTER(vp)]
+    L.mcg_paths_to_host.argtypes = [vp, dp]
+    L.mcg_paths_to_host_step_major.argtypes = [vp, dp]
+    L.mcg_paths_info.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(vp)]
+    L.mcg_paths_free.argtypes = [vp]
+    L.mcg_price_european.argtypes = [vp, vp, C.c_double, C.c_double, C.c_double, C.c_int, dp, dp]
+    L.mcg_price_lsm.argtypes = [vp, vp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, dp, dp]
+    L.mcg_estimate_params.argtypes = [dp, C.c_size_t, dp]
+    L.mcg_rbergomi_weights.argtypes = [C.c_double, C.c_double, C.c_double, C.c_int, dp, dp, C.POINTER(C.c_int)]
+    L.mcg_compat_set_seed.argtypes = [C.c_uint64, C.c_int]
+    L.mcg_compat_generate_paths.argtypes = [dp, C.c_size_t, C.c_int, C.c_int, dp]
+    L.mcg_compat_lsm_price.argtypes = [dp, C.c_int64, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double,
+                                       C.c_int, C.c_int, dp]
+    L.mcg_timing_enable.argtypes = [vp, C.c_int]
+    L.mcg_timing_reset.argtypes = [vp]
+    L.mcg_timing_get.argtypes = [vp, C.c_int, dp, C.POINTER(C.c_int64)]
+    _lib = L
+    return L
+
+
+def check(status: int) -> None:
+    if status != MCG_OK:
+        msg = load_library().mcg_last_error()
+        raise McgError(msg.decode() if msg else f"libmcgpu status {status}", status)

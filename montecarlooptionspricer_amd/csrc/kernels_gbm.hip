@@ -1,0 +1,175 @@
+// GBM path generation for gfx950: one path per lane, Philox normals, S kept in a register,
+// step-major stores so a wavefront writes 64 consecutive doubles (512 B, four full 128-B lines)
+// per time step, and a wavefront-shuffle reduction of the terminal payoff.
+//
+// Replaces, on the device, the stepping loop of /root/reference/src/models/RoughVolatility.cpp:354-364
+// with v == sigma^2 (GBM is contained in the reference as that special case) and
+// PayoffFunction (include/core/common.h:8-14) on the last column.
+//
+// Roofline: HBM write, 8*(n_steps+1) bytes per path, reads ~0.  No MFMA: the step is elementwise.
+#include "devmath.hpp"
+#include "mcg_internal.hpp"
+
+namespace mcg {
+
+struct GbmArgs {
+    double* out;       // [n_steps+1][ld]
+    int64_t ld;
+    int64_t n_paths;
+    int n_steps;
+    uint64_t path_begin;
+    uint32_t k0, k1;   // Philox key = seed
+    double S0, drift, vol;
+    double K;
+    int is_call;
+    double* partials;  // [gridDim.x][2]
+};
+
+template <bool PAYOFF>
+__global__ __launch_bounds__(256) void k_gbm_paths(GbmArgs a) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool live = i < a.n_paths;
+    const uint64_t id = a.path_begin + (uint64_t)i;
+    double* col = a.out + i;
+    double S = a.S0;
+    if (live) __builtin_nontemporal_store(S, col);
+    const int n_pairs = a.n_steps >> 1;
+    for (int b = 0; b < n_pairs; ++b) {
+        double z0, z1;
+        normal_pair(a.k0, a.k1, id, (uint32_t)b, STREAM_PRICE, z0, z1);
+        S = S * exp(fma(a.vol, z0, a.drift));
+        col += a.ld;
+        if (live) __builtin_nontemporal_store(S, col);
+        S = S * exp(fma(a.vol, z1, a.drift));
+        col += a.ld;
+        if (live) __builtin_nontemporal_store(S, col);
+    }
+    if (a.n_steps & 1) {
+        double z0, z1;
+        normal_pair(a.k0, a.k1, id, (uint32_t)n_pairs, STREAM_PRICE, z0, z1);
+        S = S * exp(fma(a.vol, z0, a.drift));
+        col += a.ld;
+        if (live) __builtin_nontemporal_store(S, col);
+    }
+    if (PAYOFF) {
+        __shared__ double red[2 * 4];
+        const double pay = live ? payoff_of(a.is_call != 0, S, a.K) : 0.0;
+        double v[2] = {pay, pay * pay};
+        block_sum<2, 4>(v, red);
+        if (threadIdx.x == 0) {
+            a.partials[2 * (int64_t)blockIdx.x] = v[0];
+            a.partials[2 * (int64_t)blockIdx.x + 1] = v[1];
+        }
+    }
+}
+
+// Terminal payoff over a stored matrix: reads the last row only (8 B per path).
+__global__ __launch_bounds__(256) void k_payoff_sums(const double* last_row, int64_t n_paths, double K,
+                                                     int is_call, double* partials) {
+    __shared__ double red[2 * 4];
+    double v[2] = {0.0, 0.0};
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_paths; i += (int64_t)gridDim.x * 256) {
+        const double pay = payoff_of(is_call != 0, last_row[i], K);
+        v[0] += pay;
+        v[1] += pay * pay;
+    }
+    block_sum<2, 4>(v, red);
+    if (threadIdx.x == 0) {
+        partials[2 * (int64_t)blockIdx.x] = v[0];
+        partials[2 * (int64_t)blockIdx.x + 1] = v[1];
+    }
+}
+
+// Single-block, fixed-order reduction of per-block partials (deterministic for a given grid).
+__global__ __launch_bounds__(1024) void k_finish_sums(const double* partials, int64_t n_blocks, double n_local,
+                                                      double* out3) {
+    __shared__ double red[2 * 16];
+    double v[2] = {0.0, 0.0};
+    for (int64_t b = threadIdx.x; b < n_blocks; b += 1024) {
+        v[0] += partials[2 * b];
+        v[1] += partials[2 * b + 1];
+    }
+    block_sum<2, 16>(v, red);
+    if (threadIdx.x == 0) {
+        out3[0] = v[0];
+        out3[1] = v[1];
+        out3[2] = n_local;
+    }
+}
+
+int finish_sums(mcg_ctx* ctx, int64_t n_blocks, int64_t n_local, double out3[3]) {
+    double* d = ctx->scalars + SC_SUMS;
+    {
+        TimedLaunch t(ctx, MCG_K_PAYOFF);
+        hipLaunchKernelGGL(k_finish_sums, dim3(1), dim3(1024), 0, ctx->stream, ctx->partials, n_blocks,
+                           (double)n_local, d);
+    }
+    MCG_HIP(hipGetLastError());
+    if (ctx->allreduce) {
+        if (ctx->allreduce(ctx->allreduce_user, d, 3, (void*)ctx->stream) != 0)
+            return fail(MCG_ERR_COMM, "all-reduce of payoff sums failed");
+    }
+    MCG_HIP(hipMemcpyAsync(ctx->h_scalars + SC_SUMS, d, 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    MCG_HIP(hipStreamSynchronize(ctx->stream));
+    out3[0] = ctx->h_scalars[SC_SUMS];
+    out3[1] = ctx->h_scalars[SC_SUMS + 1];
+    out3[2] = ctx->h_scalars[SC_SUMS + 2];
+    return MCG_OK;
+}
+
+int launch_gbm(mcg_ctx* ctx, mcg_paths* P, uint64_t seed, double S0, double r, double sigma, double dt,
+               bool want_payoff, double K, int is_call) {
+    const int64_t n_blocks = (P->n_paths + 255) / 256;
+    if (n_blocks > 0x7fffffffLL) return fail(MCG_ERR_INVALID, "n_paths too large for one launch");
+    if (want_payoff) {
+        int rc = ensure_cap(ctx, &ctx->partials, &ctx->partials_cap, (size_t)(2 * n_blocks));
+        if (rc) return rc;
+    }
+    GbmArgs a;
+    a.out = P->data;
+    a.ld = P->ld;
+    a.n_paths = P->n_paths;
+    a.n_steps = P->n_steps;
+    a.path_begin = P->path_begin;
+    a.k0 = (uint32_t)seed;
+    a.k1 = (uint32_t)(seed >> 32);
+    a.S0 = S0;
+    a.drift = (r - 0.5 * sigma * sigma) * dt;
+    a.vol = sigma * std::sqrt(dt);
+    a.K = K;
+    a.is_call = is_call;
+    a.partials = ctx->partials;
+    {
+        TimedLaunch t(ctx, MCG_K_GBM);
+        if (want_payoff)
+            hipLaunchKernelGGL(k_gbm_paths<true>, dim3((unsigned)n_blocks), dim3(256), 0, ctx->stream, a);
+        else
+            hipLaunchKernelGGL(k_gbm_paths<false>, dim3((unsigned)n_blocks), dim3(256), 0, ctx->stream, a);
+    }
+    MCG_HIP(hipGetLastError());
+    if (want_payoff) {
+        int rc = finish_sums(ctx, n_blocks, P->n_paths, P->sums);
+        if (rc) return rc;
+        // sums[] now holds the (all-reduced, if a collective is installed) totals
+        P->has_sums = true;
+        P->sums_K = K;
+        P->sums_is_call = is_call;
+    }
+    return MCG_OK;
+}
+
+int launch_payoff_sums(mcg_ctx* ctx, const mcg_paths* P, double K, int is_call, double out3[3]) {
+    int64_t n_blocks = (P->n_paths + 255) / 256;
+    if (n_blocks > 4096) n_blocks = 4096;
+    int rc = ensure_cap(ctx, &ctx->partials, &ctx->partials_cap, (size_t)(2 * n_blocks));
+    if (rc) return rc;
+    {
+        TimedLaunch t(ctx, MCG_K_PAYOFF);
+        hipLaunchKernelGGL(k_payoff_sums, dim3((unsigned)n_blocks), dim3(256), 0, ctx->stream,
+                           P->data + (int64_t)P->n_steps * P->ld, P->n_paths, K, is_call, ctx->partials);
+    }
+    MCG_HIP(hipGetLastError());
+    return finish_sums(ctx, n_blocks, P->n_paths, out3);
+}
+
+}  // namespace mcg

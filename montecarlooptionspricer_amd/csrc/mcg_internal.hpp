@@ -1,0 +1,129 @@
+// Internal definitions behind include/mcgpu.h: context, device-buffer pool, error plumbing,
+// per-kernel HIP-event timing.  Not installed; not part of the ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/mcgpu.h"
+
+namespace mcg {
+
+void set_error(const char* fmt, ...);
+int fail(int status, const char* fmt, ...);
+
+#define MCG_HIP(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess)                                                                  \
+            return ::mcg::fail(_e == hipErrorOutOfMemory ? MCG_ERR_OOM : MCG_ERR_HIP,          \
+                               "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
+                               __LINE__);                                                      \
+    } while (0)
+
+struct PoolBuf {
+    void* ptr;
+    size_t bytes;
+};
+
+struct EventPair {
+    hipEvent_t a, b;
+};
+
+}  // namespace mcg
+
+struct mcg_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool owns_stream = false;
+    int n_cus = 256;
+
+    // cached device buffers (path matrices are tens of GB: never hipMalloc per call in steady state)
+    std::vector<mcg::PoolBuf> pool;
+    // small persistent workspace
+    double* partials = nullptr;  // per-block partial sums
+    size_t partials_cap = 0;     // in doubles
+    double* scalars = nullptr;   // device: sums, moments, coefficients
+    double* h_scalars = nullptr; // pinned host mirror
+    double* weights = nullptr;   // Volterra weights + compensator
+    size_t weights_cap = 0;
+    double* lsm_v = nullptr;     // LSM value vector
+    size_t lsm_v_cap = 0;
+    double* scratch = nullptr;   // rBergomi per-lane noise scratch
+    size_t scratch_cap = 0;
+
+    // collective
+    mcg_allreduce_fn allreduce = nullptr;
+    void* allreduce_user = nullptr;
+    void* rccl_comm = nullptr;
+    int n_ranks = 1, rank = 0;
+
+    // timing
+    bool timing = false;
+    std::vector<mcg::EventPair> ev_free;
+    std::vector<std::pair<int, mcg::EventPair>> ev_live;
+    double t_total[MCG_K_COUNT] = {0};
+    int64_t t_count[MCG_K_COUNT] = {0};
+};
+
+struct mcg_paths {
+    mcg_ctx* ctx = nullptr;
+    double* data = nullptr;
+    size_t bytes = 0;
+    int64_t n_paths = 0;
+    int n_steps = 0;
+    int64_t ld = 0;
+    uint64_t path_begin = 0;
+    // fused terminal-payoff sums left by *_payoff generators
+    bool has_sums = false;
+    double sums_K = 0.0;
+    int sums_is_call = 0;
+    double sums[3] = {0, 0, 0};  // host copy {sum, sumsq, n}, local shard
+};
+
+namespace mcg {
+
+constexpr int SCALARS_DOUBLES = 256;
+// layout of ctx->scalars (doubles)
+constexpr int SC_SUMS = 0;     // [0..3)  sum, sumsq, n
+constexpr int SC_MOMENTS = 8;  // [8..8+26) LSM moments (<= 3*8+2)
+constexpr int SC_COEF = 40;    // [40..40+9) LSM coefficients, [49] = regress flag
+constexpr int SC_FINAL = 64;   // [64..67) LSM final sums
+
+int pool_alloc(mcg_ctx* ctx, size_t bytes, void** out);
+void pool_release(mcg_ctx* ctx, void* ptr, size_t bytes);
+int ensure_cap(mcg_ctx* ctx, double** buf, size_t* cap, size_t need_doubles);
+
+// timing scope: records events around a launch when ctx->timing is on
+struct TimedLaunch {
+    mcg_ctx* ctx;
+    int kernel;
+    EventPair ev{};
+    bool on;
+    TimedLaunch(mcg_ctx* c, int k);
+    ~TimedLaunch();
+};
+
+int paths_new(mcg_ctx* ctx, int64_t n_paths, int n_steps, uint64_t path_begin, mcg_paths** out);
+
+// kernel launchers (one per .hip file)
+int launch_gbm(mcg_ctx* ctx, mcg_paths* P, uint64_t seed, double S0, double r, double sigma, double dt,
+               bool want_payoff, double K, int is_call);
+int launch_rbergomi(mcg_ctx* ctx, mcg_paths* P, uint64_t seed, double S0, double r, double xi, double H,
+                    double eta, double dt, bool want_payoff, double K, int is_call);
+int launch_payoff_sums(mcg_ctx* ctx, const mcg_paths* P, double K, int is_call, double out3[3]);
+int finish_sums(mcg_ctx* ctx, int64_t n_blocks, int64_t n_local, double out3[3]);
+int run_lsm(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double maturity, double dt, int is_call,
+            int poly_order, double* mean, double* std_err);
+
+// host-side math (host/volterra.cpp, host/estimators.cpp)
+int host_estimate_params(const double* hist, size_t n, double out5[5]);
+int host_rbergomi_weights(double H, double eta, double dt, int n_steps, std::vector<double>& kappa,
+                          std::vector<double>& comp);
+
+}  // namespace mcg

@@ -1,0 +1,52 @@
+// Counter-based RNG for the path engine: Philox4x32-10 (Salmon et al., SC'11) and the
+// block -> two-normals map shared by every kernel.  Device-only code for gfx950.
+//
+// RNG contract (DESIGN.md "RNG contract"; the oracle's normal_pair mirrors it bit for bit up to
+// libm-vs-device rounding of log/sincos):
+//   key     = (seed_lo, seed_hi)
+//   counter = (path_lo, path_hi, block, stream)       stream 0: price driver, 1: volatility driver
+//   words   = philox4x32_10(counter, key)
+//   u1 = ((w1:w0 >> 12) + 1/2) * 2^-52,  u2 = ((w3:w2 >> 12) + 1/2) * 2^-52      (both in (0,1))
+//   z0 = sqrt(-2 ln u1) cos(2 pi u2),  z1 = sqrt(-2 ln u1) sin(2 pi u2)
+// A path's draws depend only on (seed, global path id): shards of one job reproduce the
+// single-GPU stream exactly.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mcg {
+
+enum : uint32_t { STREAM_PRICE = 0u, STREAM_VOL = 1u };
+
+struct Philox4 {
+    uint32_t w0, w1, w2, w3;
+};
+
+__device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                 uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        // 32x32 -> 64 products; hipcc selects v_mad_u64_u32 / v_mul_hi_u32 + v_mul_lo_u32
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1;
+        c3 = (uint32_t)p0;
+        c0 = n0;
+        c2 = n2;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return Philox4{c0, c1, c2, c3};
+}
+
+// 52 mantissa bits -> (a + 1/2) * 2^-52 in (0,1).  Built by bit-pasting into [1,2): exact.
+__device__ __forceinline__ double u01_from_bits(uint32_t lo, uint32_t hi) {
+    const uint32_t mhi = 0x3FF00000u | (hi >> 12);
+    const uint32_t mlo = (hi << 20) | (lo >> 12);
+    const double d = __hiloint2double((int)mhi, (int)mlo);  // 1 + a*2^-52
+    return (d - 1.0) + 0x1p-53;
+}
+
+}  // namespace mcg

@@ -1,0 +1,233 @@
+"""PathEngine: explicit-parameter host API over the C ABI (include/mcgpu.h).
+
+This is the (seed, S0, K, r, sigma | xi, H, eta, T, N_paths, N_steps) interface the north-star
+names; the reference hard-codes these as literals (SURVEY.md section 5 "Config / flags").
+Device memory is owned by libmcgpu; torch is only used (optionally) for the stream and for the
+cross-rank all-reduce.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Callable, Optional, Tuple
+
+import numpy as np
+
+from . import _native as N
+from ._native import McgError, check
+
+
+class _DevView:
+    """Raw device pointer exposed through __cuda_array_interface__ (zero-copy torch view)."""
+
+    def __init__(self, ptr: int, count: int):
+        self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (ptr, False),
+                                         "version": 3, "strides": None}
+
+
+class PathMatrix:
+    """Device-resident (n_steps+1) x n_paths price matrix, step-major (mcg_paths*)."""
+
+    def __init__(self, engine: "PathEngine", handle: C.c_void_p):
+        self._engine = engine
+        self._h = handle
+        n_paths, n_steps, ld, ptr = C.c_int64(), C.c_int(), C.c_int64(), C.c_void_p()
+        check(engine._L.mcg_paths_info(handle, C.byref(n_paths), C.byref(n_steps), C.byref(ld), C.byref(ptr)))
+        self.n_paths, self.n_steps, self.ld = n_paths.value, n_steps.value, ld.value
+        self.device_ptr = ptr.value or 0
+
+    @property
+    def nbytes_algorithmic(self) -> int:
+        """8*(n_steps+1) bytes per path: the figure the HBM-write roofline is computed from."""
+        return 8 * (self.n_steps + 1) * self.n_paths
+
+    def to_host(self) -> np.ndarray:
+        """Reference layout: [n_paths][n_steps+1] (what GenerateStockPricePaths returns)."""
+        self._alive()
+        out = np.empty((self.n_paths, self.n_steps + 1), dtype=np.float64)
+        check(self._engine._L.mcg_paths_to_host(self._h, out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out
+
+    def to_host_step_major(self) -> np.ndarray:
+        """As stored: [n_steps+1][n_paths]."""
+        self._alive()
+        out = np.empty((self.n_steps + 1, self.n_paths), dtype=np.float64)
+        check(self._engine._L.mcg_paths_to_host_step_major(self._h, out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out
+
+    def free(self) -> None:
+        if self._h is not None:
+            self._engine._L.mcg_paths_free(self._h)
+            self._h = None
+
+    def _alive(self):
+        if self._h is None:
+            raise McgError("PathMatrix already freed")
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class PathEngine:
+    """One context (device + stream + workspace); create one per process/GPU or per host thread."""
+
+    def __init__(self, device: int = 0, stream: Optional[int] = None):
+        self._L = N.load_library()
+        self._ctx = C.c_void_p()
+        check(self._L.mcg_init(C.byref(self._ctx), int(device), C.c_void_p(stream) if stream else None))
+        self._cb = None  # keep the ctypes callback alive
+        self.device = device
+
+    # -- lifecycle ------------------------------------------------------------------------------
+    def close(self) -> None:
+        if self._ctx:
+            self._L.mcg_finalize(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self) -> None:
+        check(self._L.mcg_synchronize(self._ctx))
+
+    def trim(self) -> None:
+        check(self._L.mcg_trim(self._ctx))
+
+    # -- collectives ----------------------------------------------------------------------------
+    def set_allreduce(self, fn: Optional[Callable[[int, int, int], None]]) -> None:
+        """fn(device_ptr, count, stream_handle) must sum `count` doubles in place over all ranks."""
+        if fn is None:
+            self._cb = None
+            check(self._L.mcg_set_allreduce(self._ctx, C.cast(None, N.ALLREDUCE_FN), None))
+            return
+
+        def _tramp(_user, buf, count, stream):
+            try:
+                fn(int(buf), int(count), int(stream or 0))
+                return 0
+            except Exception:  # never let an exception cross the C boundary
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        self._cb = N.ALLREDUCE_FN(_tramp)
+        check(self._L.mcg_set_allreduce(self._ctx, self._cb, None))
+
+    def use_torch_distributed(self, group=None) -> None:
+        """All-reduce through torch.distributed (backend "nccl" is RCCL on ROCm).  The ctx must run
+        on torch's current stream (PathEngine(stream=torch.cuda.current_stream().cuda_stream))."""
+        import torch
+        import torch.distributed as dist
+
+        def _ar(ptr: int, count: int, _stream: int) -> None:
+            t = torch.as_tensor(_DevView(ptr, count), device=torch.device("cuda", self.device))
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+
+        self.set_allreduce(_ar)
+
+    def init_rccl(self, rank: int, world: int, broadcast_bytes: Callable[[Optional[bytes]], bytes]) -> None:
+        """Built-in RCCL communicator.  broadcast_bytes(id_or_None) returns rank 0's 128-byte id on
+        every rank (e.g. via torch.distributed.broadcast_object_list)."""
+        uid = None
+        if rank == 0:
+            buf = C.create_string_buffer(128)
+            check(self._L.mcg_comm_unique_id(buf))
+            uid = buf.raw
+        uid = broadcast_bytes(uid)
+        check(self._L.mcg_comm_init_rank(self._ctx, uid, int(world), int(rank)))
+
+    # -- generation -----------------------------------------------------------------------------
+    def gbm(self, seed: int, S0: float, r: float, sigma: float, dt: float, n_steps: int, n_paths: int,
+            path_begin: int = 0, payoff: Optional[Tuple[float, bool]] = None) -> PathMatrix:
+        h = C.c_void_p()
+        if payoff is None:
+            check(self._L.mcg_paths_gbm(self._ctx, seed, S0, r, sigma, dt, n_steps, path_begin, n_paths, C.byref(h)))
+        else:
+            K, is_call = payoff
+            check(self._L.mcg_paths_gbm_payoff(self._ctx, seed, S0, r, sigma, dt, n_steps, path_begin, n_paths,
+                                               K, int(bool(is_call)), C.byref(h)))
+        return PathMatrix(self, h)
+
+    def rbergomi(self, seed: int, S0: float, r: float, xi: float, H: float, eta: float, rho: float, dt: float,
+                 n_steps: int, n_paths: int, path_begin: int = 0,
+                 payoff: Optional[Tuple[float, bool]] = None) -> PathMatrix:
+        h = C.c_void_p()
+        if payoff is None:
+            check(self._L.mcg_paths_rbergomi(self._ctx, seed, S0, r, xi, H, eta, rho, dt, n_steps, path_begin,
+                                             n_paths, C.byref(h)))
+        else:
+            K, is_call = payoff
+            check(self._L.mcg_paths_rbergomi_payoff(self._ctx, seed, S0, r, xi, H, eta, rho, dt, n_steps,
+                                                    path_begin, n_paths, K, int(bool(is_call)), C.byref(h)))
+        return PathMatrix(self, h)
+
+    def from_host(self, row_major: np.ndarray) -> PathMatrix:
+        """Upload [n_paths][n_steps+1] (the reference's pricePaths layout)."""
+        a = np.ascontiguousarray(row_major, dtype=np.float64)
+        if a.ndim != 2 or a.size == 0:
+            raise McgError("LSM::PredictOptionPrice: Empty pricePaths.", 6)
+        h = C.c_void_p()
+        check(self._L.mcg_paths_from_host(self._ctx, a.ctypes.data_as(C.POINTER(C.c_double)), a.shape[0],
+                                          a.shape[1], C.byref(h)))
+        return PathMatrix(self, h)
+
+    # -- pricing --------------------------------------------------------------------------------
+    def price_european(self, paths: PathMatrix, K: float, r: float, T: float, is_call: bool) -> Tuple[float, float]:
+        paths._alive()
+        m, se = C.c_double(), C.c_double()
+        check(self._L.mcg_price_european(self._ctx, paths._h, K, r, T, int(bool(is_call)), C.byref(m), C.byref(se)))
+        return m.value, se.value
+
+    def price_lsm(self, paths: PathMatrix, r: float, K: float, maturity: float, dt: float, is_call: bool,
+                  poly_order: int) -> Tuple[float, float]:
+        paths._alive()
+        m, se = C.c_double(), C.c_double()
+        check(self._L.mcg_price_lsm(self._ctx, paths._h, r, K, maturity, dt, int(bool(is_call)), int(poly_order),
+                                    C.byref(m), C.byref(se)))
+        return m.value, se.value
+
+    # -- measurement ----------------------------------------------------------------------------
+    def timing_enable(self, on: bool = True) -> None:
+        check(self._L.mcg_timing_enable(self._ctx, int(on)))
+
+    def timing_reset(self) -> None:
+        check(self._L.mcg_timing_reset(self._ctx))
+
+    def timing_get(self, kernel: int) -> Tuple[float, int]:
+        """(total device ms, launches) for one of _native.K_* since the last reset."""
+        ms, n = C.c_double(), C.c_int64()
+        check(self._L.mcg_timing_get(self._ctx, kernel, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+
+def estimate_params(hist) -> dict:
+    """Host-side estimators of the class API (RoughVolatility.cpp:324-331)."""
+    L = N.load_library()
+    h = np.ascontiguousarray(hist, dtype=np.float64)
+    out = np.empty(5)
+    check(L.mcg_estimate_params(h.ctypes.data_as(C.POINTER(C.c_double)), len(h), out.ctypes.data_as(C.POINTER(C.c_double))))
+    return dict(xi=out[0], H=out[1], eta=out[2], rho=out[3], S0=out[4])
+
+
+def rbergomi_weights(H: float, eta: float, dt: float, n_steps: int):
+    """(kappa[Mz], comp[n_steps]) -- the LDS-staged Volterra weights and compensator."""
+    L = N.load_library()
+    M = 1
+    while M < n_steps:
+        M *= 2
+    kappa, comp, mz = np.empty(M), np.empty(n_steps), C.c_int()
+    check(L.mcg_rbergomi_weights(H, eta, dt, n_steps, kappa.ctypes.data_as(C.POINTER(C.c_double)),
+                                 comp.ctypes.data_as(C.POINTER(C.c_double)), C.byref(mz)))
+    assert mz.value == M
+    return kappa, comp

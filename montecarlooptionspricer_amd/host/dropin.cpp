@@ -1,0 +1,158 @@
+// The reference's class API (include/mcgpu/dropin.hpp) on top of the C ABI, plus the
+// mcg_compat_* entry points that expose the same two calls to non-C++ hosts and to the tests.
+//
+//   RoughVolatility::GenerateStockPricePaths  <->  /root/reference/src/models/RoughVolatility.cpp:312-368
+//   LSM::PredictOptionPrice                   <->  /root/reference/src/models/LSMPricer.cpp:19-102
+#include <atomic>
+#include <cmath>
+#include <cstdlib>
+#include <limits>
+#include <random>
+#include <stdexcept>
+#include <string>
+
+#include "../../include/mcgpu/dropin.hpp"
+#include "../csrc/mcg_internal.hpp"
+
+namespace {
+
+// One lazily created context per host thread: the reference driver builds its pricer objects per
+// row inside an OpenMP region (PredictionGen.cpp:542-570), so construction must be free and calls
+// re-entrant.  The holder tears the ctx down when the thread exits.
+struct ThreadCtx {
+    mcg_ctx* ctx = nullptr;
+    ~ThreadCtx() {
+        if (ctx) mcg_finalize(ctx);
+    }
+    mcg_ctx* get() {
+        if (!ctx) {
+            int dev = 0;
+            if (const char* e = std::getenv("MCG_DEVICE")) dev = std::atoi(e);
+            if (mcg_init(&ctx, dev, nullptr) != MCG_OK) throw std::runtime_error(mcg_last_error());
+        }
+        return ctx;
+    }
+};
+thread_local ThreadCtx t_ctx;
+
+std::atomic<bool> g_seed_fixed{false};
+std::atomic<uint64_t> g_seed{0};
+
+uint64_t next_seed() {
+    if (g_seed_fixed.load()) return g_seed.load();
+    // the reference seeds from std::random_device on every call (RoughVolatility.cpp:239, :253)
+    std::random_device rd;
+    return ((uint64_t)rd() << 32) | rd();
+}
+
+struct PathsGuard {
+    mcg_paths* p = nullptr;
+    ~PathsGuard() { mcg_paths_free(p); }
+};
+
+[[noreturn]] void raise_last() { throw std::runtime_error(mcg_last_error()); }
+
+}  // namespace
+
+RoughVolatility::RoughVolatility() {}
+
+std::vector<std::vector<double>> RoughVolatility::GenerateStockPricePaths(
+    const std::vector<double>& historical_prices, int forward_steps, int path_num) {
+    if (historical_prices.size() < 2) throw std::runtime_error("Historical prices vector too small.");
+    if (forward_steps < 0 || path_num < 0)
+        throw std::length_error("RoughVolatility: negative forward_steps or path_num");
+
+    double p[5];
+    if (mcg_estimate_params(historical_prices.data(), historical_prices.size(), p) != MCG_OK) raise_last();
+    const double xi = p[0], H = p[1], eta = p[2], rho = p[3], S0 = p[4];
+    const double r = 0.04, dt = 1.0 / 252.0;  // RoughVolatility.cpp:321-326
+
+    std::vector<std::vector<double>> paths((size_t)path_num, std::vector<double>((size_t)forward_steps + 1, 0.0));
+    if (path_num == 0) return paths;
+    for (auto& row : paths) row[0] = S0;
+    if (forward_steps == 0) return paths;
+
+    // Degenerate estimates: the reference's arithmetic turns every step into NaN when rho is NaN
+    // (two-point history: 0/0 at :164) or when lambda is non-finite (H < 0 at t = 0, :233).
+    if (!(std::fabs(rho) <= 1.0) || !(H >= 0.0) || !std::isfinite(xi) || !std::isfinite(eta) || !(xi >= 0.0)) {
+        for (auto& row : paths)
+            for (size_t j = 1; j < row.size(); ++j) row[j] = std::numeric_limits<double>::quiet_NaN();
+        return paths;
+    }
+
+    mcg_ctx* ctx = t_ctx.get();
+    PathsGuard g;
+    if (mcg_paths_rbergomi(ctx, next_seed(), S0, r, xi, H, eta, rho, dt, forward_steps, 0, path_num, &g.p) != MCG_OK)
+        raise_last();
+    std::vector<double> flat((size_t)path_num * ((size_t)forward_steps + 1));
+    if (mcg_paths_to_host(g.p, flat.data()) != MCG_OK) raise_last();
+    const size_t cols = (size_t)forward_steps + 1;
+    for (size_t i = 0; i < (size_t)path_num; ++i) paths[i].assign(flat.begin() + i * cols, flat.begin() + (i + 1) * cols);
+    return paths;
+}
+
+double LSM::PredictOptionPrice(const std::vector<std::vector<double>>& pricePaths, double r, double strike,
+                               double maturity, double dt, bool isCall, int polyOrder) {
+    if (pricePaths.empty() || pricePaths[0].empty())
+        throw std::runtime_error("LSM::PredictOptionPrice: Empty pricePaths.");
+    if (polyOrder < 0 || polyOrder > 8) throw std::invalid_argument("LSM: polyOrder must be in [0, 8]");
+    const size_t N = pricePaths.size(), M = pricePaths[0].size();
+    std::vector<double> flat(N * M);
+    for (size_t i = 0; i < N; ++i) {
+        if (pricePaths[i].size() < M) throw std::runtime_error("LSM: Invalid path index in regression");
+        std::copy(pricePaths[i].begin(), pricePaths[i].begin() + M, flat.begin() + i * M);
+    }
+    mcg_ctx* ctx = t_ctx.get();
+    PathsGuard g;
+    if (mcg_paths_from_host(ctx, flat.data(), (int64_t)N, (int)M, &g.p) != MCG_OK) raise_last();
+    double price = 0.0;
+    if (mcg_price_lsm(ctx, g.p, r, strike, maturity, dt, isCall ? 1 : 0, polyOrder, &price, nullptr) != MCG_OK)
+        raise_last();
+    return price;
+}
+
+extern "C" {
+
+int mcg_compat_set_seed(uint64_t seed, int enabled) {
+    g_seed.store(seed);
+    g_seed_fixed.store(enabled != 0);
+    return MCG_OK;
+}
+
+int mcg_compat_generate_paths(const double* hist, size_t n, int forward_steps, int path_num, double* out) {
+    try {
+        std::vector<double> h;
+        if (hist && n) h.assign(hist, hist + n);
+        RoughVolatility rv;
+        auto m = rv.GenerateStockPricePaths(h, forward_steps, path_num);
+        if (!m.empty() && !out) return mcg::fail(MCG_ERR_INVALID, "out is NULL");
+        const size_t cols = (size_t)forward_steps + 1;
+        for (size_t i = 0; i < m.size(); ++i) std::copy(m[i].begin(), m[i].end(), out + i * cols);
+        return MCG_OK;
+    } catch (const std::exception& e) {
+        const std::string msg = e.what();
+        const int code = msg == "Historical prices vector too small." ? MCG_ERR_HISTORY_TOO_SMALL : MCG_ERR_INVALID;
+        return mcg::fail(code, "%s", msg.c_str());
+    }
+}
+
+int mcg_compat_lsm_price(const double* row_major, int64_t n_paths, int n_cols, double r, double strike,
+                         double maturity, double dt, int is_call, int poly_order, double* price) {
+    try {
+        std::vector<std::vector<double>> m;
+        if (row_major && n_paths > 0 && n_cols > 0) {
+            m.resize((size_t)n_paths);
+            for (int64_t i = 0; i < n_paths; ++i) m[i].assign(row_major + i * n_cols, row_major + (i + 1) * n_cols);
+        }
+        LSM lsm;
+        const double v = lsm.PredictOptionPrice(m, r, strike, maturity, dt, is_call != 0, poly_order);
+        if (price) *price = v;
+        return MCG_OK;
+    } catch (const std::exception& e) {
+        const std::string msg = e.what();
+        const int code = msg == "LSM::PredictOptionPrice: Empty pricePaths." ? MCG_ERR_EMPTY_PATHS : MCG_ERR_INVALID;
+        return mcg::fail(code, "%s", msg.c_str());
+    }
+}
+
+}  // extern "C"

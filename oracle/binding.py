@@ -1,0 +1,350 @@
+"""ctypes bindings for the parity oracle.  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module;
+the product package (montecarlooptionspricer_amd) never does.
+
+Two libraries:
+  * libmcgoracle.so  -- our CPU restatement (oracle/mcg_oracle.cpp), always buildable.
+  * _ref/libmcref.so -- the reference's own RoughVolatility.cpp compiled in place by
+                        oracle/Makefile (present when built in the dev container; travels to the
+                        GPU box as a prebuilt file, the reference sources do not).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_SO = os.path.join(HERE, "libmcgoracle.so")
+REF_SO = os.path.join(HERE, "_ref", "libmcref.so")
+
+_dp = C.POINTER(C.c_double)
+_u32p = C.POINTER(C.c_uint32)
+
+
+def _p(a):
+    return a.ctypes.data_as(_dp)
+
+
+def build(quiet: bool = True) -> None:
+    """(Re)build the oracle; builds _ref too when /root/reference is present."""
+    subprocess.run(["make", "-C", HERE], check=True,
+                   stdout=subprocess.DEVNULL if quiet else None)
+
+
+def have_ref() -> bool:
+    return os.path.exists(REF_SO)
+
+
+class Oracle:
+    """Our restatement (mcg_oracle.cpp)."""
+
+    def __init__(self):
+        if not os.path.exists(ORACLE_SO):
+            build()
+        L = C.CDLL(ORACLE_SO)
+        self.L = L
+        L.orc_log_returns.argtypes = [_dp, C.c_size_t, _dp]
+        L.orc_estimate_params.argtypes = [_dp, C.c_size_t, _dp]
+        L.orc_estimate_params.restype = C.c_int
+        L.orc_next_pow2.argtypes = [C.c_size_t]
+        L.orc_next_pow2.restype = C.c_size_t
+        L.orc_fft.argtypes = [_dp, C.c_size_t, C.c_int]
+        L.orc_lambda.argtypes = [C.c_int, C.c_double, C.c_double, _dp]
+        L.orc_phi.argtypes = [_dp, C.c_size_t, _dp]
+        L.orc_phi.restype = C.c_size_t
+        L.orc_fractional_gaussian.argtypes = [_dp, _dp, C.c_size_t, C.c_double, C.c_double, _dp]
+        L.orc_forward_variance.argtypes = [_dp, C.c_size_t, C.c_double, C.c_double, C.c_double,
+                                           C.c_double, _dp]
+        L.orc_step_prices.argtypes = [C.c_double, C.c_double, C.c_double, C.c_double, _dp, _dp, _dp,
+                                      C.c_size_t, _dp]
+        L.orc_payoff.argtypes = [C.c_int, C.c_double, C.c_double]
+        L.orc_payoff.restype = C.c_double
+        L.orc_generate_paths_mt.argtypes = [C.c_double] * 6 + [C.c_int, C.c_long, C.c_uint64, _dp, _dp]
+        L.orc_generate_paths_mt.restype = C.c_int
+        L.orc_generate_paths_mt_hist.argtypes = [_dp, C.c_size_t, C.c_int, C.c_long, C.c_uint64, _dp]
+        L.orc_generate_paths_mt_hist.restype = C.c_int
+        L.orc_generate_paths_mt_omp.argtypes = [C.c_double] * 6 + [C.c_int, C.c_long, C.c_int,
+                                                                  C.c_uint64, _dp]
+        L.orc_generate_paths_mt_omp.restype = C.c_int
+        L.orc_philox4x32_10.argtypes = [_u32p, _u32p, _u32p]
+        L.orc_normal_pair.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, _dp]
+        L.orc_paths_gbm.argtypes = [C.c_uint64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int,
+                                    C.c_uint64, C.c_long, _dp, C.c_size_t]
+        L.orc_paths_gbm.restype = C.c_int
+        L.orc_rbergomi_weights.argtypes = [C.c_double, C.c_double, C.c_double, C.c_int, _dp, _dp]
+        L.orc_rbergomi_weights.restype = C.c_size_t
+        L.orc_paths_rbergomi.argtypes = [C.c_uint64] + [C.c_double] * 7 + [C.c_int, C.c_uint64, C.c_long,
+                                                                          _dp, C.c_size_t, _dp]
+        L.orc_paths_rbergomi.restype = C.c_int
+        L.orc_price_european.argtypes = [_dp, C.c_size_t, C.c_size_t, C.c_long, C.c_int, C.c_double,
+                                         C.c_double, C.c_double, C.c_int, _dp, _dp]
+        L.orc_price_european.restype = C.c_int
+        L.orc_lsm_price.argtypes = [_dp, C.c_size_t, C.c_size_t, C.c_long, C.c_int, C.c_double, C.c_double,
+                                    C.c_double, C.c_double, C.c_int, C.c_int, _dp, _dp]
+        L.orc_lsm_price.restype = C.c_int
+        L.orc_num_threads.restype = C.c_int
+
+    # -- estimators / spectral ------------------------------------------------------------------
+    def log_returns(self, prices):
+        p = np.ascontiguousarray(prices, dtype=np.float64)
+        out = np.empty(max(len(p) - 1, 0))
+        self.L.orc_log_returns(_p(p), len(p), _p(out))
+        return out
+
+    def estimate_params(self, hist):
+        h = np.ascontiguousarray(hist, dtype=np.float64)
+        out = np.empty(5)
+        rc = self.L.orc_estimate_params(_p(h), len(h), _p(out))
+        if rc:
+            raise RuntimeError("Historical prices vector too small.")
+        return dict(xi=out[0], H=out[1], eta=out[2], rho=out[3], S0=out[4])
+
+    def next_pow2(self, n):
+        return int(self.L.orc_next_pow2(n))
+
+    def fft(self, z, inv):
+        z = np.asarray(z, dtype=np.complex128)
+        buf = np.ascontiguousarray(np.stack([z.real, z.imag], axis=1))
+        self.L.orc_fft(_p(buf), len(z), inv)
+        return buf[:, 0] + 1j * buf[:, 1]
+
+    def lam(self, steps, H, dt=1.0 / 252.0):
+        out = np.empty(steps + 1)
+        self.L.orc_lambda(steps, H, dt, _p(out))
+        return out
+
+    def phi(self, lam):
+        lam = np.ascontiguousarray(lam, dtype=np.float64)
+        M = self.next_pow2(len(lam))
+        buf = np.empty((M, 2))
+        self.L.orc_phi(_p(lam), len(lam), _p(buf))
+        return buf[:, 0] + 1j * buf[:, 1]
+
+    def fractional_gaussian(self, phi, Z, H, eta):
+        phi = np.asarray(phi, dtype=np.complex128)
+        Z = np.asarray(Z, dtype=np.complex128)
+        pb = np.ascontiguousarray(np.stack([phi.real, phi.imag], axis=1))
+        zb = np.ascontiguousarray(np.stack([Z.real, Z.imag], axis=1))
+        X = np.empty(len(Z))
+        self.L.orc_fractional_gaussian(_p(pb), _p(zb), len(Z), H, eta, _p(X))
+        return X
+
+    def forward_variance(self, X, xi, H, eta, dt=1.0 / 252.0):
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        v = np.empty(len(X))
+        self.L.orc_forward_variance(_p(X), len(X), dt, xi, H, eta, _p(v))
+        return v
+
+    def step_prices(self, S0, r, dt, rho, v, W1, W2):
+        v = np.ascontiguousarray(v, dtype=np.float64)
+        W1 = np.ascontiguousarray(W1, dtype=np.float64)
+        W2 = np.ascontiguousarray(W2, dtype=np.float64)
+        S = np.empty(len(v) + 1)
+        self.L.orc_step_prices(S0, r, dt, rho, _p(v), _p(W1), _p(W2), len(v), _p(S))
+        return S
+
+    def payoff(self, is_call, s, k):
+        return float(self.L.orc_payoff(int(bool(is_call)), s, k))
+
+    # -- generators -----------------------------------------------------------------------------
+    def generate_paths_mt(self, S0, r, xi, H, eta, rho, steps, paths, seed, want_intvar=False):
+        """Reference-faithful generator with explicit seed.  Returns path-major [paths][steps+1]."""
+        out = np.empty((paths, steps + 1))
+        iv = np.empty(paths) if want_intvar else None
+        rc = self.L.orc_generate_paths_mt(S0, r, xi, H, eta, rho, steps, paths, seed, _p(out),
+                                          _p(iv) if want_intvar else None)
+        if rc:
+            raise RuntimeError("orc_generate_paths_mt failed")
+        return (out, iv) if want_intvar else out
+
+    def generate_paths_mt_hist(self, hist, steps, paths, seed):
+        h = np.ascontiguousarray(hist, dtype=np.float64)
+        out = np.empty((paths, steps + 1))
+        rc = self.L.orc_generate_paths_mt_hist(_p(h), len(h), steps, paths, seed, _p(out))
+        if rc:
+            raise RuntimeError("Historical prices vector too small.")
+        return out
+
+    def generate_paths_mt_omp(self, S0, r, xi, H, eta, rho, steps, total_paths, chunk, seed):
+        s = C.c_double(0.0)
+        th = self.L.orc_generate_paths_mt_omp(S0, r, xi, H, eta, rho, steps, total_paths, chunk, seed,
+                                              C.byref(s))
+        return th, s.value
+
+    def philox(self, ctr, key):
+        c = (C.c_uint32 * 4)(*ctr)
+        k = (C.c_uint32 * 2)(*key)
+        o = (C.c_uint32 * 4)()
+        self.L.orc_philox4x32_10(c, k, o)
+        return [int(x) for x in o]
+
+    def normal_pair(self, seed, path, block, stream):
+        z = np.empty(2)
+        self.L.orc_normal_pair(seed, path, block, stream, _p(z))
+        return z
+
+    def paths_gbm(self, seed, S0, r, sigma, dt, steps, path_begin, n_paths):
+        """Philox-mode GBM; returns step-major [steps+1][n_paths]."""
+        out = np.empty((steps + 1, n_paths))
+        rc = self.L.orc_paths_gbm(seed, S0, r, sigma, dt, steps, path_begin, n_paths, _p(out), n_paths)
+        if rc:
+            raise RuntimeError("orc_paths_gbm failed")
+        return out
+
+    def rbergomi_weights(self, H, eta, dt, steps):
+        M = self.next_pow2(steps)
+        kappa = np.empty(M)
+        comp = np.empty(steps)
+        self.L.orc_rbergomi_weights(H, eta, dt, steps, _p(kappa), _p(comp))
+        return kappa, comp
+
+    def paths_rbergomi(self, seed, S0, r, xi, H, eta, rho, dt, steps, path_begin, n_paths, want_X=False):
+        out = np.empty((steps + 1, n_paths))
+        X = np.empty((n_paths, steps)) if want_X else None
+        rc = self.L.orc_paths_rbergomi(seed, S0, r, xi, H, eta, rho, dt, steps, path_begin, n_paths,
+                                       _p(out), n_paths, _p(X) if want_X else None)
+        if rc:
+            raise RuntimeError("orc_paths_rbergomi failed")
+        return (out, X) if want_X else out
+
+    # -- pricing --------------------------------------------------------------------------------
+    def price_european(self, paths, K, r, T, is_call, step_major=True):
+        a = np.ascontiguousarray(paths, dtype=np.float64)
+        if step_major:
+            n_cols, n_paths = a.shape
+            ps, ss = 1, n_paths
+        else:
+            n_paths, n_cols = a.shape
+            ps, ss = n_cols, 1
+        m, se = C.c_double(), C.c_double()
+        rc = self.L.orc_price_european(_p(a), ps, ss, n_paths, n_cols - 1, K, r, T, int(bool(is_call)),
+                                       C.byref(m), C.byref(se))
+        if rc:
+            raise RuntimeError("orc_price_european failed")
+        return m.value, se.value
+
+    def lsm_price(self, paths, r, K, maturity, dt, is_call, poly_order, step_major=True, want_v0=False):
+        a = np.ascontiguousarray(paths, dtype=np.float64)
+        if a.size == 0:
+            raise RuntimeError("LSM::PredictOptionPrice: Empty pricePaths.")
+        if step_major:
+            n_cols, n_paths = a.shape
+            ps, ss = 1, n_paths
+        else:
+            n_paths, n_cols = a.shape
+            ps, ss = n_cols, 1
+        price = C.c_double()
+        v0 = np.empty(n_paths) if want_v0 else None
+        rc = self.L.orc_lsm_price(_p(a), ps, ss, n_paths, n_cols, r, K, maturity, dt, int(bool(is_call)),
+                                  poly_order, C.byref(price), _p(v0) if want_v0 else None)
+        if rc == 1:
+            raise RuntimeError("LSM::PredictOptionPrice: Empty pricePaths.")
+        if rc:
+            raise RuntimeError("orc_lsm_price failed rc=%d" % rc)
+        return (price.value, v0) if want_v0 else price.value
+
+    def num_threads(self):
+        return int(self.L.orc_num_threads())
+
+
+class Reference:
+    """The reference's own compiled path engine (oracle/_ref/libmcref.so)."""
+
+    def __init__(self):
+        if not os.path.exists(REF_SO):
+            raise FileNotFoundError(REF_SO + " missing (built only where /root/reference exists)")
+        L = C.CDLL(REF_SO)
+        self.L = L
+        L.ref_estimators.argtypes = [_dp, C.c_size_t, _dp, _dp]
+        L.ref_estimators.restype = C.c_int
+        L.ref_next_pow2.argtypes = [C.c_size_t]
+        L.ref_next_pow2.restype = C.c_size_t
+        L.ref_fft.argtypes = [_dp, C.c_size_t, C.c_int]
+        L.ref_lambda.argtypes = [C.c_int, C.c_double, C.c_double, _dp]
+        L.ref_phi.argtypes = [_dp, C.c_size_t, C.c_double, _dp]
+        L.ref_phi.restype = C.c_size_t
+        L.ref_fractional_gaussian.argtypes = [_dp, C.c_size_t, _dp, C.c_size_t, C.c_double, C.c_double, _dp]
+        L.ref_forward_variance.argtypes = [_dp, C.c_size_t, C.c_double, C.c_double, C.c_double, C.c_double, _dp]
+        L.ref_payoff.argtypes = [C.c_int, C.c_double, C.c_double]
+        L.ref_payoff.restype = C.c_double
+        L.ref_generate_paths.argtypes = [_dp, C.c_size_t, C.c_int, C.c_int, _dp, C.c_char_p, C.c_size_t]
+        L.ref_generate_paths.restype = C.c_int
+        L.ref_generate_paths_omp.argtypes = [_dp, C.c_size_t, C.c_int, C.c_long, C.c_int, _dp]
+        L.ref_generate_paths_omp.restype = C.c_int
+
+    def estimators(self, hist):
+        h = np.ascontiguousarray(hist, dtype=np.float64)
+        rets = np.empty(max(len(h) - 1, 0))
+        out = np.empty(5)
+        rc = self.L.ref_estimators(_p(h), len(h), _p(rets), _p(out))
+        if rc:
+            raise RuntimeError("Historical prices vector too small.")
+        return rets, dict(xi=out[0], H=out[1], eta=out[2], rho=out[3], S0=out[4])
+
+    def next_pow2(self, n):
+        return int(self.L.ref_next_pow2(n))
+
+    def fft(self, z, inv):
+        z = np.asarray(z, dtype=np.complex128)
+        buf = np.ascontiguousarray(np.stack([z.real, z.imag], axis=1))
+        self.L.ref_fft(_p(buf), len(z), inv)
+        return buf[:, 0] + 1j * buf[:, 1]
+
+    def lam(self, steps, H, dt=1.0 / 252.0):
+        out = np.empty(steps + 1)
+        self.L.ref_lambda(steps, H, dt, _p(out))
+        return out
+
+    def phi(self, lam, H):
+        lam = np.ascontiguousarray(lam, dtype=np.float64)
+        M = self.next_pow2(len(lam))
+        buf = np.empty((M, 2))
+        self.L.ref_phi(_p(lam), len(lam), H, _p(buf))
+        return buf[:, 0] + 1j * buf[:, 1]
+
+    def fractional_gaussian(self, phi, Z, H, eta):
+        phi = np.asarray(phi, dtype=np.complex128)
+        Z = np.asarray(Z, dtype=np.complex128)
+        pb = np.ascontiguousarray(np.stack([phi.real, phi.imag], axis=1))
+        zb = np.ascontiguousarray(np.stack([Z.real, Z.imag], axis=1))
+        X = np.empty(len(Z))
+        self.L.ref_fractional_gaussian(_p(pb), len(phi), _p(zb), len(Z), H, eta, _p(X))
+        return X
+
+    def forward_variance(self, X, xi, H, eta, dt=1.0 / 252.0):
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        v = np.empty(len(X))
+        self.L.ref_forward_variance(_p(X), len(X), dt, xi, H, eta, _p(v))
+        return v
+
+    def payoff(self, is_call, s, k):
+        return float(self.L.ref_payoff(int(bool(is_call)), s, k))
+
+    def generate_paths(self, hist, steps, paths):
+        h = np.ascontiguousarray(hist, dtype=np.float64)
+        out = np.empty((paths, steps + 1))
+        err = C.create_string_buffer(256)
+        rc = self.L.ref_generate_paths(_p(h), len(h), steps, paths, _p(out), err, 256)
+        if rc:
+            raise RuntimeError(err.value.decode())
+        return out
+
+    def generate_paths_omp(self, hist, steps, total_paths, chunk):
+        h = np.ascontiguousarray(hist, dtype=np.float64)
+        s = C.c_double(0.0)
+        th = self.L.ref_generate_paths_omp(_p(h), len(h), steps, total_paths, chunk, C.byref(s))
+        return th, s.value
+
+
+def synthetic_history(n: int, seed: int = 42, s0: float = 100.0, mu: float = 0.05,
+                      sigma: float = 0.2) -> np.ndarray:
+    """Deterministic GBM price history for fixtures (numpy MT19937 via RandomState -- stable)."""
+    rs = np.random.RandomState(seed)
+    dt = 1.0 / 252.0
+    z = rs.standard_normal(max(n - 1, 0))
+    lr = (mu - 0.5 * sigma * sigma) * dt + sigma * np.sqrt(dt) * z
+    return s0 * np.exp(np.concatenate([[0.0], np.cumsum(lr)]))

@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the COMPILED REFERENCE (oracle/_ref/libmcref.so).
+
+TEST INFRASTRUCTURE ONLY.  Run in the dev container (where /root/reference exists):
+
+    make -C oracle && python oracle/gen_golden.py
+
+The reference has no tests and no golden vectors of its own, so every
+deterministic function on the hot path is pinned by calling the reference's own compiled code on
+fixed inputs and storing inputs + outputs bit-exactly (float64 .npz).  The fixtures are data only:
+no reference source text is stored.  tests/test_oracle_golden.py then requires our restatement
+(oracle/mcg_oracle.cpp) to reproduce them.
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle.binding import Reference, synthetic_history  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def main() -> None:
+    os.makedirs(OUT, exist_ok=True)
+    ref = Reference()
+
+    # (1) estimators: RoughVolatility.cpp:126-169 on three synthetic histories.
+    est = {}
+    for n in (2, 3, 64, 1001):
+        h = synthetic_history(n, seed=42, s0=100.0, mu=0.05, sigma=0.2)
+        rets, p = ref.estimators(h)
+        est[f"hist_{n}"] = h
+        est[f"rets_{n}"] = rets
+        est[f"params_{n}"] = np.array([p["xi"], p["H"], p["eta"], p["rho"], p["S0"]])
+    # a history with a strong leverage pattern so rho < 0 comes out of the estimator itself
+    h = synthetic_history(400, seed=7, s0=50.0, mu=0.0, sigma=0.35)
+    h[1::7] *= 0.97
+    rets, p = ref.estimators(h)
+    est["hist_lev"] = h
+    est["rets_lev"] = rets
+    est["params_lev"] = np.array([p["xi"], p["H"], p["eta"], p["rho"], p["S0"]])
+    np.savez(os.path.join(OUT, "estimators.npz"), **est)
+
+    # (2)-(4) lambda, phi, fractionalGaussian, forwardVariance: RoughVolatility.cpp:212-309.
+    spec = {}
+    shapes = [(252, 0.1), (512, 0.1), (7, 0.57), (252, 0.57), (50, 0.3), (1, 0.25), (64, 0.05)]
+    for steps, H in shapes:
+        tag = f"s{steps}_H{str(H).replace('.', 'p')}"
+        lam = ref.lam(steps, H)
+        phi = ref.phi(lam, H)
+        k = np.arange(steps, dtype=np.float64)
+        Z = np.cos(k) + 1j * np.sin(2.0 * k)           # hand-made, deterministic "Gaussians"
+        eta, xi = 1.9, 0.04
+        X = ref.fractional_gaussian(phi, Z, H, eta)
+        v = ref.forward_variance(X, xi, H, eta)
+        spec[f"{tag}_lam"] = lam
+        spec[f"{tag}_phi"] = phi
+        spec[f"{tag}_Z"] = Z
+        spec[f"{tag}_X"] = X
+        spec[f"{tag}_v"] = v
+    spec["shapes"] = np.array(shapes)
+    spec["eta_xi"] = np.array([1.9, 0.04])
+    np.savez(os.path.join(OUT, "spectral.npz"), **spec)
+
+    # (5) the FFT itself, both directions (RoughVolatility.cpp:171-202), plus nextPowerOfTwo.
+    fft = {}
+    rs = np.random.RandomState(123)
+    for n in (1, 2, 8, 64, 256):
+        z = rs.standard_normal(n) + 1j * rs.standard_normal(n)
+        fft[f"in_{n}"] = z
+        fft[f"fwd_{n}"] = ref.fft(z, 1)
+        fft[f"inv_{n}"] = ref.fft(z, -1)
+    ns = np.array([0, 1, 2, 3, 4, 5, 7, 8, 9, 252, 253, 256, 257, 512, 513, 1000])
+    fft["np2_in"] = ns
+    fft["np2_out"] = np.array([ref.next_pow2(int(n)) for n in ns])
+    np.savez(os.path.join(OUT, "fft.npz"), **fft)
+
+    # (6) PayoffFunction table (include/core/common.h:8-14).
+    s = np.array([0.0, 50.0, 99.999999, 100.0, 100.000001, 150.0, 1e-300, 1e300])
+    k = np.array([100.0, 100.0, 100.0, 100.0, 100.0, 100.0, 1.0, 1.0])
+    pay = {"S": s, "K": k,
+           "call": np.array([ref.payoff(True, a, b) for a, b in zip(s, k)]),
+           "put": np.array([ref.payoff(False, a, b) for a, b in zip(s, k)])}
+    np.savez(os.path.join(OUT, "payoff.npz"), **pay)
+    print("golden fixtures written to", OUT)
+    for f in sorted(os.listdir(OUT)):
+        print("  ", f, os.path.getsize(os.path.join(OUT, f)), "bytes")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,156 @@
+// TEST INFRASTRUCTURE ONLY -- never linked into, imported by, or executed from the product path.
+//
+// C-callable harness around the *compiled reference* path engine.  It is built by
+// oracle/Makefile from the reference sources where they lie (/root/reference/src/models/
+// RoughVolatility.cpp, compiled in place, nothing copied) into oracle/_ref/libmcref.so.
+// Purpose: (1) generate the golden vectors under tests/golden/ (oracle/gen_golden.py),
+// (2) validate oracle/mcg_oracle.cpp (our CPU restatement), (3) serve as the
+// cpu_baseline ("kind": "reference") that bench.py times on the GPU box's host cores.
+//
+// The reference keeps its numeric helpers private (include/models/RoughVolatility.h:21-53);
+// the harness reaches them by pre-including the std headers the class header needs and then
+// re-reading the class header with `private` spelled `public`.
+#include <algorithm>
+#include <cmath>
+#include <complex>
+#include <cstddef>
+#include <cstring>
+#include <stdexcept>
+#include <vector>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define private public
+#include "models/RoughVolatility.h"
+#undef private
+#include "core/common.h"
+
+namespace {
+using cvec = std::vector<std::complex<double>>;
+
+cvec unpack(const double* reim, size_t n) {
+    cvec v(n);
+    for (size_t i = 0; i < n; ++i) v[i] = std::complex<double>(reim[2 * i], reim[2 * i + 1]);
+    return v;
+}
+void pack(const cvec& v, double* reim) {
+    for (size_t i = 0; i < v.size(); ++i) {
+        reim[2 * i] = v[i].real();
+        reim[2 * i + 1] = v[i].imag();
+    }
+}
+}  // namespace
+
+extern "C" {
+
+// RoughVolatility.cpp:126-169, :324-331.  out = {xi, H, eta, rho, S0}; rets gets n-1 values.
+int ref_estimators(const double* hist, size_t n, double* rets_out, double* out5) {
+    if (n < 2) return 1;
+    RoughVolatility rv;
+    std::vector<double> h(hist, hist + n);
+    std::vector<double> rets = rv.logReturns(h);
+    if (rets_out) std::copy(rets.begin(), rets.end(), rets_out);
+    const double dt = 1.0 / 252.0;
+    out5[0] = rv.estimateXi(rets, dt);
+    out5[1] = rv.estimateH(rets);
+    out5[2] = rv.estimateEta(rets, out5[1]);
+    out5[3] = rv.estimateRho(rets);
+    out5[4] = h.back();
+    return 0;
+}
+
+size_t ref_next_pow2(size_t n) { return RoughVolatility::nextPowerOfTwo(n); }
+
+// RoughVolatility.cpp:171-202; interleaved re/im, in place.
+void ref_fft(double* reim, size_t n, int inv) {
+    RoughVolatility rv;
+    cvec a = unpack(reim, n);
+    rv.fft(a, inv);
+    pack(a, reim);
+}
+
+// RoughVolatility.cpp:227-236 on the grid of :337-340 (t_i = i*dt, i = 0..steps).
+void ref_lambda(int steps, double H, double dt, double* lam_out) {
+    RoughVolatility rv;
+    std::vector<double> grid(steps + 1);
+    for (size_t i = 0; i <= (size_t)steps; ++i) grid[i] = i * dt;
+    std::vector<double> lam = rv.rbergomiLambda(grid, H);
+    std::copy(lam.begin(), lam.end(), lam_out);
+}
+
+// RoughVolatility.cpp:212-225.  Returns M_phi; phi_out needs 2*nextpow2(n) doubles.
+size_t ref_phi(const double* lam, size_t n, double H, double* phi_out) {
+    RoughVolatility rv;
+    cvec phi = rv.rbergomiPhi(std::vector<double>(lam, lam + n), H);
+    pack(phi, phi_out);
+    return phi.size();
+}
+
+// RoughVolatility.cpp:264-292.  Z has `steps` complex entries, X_out `steps` doubles.
+void ref_fractional_gaussian(const double* phi, size_t mphi, const double* Z, size_t steps,
+                             double H, double eta, double* X_out) {
+    RoughVolatility rv;
+    std::vector<double> X = rv.fractionalGaussian(unpack(phi, mphi), unpack(Z, steps), H, eta);
+    std::copy(X.begin(), X.end(), X_out);
+}
+
+// RoughVolatility.cpp:294-309.
+void ref_forward_variance(const double* X, size_t steps, double dt, double xi, double H, double eta,
+                          double* v_out) {
+    RoughVolatility rv;
+    std::vector<double> grid(steps + 1);
+    for (size_t i = 0; i <= steps; ++i) grid[i] = i * dt;
+    std::vector<double> v = rv.forwardVariance(std::vector<double>(X, X + steps), grid, xi, H, eta);
+    std::copy(v.begin(), v.end(), v_out);
+}
+
+double ref_payoff(int is_call, double s, double k) { return PayoffFunction(is_call != 0, s, k); }
+
+// RoughVolatility.cpp:312-368 (unseeded: std::random_device).  out is path-major
+// [paths][steps+1], exactly the reference's return layout.  Returns 0, or 1 when the reference
+// throws ("Historical prices vector too small.", :317-319) with the message in err.
+int ref_generate_paths(const double* hist, size_t n, int steps, int paths, double* out, char* err,
+                       size_t errlen) {
+    try {
+        RoughVolatility rv;
+        auto m = rv.GenerateStockPricePaths(std::vector<double>(hist, hist + n), steps, paths);
+        for (size_t i = 0; i < m.size(); ++i)
+            std::memcpy(out + i * (size_t)(steps + 1), m[i].data(), sizeof(double) * (steps + 1));
+        return 0;
+    } catch (const std::exception& e) {
+        if (err && errlen) {
+            std::strncpy(err, e.what(), errlen - 1);
+            err[errlen - 1] = 0;
+        }
+        return 1;
+    }
+}
+
+// CPU baseline: the reference generator run the way the reference parallelises it --
+// independent GenerateStockPricePaths calls under `omp parallel for schedule(dynamic)`
+// (src/core/PredictionGen.cpp:542-546), one chunk of `chunk` paths per call.  Only the terminal
+// column is kept (sum of S_T for a sanity check), so the baseline does not need paths*steps of
+// host memory.  Returns the number of threads used; *sum_ST gets sum of S_T over all paths.
+int ref_generate_paths_omp(const double* hist, size_t n, int steps, long total_paths, int chunk,
+                           double* sum_ST) {
+    std::vector<double> h(hist, hist + n);
+    long n_chunks = (total_paths + chunk - 1) / chunk;
+    double acc = 0.0;
+    int threads = 1;
+#ifdef _OPENMP
+    threads = omp_get_max_threads();
+#endif
+#pragma omp parallel for schedule(dynamic) reduction(+ : acc)
+    for (long c = 0; c < n_chunks; ++c) {
+        long lo = c * (long)chunk;
+        int cnt = (int)std::min<long>(chunk, total_paths - lo);
+        RoughVolatility rv;
+        auto m = rv.GenerateStockPricePaths(h, steps, cnt);
+        for (auto& p : m) acc += p.back();
+    }
+    *sum_ST = acc;
+    return threads;
+}
+
+}  // extern "C"

@@ -1,0 +1,83 @@
+"""CPU-side checks of the drop-in boundary: libmcgpu.so loads, exports every symbol include/mcgpu.h
+declares, and fails LOUDLY (no CPU fallback) when no GPU is present.  No compute calls here."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+import montecarlooptionspricer_amd as mc
+from montecarlooptionspricer_amd import _native
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "mcgpu.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = set(re.findall(r"\b(mcg_[a-z0-9_]+)\s*\(", src))
+    names.discard("mcg_allreduce_fn")
+    return sorted(names)
+
+
+def test_every_declared_symbol_is_exported():
+    L = mc.load_library()
+    names = _declared()
+    assert len(names) >= 25
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, missing
+
+
+def test_version_and_error_channel():
+    L = mc.load_library()
+    assert b"gfx950" in L.mcg_version()
+    assert L.mcg_paths_free(None) == 0          # free(NULL) is a no-op
+    assert L.mcg_timing_enable(None, 1) != 0     # NULL ctx is an error, with a message
+    assert b"NULL" in L.mcg_last_error()
+
+
+def test_host_only_entry_points_work_without_gpu():
+    """a2/a3 are host work: estimators and Volterra weights must run on a CPU-only box."""
+    import numpy as np
+    from montecarlooptionspricer_amd.engine import estimate_params, rbergomi_weights
+    p = estimate_params(100.0 * np.exp(np.cumsum(0.01 * np.sin(np.arange(300.0)))))
+    assert np.isfinite(p["xi"]) and p["S0"] > 0
+    kappa, comp = rbergomi_weights(0.1, 1.9, 1.0 / 252.0, 252)
+    assert kappa.shape == (256,) and comp.shape == (252,) and comp[0] == 0.0
+    with pytest.raises(mc.McgError, match="Historical prices vector too small."):
+        estimate_params([1.0])
+
+
+def _no_gpu():
+    L = mc.load_library()
+    n = C.c_int()
+    L.mcg_device_count(C.byref(n))
+    return n.value == 0
+
+
+@pytest.mark.skipif(not _no_gpu(), reason="this check is for GPU-less hosts")
+def test_no_silent_cpu_fallback():
+    with pytest.raises(mc.McgError, match="no CPU fallback"):
+        mc.PathEngine()
+    with pytest.raises(mc.McgError):
+        mc.RoughVolatility().GenerateStockPricePaths([100.0, 101.0, 102.0], 4, 2)
+    with pytest.raises(mc.McgError):
+        mc.LSM().PredictOptionPrice([[100.0, 99.0], [100.0, 101.0]], 0.04, 100.0, 1.0, 0.5, False, 2)
+    # the reference's own error conditions are still reported first, GPU or not
+    with pytest.raises(mc.McgError, match="Historical prices vector too small."):
+        mc.RoughVolatility().GenerateStockPricePaths([100.0], 4, 2)
+    with pytest.raises(mc.McgError, match="LSM::PredictOptionPrice: Empty pricePaths."):
+        mc.LSM().PredictOptionPrice([], 0.04, 100.0, 1.0, 0.5, False, 2)
+
+
+def test_product_never_touches_the_oracle():
+    """The product tree must not reference oracle/ in any form."""
+    pkg = os.path.join(ROOT, "montecarlooptionspricer_amd")
+    for base, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h")):
+                txt = open(os.path.join(base, f), errors="ignore").read()
+                for needle in ("oracle/", "import oracle", "from oracle", "mcgoracle", "mcref", "orc_"):
+                    assert needle not in txt, (os.path.join(base, f), needle)
+    out = os.popen(f"ldd {_native.lib_path()}").read()
+    assert "oracle" not in out and "mcref" not in out

@@ -1,0 +1,313 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI,
+against the CPU oracle on the same seeded inputs.
+
+Tolerances (all arithmetic is binary64):
+  * path values, GPU vs oracle "philox" mode (same draws, libm vs device log/sincos/exp):
+      GBM       rel 1e-11   (252 steps x a few ulp each)
+      rBergomi  rel 1e-9    (plus a 256..512-term FMA chain per step)
+  * prices vs closed forms / independent samples: |z| <= 2 MC standard errors (north-star bar)
+  * LSM given identical paths (deterministic): rel 1e-8
+  * layout conversions, sharding by path_begin: bit-exact
+"""
+import math
+
+import numpy as np
+import pytest
+
+import montecarlooptionspricer_amd as mc
+from oracle.binding import Oracle, synthetic_history
+
+pytestmark = pytest.mark.gpu
+
+SEED = 20251031
+DT = 1.0 / 252.0
+
+
+@pytest.fixture(scope="module")
+def eng():
+    e = mc.PathEngine(0)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def orc():
+    return Oracle()
+
+
+def bs_price(S0, K, r, sigma, T, call=True):
+    d1 = (math.log(S0 / K) + (r + 0.5 * sigma * sigma) * T) / (sigma * math.sqrt(T))
+    d2 = d1 - sigma * math.sqrt(T)
+    N = lambda x: 0.5 * math.erfc(-x / math.sqrt(2.0))  # noqa: E731
+    c = S0 * N(d1) - K * math.exp(-r * T) * N(d2)
+    return c if call else c - S0 + K * math.exp(-r * T)
+
+
+def rel_err(a, b):
+    return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-300)))
+
+
+# ------------------------------------------------------------------------------------------------
+# GBM
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n_paths,n_steps", [(1000, 252), (64, 1), (257, 7), (1, 50), (4096, 50)])
+def test_gbm_paths_match_oracle(eng, orc, n_paths, n_steps):
+    P = eng.gbm(SEED, 100.0, 0.04, 0.2, DT, n_steps, n_paths, path_begin=12345)
+    got = P.to_host_step_major()
+    want = orc.paths_gbm(SEED, 100.0, 0.04, 0.2, DT, n_steps, 12345, n_paths)
+    assert got.shape == want.shape == (n_steps + 1, n_paths)
+    assert (got[0] == 100.0).all()
+    assert rel_err(got, want) < 1e-11
+    P.free()
+
+
+def test_gbm_layouts_and_sharding_are_exact(eng):
+    """to_host is the transpose of the stored matrix; a shard [b, b+n) reproduces the same ids."""
+    full = eng.gbm(SEED, 100.0, 0.04, 0.2, DT, 33, 1000)
+    sm = full.to_host_step_major()
+    pm = full.to_host()
+    assert pm.shape == (1000, 34) and np.array_equal(pm, sm.T)
+    parts = []
+    for b, n in [(0, 300), (300, 1), (301, 699)]:
+        Q = eng.gbm(SEED, 100.0, 0.04, 0.2, DT, 33, n, path_begin=b)
+        parts.append(Q.to_host_step_major())
+        Q.free()
+    assert np.array_equal(np.concatenate(parts, axis=1), sm)
+    full.free()
+
+
+def test_gbm_empty_and_bad_arguments(eng):
+    P = eng.gbm(SEED, 100.0, 0.04, 0.2, DT, 10, 0)
+    assert P.n_paths == 0 and P.to_host().shape == (0, 11)
+    with pytest.raises(mc.McgError, match="no paths"):
+        eng.price_european(P, 100.0, 0.04, 1.0, True)
+    P.free()
+    with pytest.raises(mc.McgError, match="n_steps"):
+        eng.gbm(SEED, 100.0, 0.04, 0.2, DT, 0, 10)
+    with pytest.raises(mc.McgError, match="n_paths"):
+        eng.gbm(SEED, 100.0, 0.04, 0.2, DT, 10, -1)
+    with pytest.raises(mc.McgError, match="sigma"):
+        eng.gbm(SEED, 100.0, 0.04, -0.2, DT, 10, 10)
+
+
+def test_gbm_zero_vol_is_deterministic_growth(eng):
+    P = eng.gbm(SEED, 100.0, 0.04, 0.0, DT, 252, 128)
+    a = P.to_host()
+    assert np.allclose(a[:, -1], 100.0 * math.exp(0.04), rtol=1e-13)
+    assert (a == a[0]).all()
+    P.free()
+
+
+def test_european_call_c1_config_vs_black_scholes_and_oracle(eng, orc):
+    """Config C1 (100k x 252, S0=K=100, r=0.04, sigma=0.2, T=1): BS = 9.9251."""
+    n = 100_000
+    P = eng.gbm(SEED, 100.0, 0.04, 0.2, DT, 252, n, payoff=(100.0, True))
+    mean, se = eng.price_european(P, 100.0, 0.04, 1.0, True)          # fused sums
+    ref = bs_price(100.0, 100.0, 0.04, 0.2, 1.0)
+    assert abs(ref - 9.9251) < 1e-4
+    assert abs(mean - ref) <= 2.0 * se, (mean, se, ref)
+    # same number from the stored matrix, from the put side, and from the oracle on the same paths
+    mean2, se2 = eng.price_european(P, 100.0, 0.04, 1.0, False)       # different payoff -> re-reads last row
+    assert abs(mean2 - bs_price(100.0, 100.0, 0.04, 0.2, 1.0, call=False)) <= 2.0 * se2
+    host = P.to_host_step_major()
+    om, ose = orc.price_european(host, 100.0, 0.04, 1.0, True)
+    assert abs(om - mean) <= 1e-11 * abs(om) and abs(ose - se) <= 1e-9 * ose
+    Q = eng.gbm(SEED, 100.0, 0.04, 0.2, DT, 252, n)                    # unfused path, same draws
+    mean3, se3 = eng.price_european(Q, 100.0, 0.04, 1.0, True)
+    assert abs(mean3 - mean) <= 1e-12 * mean and abs(se3 - se) <= 1e-9 * se
+    P.free()
+    Q.free()
+
+
+def test_gbm_martingale_property_large(eng):
+    """Size-independent property at a larger size: E[S_T] = S0 e^{rT}."""
+    n = 2_000_000
+    P = eng.gbm(7, 100.0, 0.04, 0.2, DT, 252, n)
+    # forward = e^{rT} * (call - put) + K  (put-call parity on the same paths)
+    c, cse = eng.price_european(P, 100.0, 0.04, 1.0, True)
+    p, pse = eng.price_european(P, 100.0, 0.04, 1.0, False)
+    fwd = math.exp(0.04) * (c - p) + 100.0
+    se = math.exp(0.04) * math.hypot(cse, pse)
+    assert abs(fwd - 100.0 * math.exp(0.04)) <= 2.5 * se
+    P.free()
+
+
+# ------------------------------------------------------------------------------------------------
+# rBergomi
+# ------------------------------------------------------------------------------------------------
+RB = dict(S0=100.0, r=0.04, xi=0.04, H=0.1, eta=1.9, rho=-0.9)
+
+
+@pytest.mark.parametrize("n_paths,n_steps", [(192, 64), (100, 252), (70, 7), (65, 1), (64, 512)])
+def test_rbergomi_paths_match_oracle(eng, orc, n_paths, n_steps):
+    P = eng.rbergomi(SEED, RB["S0"], RB["r"], RB["xi"], RB["H"], RB["eta"], RB["rho"], DT, n_steps, n_paths,
+                     path_begin=999)
+    got = P.to_host_step_major()
+    want = orc.paths_rbergomi(SEED, RB["S0"], RB["r"], RB["xi"], RB["H"], RB["eta"], RB["rho"], DT, n_steps, 999,
+                              n_paths)
+    assert rel_err(got, want) < 1e-9
+    P.free()
+
+
+def test_rbergomi_weights_match_oracle(orc):
+    from montecarlooptionspricer_amd.engine import rbergomi_weights
+    for steps, H, eta in [(252, 0.1, 1.9), (512, 0.1, 1.9), (7, 0.57, 0.03), (1, 0.3, 1.0)]:
+        k, c = rbergomi_weights(H, eta, DT, steps)
+        ko, co = orc.rbergomi_weights(H, eta, DT, steps)
+        assert np.allclose(k, ko, rtol=0, atol=1e-14 * max(1.0, np.abs(ko).max()))
+        assert np.allclose(c, co, rtol=1e-15, atol=0)
+
+
+def test_rbergomi_eta_zero_is_gbm_with_sigma2_xi(eng):
+    """constant variance v == xi turns the reference's stepping loop into GBM."""
+    A = eng.rbergomi(SEED, 100.0, 0.04, 0.04, 0.3, 0.0, -0.5, DT, 50, 500)
+    B = eng.gbm(SEED, 100.0, 0.04, 0.2, DT, 50, 500)
+    assert rel_err(A.to_host_step_major(), B.to_host_step_major()) < 1e-12
+    A.free()
+    B.free()
+
+
+def test_rbergomi_martingale_and_mixing_price(eng, orc):
+    """Known answers of the reference's dynamics: E[S_T] = S0 e^{rT}, and the
+    European price equals the oracle's reference-faithful ("mt") sample within 2 combined std-errs."""
+    steps, T = 64, 64 * DT
+    n = 400_000
+    P = eng.rbergomi(SEED, RB["S0"], RB["r"], RB["xi"], RB["H"], RB["eta"], RB["rho"], DT, steps, n,
+                     payoff=(100.0, True))
+    c, cse = eng.price_european(P, 100.0, RB["r"], T, True)
+    p, pse = eng.price_european(P, 100.0, RB["r"], T, False)
+    fwd = math.exp(RB["r"] * T) * (c - p) + 100.0
+    assert abs(fwd - 100.0 * math.exp(RB["r"] * T)) <= 2.5 * math.exp(RB["r"] * T) * math.hypot(cse, pse)
+    ref_paths = orc.generate_paths_mt(RB["S0"], RB["r"], RB["xi"], RB["H"], RB["eta"], RB["rho"], steps, 60_000, 11)
+    rm, rse = orc.price_european(ref_paths, 100.0, RB["r"], T, True, step_major=False)
+    z = abs(c - rm) / math.hypot(cse, rse)
+    assert z <= 2.0, (c, cse, rm, rse, z)
+    P.free()
+
+
+# ------------------------------------------------------------------------------------------------
+# LSM
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("is_call,poly", [(False, 2), (False, 3), (True, 2), (False, 0), (False, 1)])
+def test_lsm_matches_oracle_on_same_paths(eng, orc, is_call, poly):
+    """C3-shaped (GBM, 50 exercise dates, dt = 0.02) at a size the oracle finishes in seconds."""
+    n, steps, dt = 20_000, 50, 0.02
+    P = eng.gbm(SEED, 100.0, 0.04, 0.2, dt, steps, n)
+    host = P.to_host_step_major()
+    got, se = eng.price_lsm(P, 0.04, 100.0, 1.0, dt, is_call, poly)
+    want, v0 = orc.lsm_price(host, 0.04, 100.0, 1.0, dt, is_call, poly, want_v0=True)
+    assert abs(got - want) <= 1e-8 * abs(want), (got, want)
+    assert abs(se - v0.std(ddof=1) / math.sqrt(n)) <= 1e-6 * se
+    P.free()
+
+
+def test_lsm_american_put_bounds(eng):
+    """Sanity (not parity): American put >= European put (BS 6.0040 at these parameters)."""
+    n, steps, dt = 200_000, 50, 0.02
+    P = eng.gbm(SEED, 100.0, 0.04, 0.2, dt, steps, n)
+    am, se = eng.price_lsm(P, 0.04, 100.0, 1.0, dt, False, 2)
+    eu = bs_price(100.0, 100.0, 0.04, 0.2, 1.0, call=False)
+    assert eu - 3 * se < am < eu + 1.5
+    P.free()
+
+
+def test_lsm_edge_cases_match_oracle(eng, orc):
+    rs = np.random.RandomState(3)
+    # (a) every column OTM for a put -> pure discounting (LSMPricer.cpp:89-94)
+    otm = 150.0 + rs.rand(50, 6)
+    # (b) maturity shorter than the grid -> j*dt > maturity branch (:43-49)
+    mixed = 100.0 * np.exp(np.cumsum(0.1 * rs.standard_normal((300, 9)), axis=1))
+    mixed[:, 0] = 100.0
+    # (c) a single ITM path per date (rank-1 regression), (d) a single path, (e) one column only
+    one_itm = 120.0 + rs.rand(40, 5)
+    one_itm[7, :] = 80.0
+    single = np.array([[100.0, 90.0, 95.0, 85.0]])
+    onecol = np.array([[90.0], [110.0], [100.0]])
+    cases = [(otm, 1.0, 0.2, 2), (mixed, 0.35, 0.1, 2), (mixed, 10.0, 0.1, 3), (one_itm, 1.0, 0.25, 2),
+             (single, 1.0, 0.25, 2), (onecol, 1.0, 0.25, 2)]
+    for arr, maturity, dt, poly in cases:
+        P = eng.from_host(arr)
+        got, _ = eng.price_lsm(P, 0.04, 100.0, maturity, dt, False, poly)
+        want = orc.lsm_price(arr, 0.04, 100.0, maturity, dt, False, poly, step_major=False)
+        assert abs(got - want) <= 1e-8 * max(abs(want), 1e-12), (arr.shape, maturity, got, want)
+        P.free()
+    with pytest.raises(mc.McgError, match="poly_order"):
+        P = eng.from_host(mixed)
+        eng.price_lsm(P, 0.04, 100.0, 1.0, 0.1, False, 9)
+
+
+def test_from_host_roundtrip_is_exact(eng):
+    rs = np.random.RandomState(0)
+    a = rs.rand(777, 13) * 100
+    P = eng.from_host(a)
+    assert np.array_equal(P.to_host(), a)
+    assert np.array_equal(P.to_host_step_major(), a.T)
+    P.free()
+
+
+# ------------------------------------------------------------------------------------------------
+# the reference's class API (drop-in boundary)
+# ------------------------------------------------------------------------------------------------
+def test_class_api_generate_paths(eng, orc):
+    hist = synthetic_history(1001, seed=42)
+    mc.set_compat_seed(SEED)
+    rv = mc.RoughVolatility()
+    a = rv.GenerateStockPricePaths(hist, 30, 250)        # 250 paths/row is the reference's production size
+    assert a.shape == (250, 31) and np.isfinite(a).all() and (a[:, 0] == hist[-1]).all()
+    assert np.array_equal(a, rv.GenerateStockPricePaths(hist, 30, 250))  # fixed seed -> reproducible
+    p = orc.estimate_params(hist)                         # host estimators == reference-pinned oracle
+    P = eng.rbergomi(SEED, p["S0"], 0.04, p["xi"], p["H"], p["eta"], p["rho"], DT, 30, 250)
+    assert np.array_equal(P.to_host(), a)
+    P.free()
+    mc.set_compat_seed(None)
+    b = rv.GenerateStockPricePaths(hist, 30, 250)         # unseeded like the reference: differs run to run
+    assert not np.array_equal(a, b)
+    with pytest.raises(mc.McgError, match="Historical prices vector too small."):
+        rv.GenerateStockPricePaths([100.0], 30, 250)
+    assert rv.GenerateStockPricePaths(hist, 30, 0).shape == (0, 31)
+    z = rv.GenerateStockPricePaths(hist, 0, 5)
+    assert z.shape == (5, 1) and (z == hist[-1]).all()
+    # two-point history: rho = NaN in the reference -> every step is NaN there too
+    d = rv.GenerateStockPricePaths([100.0, 101.0], 4, 3)
+    assert (d[:, 0] == 101.0).all() and np.isnan(d[:, 1:]).all()
+
+
+def test_class_api_statistics_match_reference_faithful_sample(orc):
+    """Statistical parity with the reference's own algorithm (mt mode): terminal mean and the mean
+    of log-returns' variance agree within sampling error on 20k paths."""
+    hist = synthetic_history(1001, seed=42)
+    mc.set_compat_seed(99)
+    a = mc.RoughVolatility().GenerateStockPricePaths(hist, 60, 20_000)
+    mc.set_compat_seed(None)
+    b = orc.generate_paths_mt_hist(hist, 60, 20_000, 5)
+    for x in (a, b):
+        assert np.isfinite(x).all()
+    za = np.log(a[:, -1] / a[:, 0])
+    zb = np.log(b[:, -1] / b[:, 0])
+    se_m = math.sqrt(za.var() / len(za) + zb.var() / len(zb))
+    assert abs(za.mean() - zb.mean()) <= 3.0 * se_m
+    assert abs(za.var() / zb.var() - 1.0) <= 0.06
+
+
+def test_class_api_lsm(eng, orc):
+    hist = synthetic_history(300, seed=1)
+    mc.set_compat_seed(5)
+    paths = mc.RoughVolatility().GenerateStockPricePaths(hist, 40, 250)
+    mc.set_compat_seed(None)
+    K = float(hist[-1])
+    got = mc.LSM().PredictOptionPrice(paths, 0.04, K, 40 / 365.0, DT, False, 2)   # PredictionGen.cpp:700-704,:790
+    want = orc.lsm_price(paths, 0.04, K, 40 / 365.0, DT, False, 2, step_major=False)
+    assert abs(got - want) <= 1e-8 * abs(want)
+    with pytest.raises(mc.McgError, match="LSM::PredictOptionPrice: Empty pricePaths."):
+        mc.LSM().PredictOptionPrice(np.zeros((0, 0)), 0.04, K, 1.0, DT, False, 2)
+
+
+def test_timing_counters(eng):
+    from montecarlooptionspricer_amd import _native as N
+    eng.timing_enable(True)
+    eng.timing_reset()
+    P = eng.gbm(SEED, 100.0, 0.04, 0.2, DT, 252, 100_000, payoff=(100.0, True))
+    ms, n = eng.timing_get(N.K_GBM)
+    assert n == 1 and ms > 0
+    eng.timing_enable(False)
+    P.free()

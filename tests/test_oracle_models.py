@@ -1,0 +1,197 @@
+"""CPU tests of the oracle beyond the golden vectors: RNG contract, the law-preserving Volterra
+form, the reference-faithful generator against the compiled reference, and the LSM restatement
+against an independent LAPACK (gelsd) least squares.  Everything here runs without a GPU."""
+import math
+
+import numpy as np
+import pytest
+
+from oracle.binding import Oracle, Reference, have_ref, synthetic_history
+
+DT = 1.0 / 252.0
+
+
+@pytest.fixture(scope="module")
+def orc():
+    return Oracle()
+
+
+# ---- RNG contract ------------------------------------------------------------------------------
+def test_philox_known_answers(orc):
+    """Random123 kat_vectors for philox4x32-10."""
+    assert orc.philox([0, 0, 0, 0], [0, 0]) == [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]
+    assert orc.philox([0xFFFFFFFF] * 4, [0xFFFFFFFF] * 2) == [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]
+    assert orc.philox([0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344], [0xA4093822, 0x299F31D0]) == \
+        [0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1]
+
+
+def test_normal_pair_definition(orc):
+    """z = sqrt(-2 ln u1) (cos, sin)(2 pi u2) with u = ((w_hi:w_lo >> 12) + 1/2) 2^-52."""
+    seed, path, block, stream = 20251031, (5 << 32) + 17, 3, 1
+    w = orc.philox([path & 0xFFFFFFFF, path >> 32, block, stream], [seed & 0xFFFFFFFF, seed >> 32])
+    u1 = (((w[1] << 32 | w[0]) >> 12) + 0.5) * 2.0 ** -52
+    u2 = (((w[3] << 32 | w[2]) >> 12) + 0.5) * 2.0 ** -52
+    r = math.sqrt(-2.0 * math.log(u1))
+    z = orc.normal_pair(seed, path, block, stream)
+    assert z[0] == r * math.cos(2.0 * math.pi * u2) and z[1] == r * math.sin(2.0 * math.pi * u2)
+
+
+def test_normal_pair_moments(orc):
+    z = np.array([orc.normal_pair(1, p, 0, 0) for p in range(20000)]).ravel()
+    assert abs(z.mean()) < 4 / math.sqrt(len(z))
+    assert abs(z.var() - 1.0) < 0.03
+    assert abs((z ** 4).mean() - 3.0) < 0.15
+
+
+# ---- GBM ---------------------------------------------------------------------------------------
+def test_gbm_oracle_black_scholes(orc):
+    n = 40_000
+    paths = orc.paths_gbm(20251031, 100.0, 0.04, 0.2, DT, 252, 0, n)
+    m, se = orc.price_european(paths, 100.0, 0.04, 1.0, True)
+    assert abs(m - 9.9251) <= 2.5 * se
+    # shards reproduce the same ids
+    part = orc.paths_gbm(20251031, 100.0, 0.04, 0.2, DT, 252, 1000, 10)
+    assert np.array_equal(part, paths[:, 1000:1010])
+
+
+# ---- rBergomi: the Volterra form has the reference's law ---------------------------------------
+@pytest.mark.parametrize("steps,H,eta", [(252, 0.1, 1.9), (512, 0.1, 1.9), (7, 0.57, 0.03), (50, 0.3, 1.0), (1, 0.2, 0.5)])
+def test_volterra_kernel_reproduces_reference_covariance(orc, steps, H, eta):
+    """Cov(X_n, X_{n+d}) of the reference == (kappa * kappa)(d) for all lags.
+    Both are zero-mean Gaussian vectors, so equal covariance <=> equal law."""
+    lam = orc.lam(steps, H)
+    phi = orc.phi(lam)                       # pinned bit-exact to the compiled reference
+    M = orc.next_pow2(steps)
+    P = np.zeros(M)
+    P[:min(steps, M)] = np.abs(phi[:min(steps, M)]) ** 2
+    d = np.arange(M)
+    k = np.arange(M)
+    cov_ref = (2 * H * eta ** 2 / M ** 2) * (P[None, :] * np.cos(2 * np.pi * np.outer(d, k) / M)).sum(axis=1)
+    kappa, comp = orc.rbergomi_weights(H, eta, DT, steps)
+    cov_ours = np.array([np.dot(kappa, np.roll(kappa, -int(s))) for s in d])
+    assert np.allclose(cov_ours, cov_ref, rtol=1e-10, atol=1e-13 * max(1.0, abs(cov_ref[0])))
+    assert np.allclose(comp, -0.5 * eta ** 2 * (np.arange(steps) * DT) ** (2 * H), rtol=1e-14)
+    if steps == 252:
+        assert abs(cov_ref[0] - 0.12552) < 5e-5      # SURVEY-verified Var(X_n)
+    if steps == 512:
+        assert abs(cov_ref[0] - 0.25480) < 5e-5      # the M_phi=1024 / M_z=512 quirk
+
+
+def test_volterra_sample_covariance_vs_reference_transform(orc):
+    """Sampled X from the device algorithm vs X from the reference's own transform on mt noise."""
+    steps, H, eta, n = 64, 0.1, 1.9, 4000
+    _, X = orc.paths_rbergomi(3, 100.0, 0.04, 0.04, H, eta, -0.9, DT, steps, 0, n, want_X=True)
+    phi = orc.phi(orc.lam(steps, H))
+    rs = np.random.RandomState(1)
+    Xr = np.array([orc.fractional_gaussian(phi, rs.standard_normal(steps) + 1j * rs.standard_normal(steps), H, eta)
+                   for _ in range(n)])
+    for lag in (0, 1, 5, 31):
+        a = (X[:, 10] * X[:, (10 + lag) % steps]).mean()
+        b = (Xr[:, 10] * Xr[:, (10 + lag) % steps]).mean()
+        tol = 5 * Xr[:, 10].var() / math.sqrt(n)
+        assert abs(a - b) < tol, (lag, a, b)
+
+
+def test_rbergomi_oracle_martingale(orc):
+    steps, n = 64, 30_000
+    paths = orc.paths_rbergomi(5, 100.0, 0.04, 0.04, 0.1, 1.9, -0.9, DT, steps, 0, n)
+    ST = paths[-1]
+    assert abs(ST.mean() - 100.0 * math.exp(0.04 * steps * DT)) <= 3 * ST.std() / math.sqrt(n)
+
+
+# ---- reference-faithful generator vs the compiled reference ------------------------------------
+@pytest.mark.skipif(not have_ref(), reason="compiled reference not present")
+def test_mt_mode_statistics_match_compiled_reference(orc):
+    ref = Reference()
+    hist = synthetic_history(1001, seed=42)
+    n, steps = 6000, 40
+    a = ref.generate_paths(hist, steps, n)           # unseeded std::random_device
+    b = orc.generate_paths_mt_hist(hist, steps, n, 77)
+    assert a.shape == b.shape == (n, steps + 1)
+    assert (a[:, 0] == hist[-1]).all() and (b[:, 0] == hist[-1]).all()
+    la, lb = np.log(a[:, -1] / a[:, 0]), np.log(b[:, -1] / b[:, 0])
+    assert abs(la.mean() - lb.mean()) <= 4 * math.sqrt(la.var() / n + lb.var() / n)
+    assert abs(la.var() / lb.var() - 1) < 0.12
+    with pytest.raises(RuntimeError, match="Historical prices vector too small."):
+        ref.generate_paths([100.0], 5, 5)
+
+
+@pytest.mark.skipif(not have_ref(), reason="compiled reference not present")
+def test_philox_mode_statistics_match_compiled_reference(orc):
+    """Device algorithm (Philox mode) vs the compiled reference itself, class-level parameters."""
+    ref = Reference()
+    hist = synthetic_history(1001, seed=42)
+    p = orc.estimate_params(hist)
+    n, steps = 6000, 40
+    a = ref.generate_paths(hist, steps, n)
+    b = orc.paths_rbergomi(123, p["S0"], 0.04, p["xi"], p["H"], p["eta"], p["rho"], DT, steps, 0, n).T
+    la, lb = np.log(a[:, -1] / a[:, 0]), np.log(b[:, -1] / b[:, 0])
+    assert abs(la.mean() - lb.mean()) <= 4 * math.sqrt(la.var() / n + lb.var() / n)
+    assert abs(la.var() / lb.var() - 1) < 0.12
+
+
+# ---- LSM ---------------------------------------------------------------------------------------
+def lsm_numpy(paths_pm, r, K, maturity, dt, is_call, poly):
+    """Independent restatement of LSMPricer.cpp:19-102 with LAPACK gelsd (SVD, min-norm)."""
+    pay = (lambda s: np.maximum(0.0, s - K)) if is_call else (lambda s: np.maximum(0.0, K - s))
+    N, M = paths_pm.shape
+    V = pay(paths_pm[:, M - 1])
+    disc = math.exp(-r * dt)
+    for j in range(M - 2, -1, -1):
+        if j * dt > maturity:
+            V = V * disc
+            continue
+        s = paths_pm[:, j]
+        p = pay(s)
+        itm = p > 1e-14
+        Vn = np.zeros(N)
+        if itm.any():
+            A = np.vander(s[itm], poly + 1, increasing=True)
+            c, *_ = np.linalg.lstsq(A, V[itm] * disc, rcond=min(A.shape) * np.finfo(float).eps)
+            Vn[itm] = np.maximum(p[itm], A @ c)
+        otm = p < 1e-14
+        Vn[otm] = V[otm] * disc
+        V = Vn
+    return V.mean()
+
+
+@pytest.mark.parametrize("is_call,poly", [(False, 2), (True, 2), (False, 3), (False, 0)])
+def test_lsm_oracle_vs_lapack(orc, is_call, poly):
+    n, steps, dt = 4000, 50, 0.02
+    paths = orc.paths_gbm(9, 100.0, 0.04, 0.2, dt, steps, 0, n)      # step-major
+    got = orc.lsm_price(paths, 0.04, 100.0, 1.0, dt, is_call, poly)
+    want = lsm_numpy(paths.T, 0.04, 100.0, 1.0, dt, is_call, poly)
+    assert abs(got - want) <= 1e-9 * abs(want), (got, want)
+    # layout-independent
+    assert orc.lsm_price(np.ascontiguousarray(paths.T), 0.04, 100.0, 1.0, dt, is_call, poly, step_major=False) == got
+
+
+def test_lsm_oracle_edge_cases(orc):
+    rs = np.random.RandomState(3)
+    otm = 150.0 + rs.rand(50, 6)                                   # all OTM: pure discount (:89-94)
+    v = orc.lsm_price(otm, 0.04, 100.0, 1.0, 0.2, False, 2, step_major=False)
+    assert v == 0.0
+    itm_end = np.full((10, 4), 150.0)
+    itm_end[:, -1] = 90.0                                          # payoff 10 at the end only
+    v = orc.lsm_price(itm_end, 0.04, 100.0, 1.0, 0.25, False, 2, step_major=False)
+    assert abs(v - 10.0 * math.exp(-0.04 * 0.75)) < 1e-12
+    # grid longer than maturity (:43-49): dates past maturity only discount
+    mixed = 100.0 * np.exp(np.cumsum(0.1 * rs.standard_normal((300, 9)), axis=1))
+    a = orc.lsm_price(mixed, 0.04, 100.0, 0.35, 0.1, False, 2, step_major=False)
+    b = lsm_numpy(mixed, 0.04, 100.0, 0.35, 0.1, False, 2)
+    assert abs(a - b) <= 1e-9 * abs(b)
+    # N = 1 (rank-1 fit reproduces the single discounted value), and empty input throws
+    single = np.array([[100.0, 90.0, 95.0, 85.0]])
+    a = orc.lsm_price(single, 0.04, 100.0, 1.0, 0.25, False, 2, step_major=False)
+    b = lsm_numpy(single, 0.04, 100.0, 1.0, 0.25, False, 2)
+    assert abs(a - b) <= 1e-12 * abs(b)
+    with pytest.raises(RuntimeError, match="LSM::PredictOptionPrice: Empty pricePaths."):
+        orc.lsm_price(np.zeros((0, 0)), 0.04, 100.0, 1.0, 0.25, False, 2)
+
+
+def test_lsm_american_put_above_european(orc):
+    n, steps, dt = 30_000, 50, 0.02
+    paths = orc.paths_gbm(11, 100.0, 0.04, 0.2, dt, steps, 0, n)
+    am = orc.lsm_price(paths, 0.04, 100.0, 1.0, dt, False, 2)
+    eu, se = orc.price_european(paths, 100.0, 0.04, 1.0, False)
+    assert am > eu - 2 * se and am < eu + 1.5
