@@ -72,6 +72,7 @@ def load_library():
     L.mcg_compat_generate_paths.argtypes = [dp, C.c_size_t, C.c_int, C.c_int, dp]
     L.mcg_compat_lsm_price.argtypes = [dp, C.c_int64, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double,
                                        C.c_int, C.c_int, dp]
+    L.mcg_debug_eval.argtypes = [vp, C.c_int, dp, dp, C.c_int64]
     L.mcg_timing_enable.argtypes = [vp, C.c_int]
     L.mcg_timing_reset.argtypes = [vp]
     L.mcg_timing_get.argtypes = [vp, C.c_int, dp, C.POINTER(C.c_int64)]

@@ -1,0 +1,145 @@
+// Hand-scheduled binary64 math for the path kernels (gfx950).  The GBM step is issue-bound on the
+// fp64 VALU (a wave64 fp64 op takes 4 SIMD cycles; v_rcp/rsq/sqrt_f64 take ~16.5; 32-bit integer
+// and bit ops ~2.8 -- tools/ubench_issue.hip), so every function here is written to minimise the
+// fp64 instruction count for exactly the argument ranges the kernels produce, with no special-case
+// branches (a divergent branch costs both sides on a 64-lane wave).  Accuracy target: <= ~2 ulp,
+// checked against mpmath in tests (mcg_debug_eval).
+//
+//   scaled_exp(S, a)        S * e^a           any finite a (overflow -> inf, underflow -> 0)
+//   neg2log(u, tab)         -2 ln u           u in (0, 1]; 128-entry {1/c, -2 ln c} table in LDS
+//   sqrt_pos(x)             sqrt(x)           x in [1e-300, 1e300], no denormal/negative handling
+//   sincos_octant(w2, w3)   cos/sin(2 pi u2)  u2 = ((w3:w2 >> 12) + 1/2) 2^-52, from the raw words
+//   normal_pair_fast(...)   the Box-Muller pair of philox.hpp's contract built from the above
+//
+// Polynomials: interpolation at Chebyshev nodes in 60-digit arithmetic, rounded to binary64
+// (tools/gen_coeffs.py prints them with their achieved max error).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "philox.hpp"
+
+namespace mcg {
+namespace fm {
+
+constexpr int LOG_TAB_ENTRIES = 128;  // x 16 B = 2 KiB of LDS per workgroup
+
+__device__ __forceinline__ double from_words(uint32_t hi, uint32_t lo) { return __hiloint2double((int)hi, (int)lo); }
+
+// S * e^a.  k = rint(a/ln2), r = a - k ln2 (hi/lo split; k*hi exact for |k| < 2^21),
+// e^r = 1 + r + r^2 q(r) with q of degree 9 on |r| <= ln2/2 (max rel err 2^-55.8),
+// result = ldexp(S + S*(e^r - 1), k).  18 fp64-class instructions.
+__device__ __forceinline__ double scaled_exp(double S, double a) {
+    const double kd = __builtin_rint(a * 0x1.71547652b82fep+0);
+    double r = __builtin_fma(kd, -0x1.62e42fee00000p-1, a);
+    r = __builtin_fma(kd, -0x1.a39ef35793c76p-33, r);
+    double q = 0x1.af38a9b0ec855p-26;
+    q = __builtin_fma(q, r, 0x1.289185613a3d6p-22);
+    q = __builtin_fma(q, r, 0x1.71de0dae63bb3p-19);
+    q = __builtin_fma(q, r, 0x1.a019b90d2ae7ap-16);
+    q = __builtin_fma(q, r, 0x1.a01a01a7c41d5p-13);
+    q = __builtin_fma(q, r, 0x1.6c16c1788bd90p-10);
+    q = __builtin_fma(q, r, 0x1.11111111109b3p-7);
+    q = __builtin_fma(q, r, 0x1.5555555553d63p-5);
+    q = __builtin_fma(q, r, 0x1.5555555555556p-3);
+    q = __builtin_fma(q, r, 0x1.0000000000001p-1);
+    const double em1 = __builtin_fma(r * r, q, r);  // e^r - 1
+    const double v = __builtin_fma(S, em1, S);
+    return __builtin_ldexp(v, (int)kd);  // v_cvt_i32_f64 saturates; v_ldexp_f64 clamps
+}
+
+// -2 ln u for u in (0,1].  u = z * 2^k with z in [0.6875, 1.375) (so u near 1 has k = 0 and no
+// cancellation); i = interval of z, r = z/c_i - 1 via one FMA with the tabulated 1/c_i;
+// ln z = ln c_i + log1p(r), log1p(r) = r - r^2/2 + r^3 p(r), p of degree 4 on |r| <= 0.0045
+// (max rel err 2^-61).  The interval containing 1 has c = 1 exactly.
+// tab: LDS, entry i = {1/c_i, -2 ln c_i}.
+__device__ __forceinline__ double neg2log(double u, const double2* tab) {
+    const uint32_t hi = (uint32_t)__double2hiint(u), lo = (uint32_t)__double2loint(u);
+    const uint32_t t = hi - 0x3FE60000u;                  // offset so the mantissa window starts at 0.6875
+    const int k = (int)t >> 20;                            // exponent of the window (arithmetic shift)
+    const uint32_t i = (t >> 13) & 127u;                   // top 7 bits inside the window
+    const double z = from_words(hi - (t & 0xFFF00000u), lo);
+    const double2 e = tab[i];
+    const double r = __builtin_fma(z, e.x, -1.0);
+    const double r2 = r * r;
+    double p = 0x1.2493c2a2efcc3p-3;
+    p = __builtin_fma(p, r, -0x1.5556fe0374498p-3);
+    p = __builtin_fma(p, r, 0x1.999999991c5b3p-3);
+    p = __builtin_fma(p, r, -0x1.ffffffff7319dp-3);
+    p = __builtin_fma(p, r, 0x1.5555555555555p-2);
+    const double l1p = __builtin_fma(r2 * r, p, __builtin_fma(r2, -0.5, r));  // log1p(r)
+    // -2 ln u = -2 k ln2 + (-2 ln c) - 2 log1p(r)
+    const double base = __builtin_fma((double)k, -0x1.62e42fefa39efp+0, e.y);
+    return __builtin_fma(-2.0, l1p, base);
+}
+
+// sqrt for positive normal x: hardware rsq seed, one coupled Newton step and a final correction.
+__device__ __forceinline__ double sqrt_pos(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y;
+    double h = 0.5 * y;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    const double d = __builtin_fma(-g, g, x);
+    return __builtin_fma(d, h, g);
+}
+
+// cos(2 pi u2), sin(2 pi u2) with u2 = ((w3:w2 >> 12) + 1/2) * 2^-52, straight from the Philox words:
+// 8 u2 = q + x, q = top 3 bits (octant), x = (rem + 1/2) 2^-49 in (0,1); odd octants use 1 - x, which
+// is the bitwise complement of rem.  sin/cos(pi/4 * y) on [0,1] by polynomials in y^2 (max rel err
+// 2^-54 / 2^-55), then the octant symmetries as sign-bit xors and one swap.
+__device__ __forceinline__ void sincos_octant(uint32_t w2, uint32_t w3, double& c_out, double& s_out) {
+    const uint32_t odd = 0u - ((w3 >> 29) & 1u);           // all ones in odd octants
+    uint32_t mhi = (w3 >> 9) & 0xFFFFFu;                    // mantissa bits 51..32 = rem bits 48..29
+    uint32_t mlo = (w3 << 23) | ((w2 >> 9) & 0x7FFFF8u);    // mantissa bits 31..3 = rem bits 28..0
+    mhi ^= odd & 0xFFFFFu;
+    mlo ^= odd & 0xFFFFFFF8u;
+    const double y = (from_words(0x3FF00000u | mhi, mlo) - 1.0) + 0x1p-50;
+    const double w = y * y;
+    double ps = 0x1.e4a9d9166f052p-38;
+    ps = __builtin_fma(ps, w, -0x1.e3027dea82bd7p-30);
+    ps = __builtin_fma(ps, w, 0x1.50783208843ebp-22);
+    ps = __builtin_fma(ps, w, -0x1.32d2cce500387p-15);
+    ps = __builtin_fma(ps, w, 0x1.466bc6775a476p-9);
+    ps = __builtin_fma(ps, w, -0x1.4abbce625be52p-4);
+    const double sn = y * __builtin_fma(ps, w, 0x1.921fb54442d18p-1);
+    double pc = -0x1.b2f3eb054afcdp-42;
+    pc = __builtin_fma(pc, w, 0x1.f9ce245cada0bp-34);
+    pc = __builtin_fma(pc, w, -0x1.a6d1eef479be1p-26);
+    pc = __builtin_fma(pc, w, 0x1.e1f5068688d5bp-19);
+    pc = __builtin_fma(pc, w, -0x1.55d3c7e3cb241p-12);
+    pc = __builtin_fma(pc, w, 0x1.03c1f081b5ac0p-6);
+    pc = __builtin_fma(pc, w, -0x1.3bd3cc9be45dep-2);
+    const double cs = __builtin_fma(pc, w, 1.0);
+    // octant q = w3 >> 29: swap for q in {1,2,5,6} (bit0 ^ bit1), cos < 0 for q in {2,3,4,5}
+    // (bit1 ^ bit2), sin < 0 for q >= 4 (bit2)
+    const bool swap = (((w3 >> 29) ^ (w3 >> 30)) & 1u) != 0u;
+    const double cc = swap ? sn : cs;
+    const double ss = swap ? cs : sn;
+    const uint32_t sign_c = (w3 ^ (w3 << 1)) & 0x80000000u;
+    const uint32_t sign_s = w3 & 0x80000000u;
+    c_out = from_words((uint32_t)__double2hiint(cc) ^ sign_c, (uint32_t)__double2loint(cc));
+    s_out = from_words((uint32_t)__double2hiint(ss) ^ sign_s, (uint32_t)__double2loint(ss));
+}
+
+// Same contract as mcg::normal_pair (philox.hpp), built from the pieces above.
+__device__ __forceinline__ void normal_pair_fast(uint32_t k0, uint32_t k1, uint64_t path, uint32_t block,
+                                                 uint32_t stream, const double2* log_tab, double& z0, double& z1) {
+    const Philox4 w = philox4x32_10((uint32_t)path, (uint32_t)(path >> 32), block, stream, k0, k1);
+    const double u1 = u01_from_bits(w.w0, w.w1);
+    const double rad = sqrt_pos(neg2log(u1, log_tab));
+    double c, s;
+    sincos_octant(w.w2, w.w3, c, s);
+    z0 = rad * c;
+    z1 = rad * s;
+}
+
+// Cooperative copy of the log table (global, 2 KiB) into LDS; call before the first normal_pair_fast
+// and follow with __syncthreads().
+__device__ __forceinline__ void load_log_table(double2* lds_tab, const double2* __restrict__ gtab) {
+    for (int i = threadIdx.x; i < LOG_TAB_ENTRIES; i += blockDim.x) lds_tab[i] = gtab[i];
+}
+
+}  // namespace fm
+}  // namespace mcg

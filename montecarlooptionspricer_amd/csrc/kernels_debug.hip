@@ -1,0 +1,60 @@
+// Test hook behind mcg_debug_eval: runs one routine of fastmath.hpp elementwise so that tests can
+// measure its error against mpmath / libm.  Not on any product path.
+#include "devmath.hpp"
+#include "fastmath.hpp"
+#include "mcg_internal.hpp"
+
+namespace mcg {
+
+__global__ __launch_bounds__(256) void k_debug_eval(int fn, const double* x, double* y, int64_t n,
+                                                    const double2* gtab) {
+    __shared__ double2 tab[fm::LOG_TAB_ENTRIES];
+    fm::load_log_table(tab, gtab);
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double v = x[i];
+    double a = 0.0, b = 0.0;
+    switch (fn) {
+        case 0: a = fm::scaled_exp(1.0, v); break;
+        case 1: a = fm::neg2log(v, tab); break;
+        case 2: a = fm::sqrt_pos(v); break;
+        case 3: {
+            const uint64_t w = (uint64_t)__double_as_longlong(v);
+            fm::sincos_octant((uint32_t)w, (uint32_t)(w >> 32), a, b);
+            break;
+        }
+        case 4: fm::normal_pair_fast(1u, 0u, (uint64_t)v, 0u, STREAM_PRICE, tab, a, b); break;
+        default: normal_pair(1u, 0u, (uint64_t)v, 0u, STREAM_PRICE, a, b); break;
+    }
+    y[2 * i] = a;
+    y[2 * i + 1] = b;
+}
+
+}  // namespace mcg
+
+extern "C" int mcg_debug_eval(mcg_ctx* ctx, int fn, const double* x, double* y, int64_t n) {
+    using namespace mcg;
+    if (!ctx || !x || !y || n < 0 || fn < 0 || fn > 5) return fail(MCG_ERR_INVALID, "bad arguments");
+    if (n == 0) return MCG_OK;
+    MCG_HIP(hipSetDevice(ctx->device));
+    double *dx = nullptr, *dy = nullptr;
+    MCG_HIP(hipMalloc((void**)&dx, (size_t)n * sizeof(double)));
+    if (hipMalloc((void**)&dy, (size_t)n * 2 * sizeof(double)) != hipSuccess) {
+        (void)hipFree(dx);
+        return fail(MCG_ERR_OOM, "hipMalloc failed");
+    }
+    int rc = MCG_OK;
+    if (hipMemcpyAsync(dx, x, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+        rc = fail(MCG_ERR_HIP, "H2D failed");
+    if (rc == MCG_OK) {
+        hipLaunchKernelGGL(k_debug_eval, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, fn, dx, dy, n,
+                           (const double2*)ctx->log_tab);
+        if (hipMemcpyAsync(y, dy, (size_t)n * 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+            hipStreamSynchronize(ctx->stream) != hipSuccess)
+            rc = fail(MCG_ERR_HIP, "debug eval failed: %s", hipGetErrorString(hipGetLastError()));
+    }
+    (void)hipFree(dx);
+    (void)hipFree(dy);
+    return rc;
+}

@@ -8,6 +8,7 @@
 //
 // Roofline: HBM write, 8*(n_steps+1) bytes per path, reads ~0.  No MFMA: the step is elementwise.
 #include "devmath.hpp"
+#include "fastmath.hpp"
 #include "mcg_internal.hpp"
 
 namespace mcg {
@@ -23,10 +24,14 @@ struct GbmArgs {
     double K;
     int is_call;
     double* partials;  // [gridDim.x][2]
+    const double2* log_tab;  // fm::LOG_TAB_HOST on the device
 };
 
 template <bool PAYOFF>
 __global__ __launch_bounds__(256) void k_gbm_paths(GbmArgs a) {
+    __shared__ double2 tab[fm::LOG_TAB_ENTRIES];
+    fm::load_log_table(tab, a.log_tab);
+    __syncthreads();
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const bool live = i < a.n_paths;
     const uint64_t id = a.path_begin + (uint64_t)i;
@@ -36,18 +41,18 @@ __global__ __launch_bounds__(256) void k_gbm_paths(GbmArgs a) {
     const int n_pairs = a.n_steps >> 1;
     for (int b = 0; b < n_pairs; ++b) {
         double z0, z1;
-        normal_pair(a.k0, a.k1, id, (uint32_t)b, STREAM_PRICE, z0, z1);
-        S = S * exp(fma(a.vol, z0, a.drift));
+        fm::normal_pair_fast(a.k0, a.k1, id, (uint32_t)b, STREAM_PRICE, tab, z0, z1);
+        S = fm::scaled_exp(S, fma(a.vol, z0, a.drift));
         col += a.ld;
         if (live) __builtin_nontemporal_store(S, col);
-        S = S * exp(fma(a.vol, z1, a.drift));
+        S = fm::scaled_exp(S, fma(a.vol, z1, a.drift));
         col += a.ld;
         if (live) __builtin_nontemporal_store(S, col);
     }
     if (a.n_steps & 1) {
         double z0, z1;
-        normal_pair(a.k0, a.k1, id, (uint32_t)n_pairs, STREAM_PRICE, z0, z1);
-        S = S * exp(fma(a.vol, z0, a.drift));
+        fm::normal_pair_fast(a.k0, a.k1, id, (uint32_t)n_pairs, STREAM_PRICE, tab, z0, z1);
+        S = fm::scaled_exp(S, fma(a.vol, z0, a.drift));
         col += a.ld;
         if (live) __builtin_nontemporal_store(S, col);
     }
@@ -139,6 +144,7 @@ int launch_gbm(mcg_ctx* ctx, mcg_paths* P, uint64_t seed, double S0, double r, d
     a.K = K;
     a.is_call = is_call;
     a.partials = ctx->partials;
+    a.log_tab = (const double2*)ctx->log_tab;
     {
         TimedLaunch t(ctx, MCG_K_GBM);
         if (want_payoff)

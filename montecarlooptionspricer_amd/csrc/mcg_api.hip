@@ -5,6 +5,7 @@
 #include <cstring>
 #include <new>
 
+#include "fastmath_tables.hpp"
 #include "mcg_internal.hpp"
 
 namespace mcg {
@@ -236,6 +237,11 @@ int mcg_init(mcg_ctx** out, int device, void* external_stream) {
         mcg_finalize(ctx);
         return fail(MCG_ERR_OOM, "workspace allocation failed");
     }
+    if (hipMalloc((void**)&ctx->log_tab, sizeof(fm::LOG_TAB_HOST)) != hipSuccess ||
+        hipMemcpy(ctx->log_tab, fm::LOG_TAB_HOST, sizeof(fm::LOG_TAB_HOST), hipMemcpyHostToDevice) != hipSuccess) {
+        mcg_finalize(ctx);
+        return fail(MCG_ERR_OOM, "table upload failed");
+    }
     *out = ctx;
     return MCG_OK;
 }
@@ -260,6 +266,7 @@ int mcg_finalize(mcg_ctx* ctx) {
     if (ctx->weights) (void)hipFree(ctx->weights);
     if (ctx->lsm_v) (void)hipFree(ctx->lsm_v);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->log_tab) (void)hipFree(ctx->log_tab);
     if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return MCG_OK;

@@ -1,0 +1,95 @@
+"""Accuracy of the hand-written device math (csrc/fastmath.hpp) through mcg_debug_eval, against
+mpmath (50 digits).  Bar: <= 2 ulp for exp / sqrt / sincos, <= 4 ulp for -2 ln u (table + cancellation
+next to u = 1), and the fast normal pair within 1e-14 absolute of the RNG contract evaluated in
+high precision."""
+import struct
+
+import mpmath as mp
+import numpy as np
+import pytest
+
+import montecarlooptionspricer_amd as mc
+from oracle.binding import Oracle
+
+pytestmark = pytest.mark.gpu
+mp.mp.dps = 50
+
+
+@pytest.fixture(scope="module")
+def eng():
+    e = mc.PathEngine(0)
+    yield e
+    e.close()
+
+
+def ulp_err(got, exact_mp):
+    exact = float(exact_mp)
+    if exact == 0.0:
+        return abs(got)
+    ulp = np.spacing(abs(exact))
+    return float(abs(mp.mpf(got) - exact_mp) / mp.mpf(ulp))
+
+
+def test_scaled_exp(eng):
+    rs = np.random.RandomState(0)
+    x = np.concatenate([rs.uniform(-0.7, 0.7, 3000), rs.uniform(-40, 40, 1000), rs.normal(0, 0.02, 2000),
+                        [0.0, 1e-300, -1e-300, 0.34657359, -0.34657359, 709.0, -740.0, 1000.0, -1000.0]])
+    y = eng.debug_eval(0, x)[:, 0]
+    worst = 0.0
+    for xi, yi in zip(x[:-2], y[:-2]):
+        worst = max(worst, ulp_err(yi, mp.e ** mp.mpf(xi)))
+    assert worst <= 2.0, worst
+    assert y[-2] == np.inf and y[-1] == 0.0
+
+
+def test_neg2log(eng):
+    rs = np.random.RandomState(1)
+    u = np.concatenate([rs.uniform(0, 1, 4000), 1 - rs.uniform(0, 1, 1500) ** 8, rs.uniform(0, 1, 1500) ** 12,
+                        [2.0 ** -53, 1 - 2.0 ** -53, 0.5, 0.6875, 0.99609375, 0.25, 1.0, 2.0 ** -52 * 1.5]])
+    u = u[(u > 0) & (u <= 1)]
+    y = eng.debug_eval(1, u)[:, 0]
+    worst = 0.0
+    for ui, yi in zip(u, y):
+        worst = max(worst, ulp_err(yi, -2 * mp.log(mp.mpf(ui))))
+    assert worst <= 4.0, worst
+
+
+def test_sqrt_pos(eng):
+    rs = np.random.RandomState(2)
+    x = np.concatenate([rs.uniform(0, 80, 4000), 10.0 ** rs.uniform(-16, 2, 2000), [2.2e-16, 73.5, 1.0, 4.0]])
+    y = eng.debug_eval(2, x)[:, 0]
+    worst = max(ulp_err(yi, mp.sqrt(mp.mpf(xi))) for xi, yi in zip(x, y))
+    assert worst <= 1.0, worst
+
+
+def test_sincos_octant(eng):
+    rs = np.random.RandomState(3)
+    words = rs.randint(0, 2 ** 63, size=6000, dtype=np.uint64) * 2 + rs.randint(0, 2, size=6000).astype(np.uint64)
+    edge = np.array([0, 2 ** 64 - 1, 1 << 61, (1 << 61) - 1, 3 << 61, (5 << 61) + 4095, 7 << 61, 1 << 12], dtype=np.uint64)
+    words = np.concatenate([words, edge])
+    x = words.view(np.float64)
+    y = eng.debug_eval(3, x)
+    worst = 0.0
+    for w, (c, s) in zip(words, y):
+        a = int(w) >> 12
+        ang = 2 * mp.pi * (mp.mpf(a) + mp.mpf(1) / 2) / mp.mpf(2) ** 52
+        worst = max(worst, ulp_err(c, mp.cos(ang)), ulp_err(s, mp.sin(ang)))
+    assert worst <= 2.0, worst
+
+
+def test_normal_pair_fast_matches_contract(eng):
+    orc = Oracle()
+    ids = np.arange(0, 5000, dtype=np.float64)
+    fast = eng.debug_eval(4, ids)
+    slow = eng.debug_eval(5, ids)
+    want = np.array([orc.normal_pair(1, int(i), 0, 0) for i in ids])
+    assert np.max(np.abs(fast - want)) < 1e-14
+    assert np.max(np.abs(slow - want)) < 1e-14
+    # and in high precision for a few
+    for i in range(0, 5000, 500):
+        w = orc.philox([i, 0, 0, 0], [1, 0])
+        u1 = (mp.mpf((w[1] << 32 | w[0]) >> 12) + mp.mpf(1) / 2) / mp.mpf(2) ** 52
+        u2 = (mp.mpf((w[3] << 32 | w[2]) >> 12) + mp.mpf(1) / 2) / mp.mpf(2) ** 52
+        r = mp.sqrt(-2 * mp.log(u1))
+        assert abs(mp.mpf(fast[i, 0]) - r * mp.cos(2 * mp.pi * u2)) < mp.mpf("4e-15")
+        assert abs(mp.mpf(fast[i, 1]) - r * mp.sin(2 * mp.pi * u2)) < mp.mpf("4e-15")
