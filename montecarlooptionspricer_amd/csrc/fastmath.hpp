@@ -26,6 +26,15 @@ constexpr int LOG_TAB_ENTRIES = 128;  // x 16 B = 2 KiB of LDS per workgroup
 
 __device__ __forceinline__ double from_words(uint32_t hi, uint32_t lo) { return __hiloint2double((int)hi, (int)lo); }
 
+// q*r + C with the constant C read from a scalar register pair.  hipcc otherwise keeps hoisted
+// constants in VGPRs and lowers each Horner step to v_mov_b64 + v_fmac_f64 (the two-address form
+// clobbers its addend); one VOP3 v_fma_f64 with an SGPR addend needs no copy.
+__device__ __forceinline__ double fma_sc(double q, double r, double C) {
+    double out;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(out) : "v"(q), "v"(r), "s"(C));
+    return out;
+}
+
 // S * e^a.  k = rint(a/ln2), r = a - k ln2 (hi/lo split; k*hi exact for |k| < 2^21),
 // e^r = 1 + r + r^2 q(r) with q of degree 9 on |r| <= ln2/2 (max rel err 2^-55.8),
 // result = ldexp(S + S*(e^r - 1), k).  18 fp64-class instructions.
@@ -34,15 +43,15 @@ __device__ __forceinline__ double scaled_exp(double S, double a) {
     double r = __builtin_fma(kd, -0x1.62e42fee00000p-1, a);
     r = __builtin_fma(kd, -0x1.a39ef35793c76p-33, r);
     double q = 0x1.af38a9b0ec855p-26;
-    q = __builtin_fma(q, r, 0x1.289185613a3d6p-22);
-    q = __builtin_fma(q, r, 0x1.71de0dae63bb3p-19);
-    q = __builtin_fma(q, r, 0x1.a019b90d2ae7ap-16);
-    q = __builtin_fma(q, r, 0x1.a01a01a7c41d5p-13);
-    q = __builtin_fma(q, r, 0x1.6c16c1788bd90p-10);
-    q = __builtin_fma(q, r, 0x1.11111111109b3p-7);
-    q = __builtin_fma(q, r, 0x1.5555555553d63p-5);
-    q = __builtin_fma(q, r, 0x1.5555555555556p-3);
-    q = __builtin_fma(q, r, 0x1.0000000000001p-1);
+    q = fma_sc(q, r, 0x1.289185613a3d6p-22);
+    q = fma_sc(q, r, 0x1.71de0dae63bb3p-19);
+    q = fma_sc(q, r, 0x1.a019b90d2ae7ap-16);
+    q = fma_sc(q, r, 0x1.a01a01a7c41d5p-13);
+    q = fma_sc(q, r, 0x1.6c16c1788bd90p-10);
+    q = fma_sc(q, r, 0x1.11111111109b3p-7);
+    q = fma_sc(q, r, 0x1.5555555553d63p-5);
+    q = fma_sc(q, r, 0x1.5555555555556p-3);
+    q = fma_sc(q, r, 0x1.0000000000001p-1);
     const double em1 = __builtin_fma(r * r, q, r);  // e^r - 1
     const double v = __builtin_fma(S, em1, S);
     return __builtin_ldexp(v, (int)kd);  // v_cvt_i32_f64 saturates; v_ldexp_f64 clamps

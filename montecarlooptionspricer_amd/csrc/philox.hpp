@@ -29,8 +29,9 @@ __device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint3
         // 32x32 -> 64 products; hipcc selects v_mad_u64_u32 / v_mul_hi_u32 + v_mul_lo_u32
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
         const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
-        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
-        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        // three-input xor in one v_bitop3_b32 (truth table 0x96); the round key is wave-uniform (SGPR)
+        const uint32_t n0 = __builtin_amdgcn_bitop3_b32((uint32_t)(p1 >> 32), c1, k0, 0x96);
+        const uint32_t n2 = __builtin_amdgcn_bitop3_b32((uint32_t)(p0 >> 32), c3, k1, 0x96);
         c1 = (uint32_t)p1;
         c3 = (uint32_t)p0;
         c0 = n0;
