@@ -313,3 +313,64 @@ def test_timing_counters(eng):
     assert n == 1 and ms > 0
     eng.timing_enable(False)
     P.free()
+
+
+# ------------------------------------------------------------------------------------------------
+# collectives (single GPU box: world_size 1, plus a callback that emulates a second identical rank)
+# ------------------------------------------------------------------------------------------------
+def test_allreduce_callback_plumbing():
+    """A callback that doubles the buffer == two ranks holding identical shards: same mean, n doubles,
+    std-err shrinks by sqrt(2); LSM moments doubled leave the fit (hence the price) unchanged."""
+    import torch
+    e = mc.PathEngine(0, stream=torch.cuda.current_stream().cuda_stream)
+    calls = []
+
+    def doubler(ptr, count, stream):
+        from montecarlooptionspricer_amd.engine import _DevView
+        t = torch.as_tensor(_DevView(ptr, count), device="cuda:0")
+        t.mul_(2.0)
+        calls.append(count)
+
+    P = e.gbm(SEED, 100.0, 0.04, 0.2, 0.02, 50, 30_000)
+    m1, se1 = e.price_european(P, 100.0, 0.04, 1.0, False)
+    l1, lse1 = e.price_lsm(P, 0.04, 100.0, 1.0, 0.02, False, 2)
+    e.set_allreduce(doubler)
+    m2, se2 = e.price_european(P, 100.0, 0.04, 1.0, False)
+    l2, lse2 = e.price_lsm(P, 0.04, 100.0, 1.0, 0.02, False, 2)
+    assert abs(m2 - m1) <= 1e-13 * m1 and abs(se2 * math.sqrt(2.0) - se1) <= 1e-4 * se1
+    assert abs(l2 - l1) <= 1e-12 * l1 and abs(lse2 * math.sqrt(2.0) - lse1) <= 1e-4 * lse1
+    assert calls.count(3) == 2 and calls.count(8) == 50       # 3p+2 = 8 moments on each of 50 dates
+    e.set_allreduce(None)
+    m3, _ = e.price_european(P, 100.0, 0.04, 1.0, False)
+    assert m3 == m1
+    P.free()
+    e.close()
+
+
+def test_torch_distributed_and_builtin_rccl_world_size_one():
+    import os
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        e = mc.PathEngine(0, stream=torch.cuda.current_stream().cuda_stream)
+        P = e.gbm(SEED, 100.0, 0.04, 0.2, 0.02, 50, 20_000, payoff=(100.0, False))
+        base = mc.PathEngine(0)
+        Q = base.gbm(SEED, 100.0, 0.04, 0.2, 0.02, 50, 20_000)
+        want_e = base.price_european(Q, 100.0, 0.04, 1.0, False)
+        want_l = base.price_lsm(Q, 0.04, 100.0, 1.0, 0.02, False, 2)
+        e.use_torch_distributed()
+        assert e.price_lsm(P, 0.04, 100.0, 1.0, 0.02, False, 2) == want_l
+        R = e.gbm(SEED, 100.0, 0.04, 0.2, 0.02, 50, 20_000, payoff=(100.0, False))
+        assert e.price_european(R, 100.0, 0.04, 1.0, False) == want_e
+        e.set_allreduce(None)
+        e.init_rccl(0, 1, lambda uid: uid)                   # built-in RCCL communicator, 1 rank
+        assert e.price_lsm(P, 0.04, 100.0, 1.0, 0.02, False, 2) == want_l
+        for x in (P, Q, R):
+            x.free()
+        e.close()
+        base.close()
+    finally:
+        dist.destroy_process_group()

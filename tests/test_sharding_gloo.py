@@ -1,0 +1,122 @@
+"""The N>1 path on CPU: two gloo ranks shard one pricing job the way bench.py / the C ABI do it.
+
+What is exercised is the product's host logic (sharding.shard_range / combine_sums /
+price_from_sums) and the sharded ALGORITHM the device runs -- contiguous global path ids per rank,
+one all-reduce of {sum, sum^2, n} (European) or of the 3p+2 regression moments per exercise date
+with an identical redundant solve on every rank (LSM, csrc/kernels_lsm.hip) -- with the oracle
+standing in for the per-shard kernels.  The result must equal the single-rank run.
+"""
+import math
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from montecarlooptionspricer_amd.sharding import combine_sums, price_from_sums, shard_range
+from oracle.binding import Oracle
+
+SEED, DT = 20251031, 1.0 / 252.0
+
+
+def test_shard_range_partitions_exactly():
+    for n in (0, 1, 7, 10_000_000, 64_000_001):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and sum(c for _, c in spans) == n
+            for (b0, c0), (b1, _) in zip(spans, spans[1:]):
+                assert b0 + c0 == b1
+            assert max(c for _, c in spans) - min(c for _, c in spans) <= 1
+    with pytest.raises(ValueError):
+        shard_range(10, 2, 2)
+
+
+def test_combine_and_price_from_sums():
+    x = np.random.RandomState(0).rand(1000)
+    parts = [(x[:300].sum(), (x[:300] ** 2).sum(), 300.0), (x[300:].sum(), (x[300:] ** 2).sum(), 700.0)]
+    m, se = price_from_sums(combine_sums(parts), discount=0.5)
+    assert abs(m - 0.5 * x.mean()) < 1e-14 and abs(se - 0.5 * x.std(ddof=1) / math.sqrt(1000)) < 1e-14
+
+
+def _lsm_sharded(S_local, r, K, maturity, dt, is_call, p):
+    """Host restatement of the device LSM protocol on one shard (step-major S_local[j][path])."""
+    pay = (lambda s: np.maximum(0.0, s - K)) if is_call else (lambda s: np.maximum(0.0, K - s))
+    M = S_local.shape[0]
+    disc = math.exp(-r * dt)
+    V = pay(S_local[M - 1])
+    for j in range(M - 2, -1, -1):
+        if j * dt > maturity:
+            V = V * disc
+            continue
+        s = S_local[j]
+        pj = pay(s)
+        itm = pj > 1e-14
+        x = s[itm] / K - 1.0
+        y = V[itm] * disc
+        mom = np.array([np.sum(x ** q) for q in range(2 * p + 1)] + [np.sum(x ** q * y) for q in range(p + 1)])
+        t = torch.from_numpy(mom)
+        dist.all_reduce(t)                                   # the one exchange step per exercise date
+        mom = t.numpy()
+        Vn = np.zeros_like(V)
+        if mom[0] > 0:
+            G = np.array([[mom[a + b] for b in range(p + 1)] for a in range(p + 1)])
+            c = np.linalg.pinv(G, rcond=1e-12) @ mom[2 * p + 1:]
+            Vn[itm] = np.maximum(pj[itm], np.polynomial.polynomial.polyval(s[itm] / K - 1.0, c))
+        otm = pj < 1e-14
+        Vn[otm] = V[otm] * disc
+        V = Vn
+    t = torch.tensor([V.sum(), (V ** 2).sum(), float(len(V))], dtype=torch.float64)
+    dist.all_reduce(t)
+    return price_from_sums(t.tolist())
+
+
+def _worker(rank, world, port, n_paths, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    orc = Oracle()
+    begin, count = shard_range(n_paths, rank, world)
+    # European, config C1 shape (252 steps)
+    S = orc.paths_gbm(SEED, 100.0, 0.04, 0.2, DT, 252, begin, count)
+    payoff = np.maximum(0.0, S[-1] - 100.0)
+    t = torch.tensor([payoff.sum(), (payoff ** 2).sum(), float(count)], dtype=torch.float64)
+    dist.all_reduce(t)
+    euro = price_from_sums(t.tolist(), discount=math.exp(-0.04))
+    # American put, config C3 shape (50 exercise dates)
+    S3 = orc.paths_gbm(SEED, 100.0, 0.04, 0.2, 0.02, 50, begin, count)
+    lsm = _lsm_sharded(S3, 0.04, 100.0, 1.0, 0.02, False, 2)
+    if rank == 0:
+        out.put((euro, lsm))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_two_rank_job_equals_single_rank():
+    n_paths, world = 6001, 2          # odd on purpose: unequal shards
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, (port := _free_port()) if r == 0 else port, n_paths, out))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    euro, lsm = out.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    orc = Oracle()
+    full = orc.paths_gbm(SEED, 100.0, 0.04, 0.2, DT, 252, 0, n_paths)
+    m, se = orc.price_european(full, 100.0, 0.04, 1.0, True)
+    assert abs(euro[0] - m) <= 1e-12 * m and abs(euro[1] - se) <= 1e-9 * se
+    full3 = orc.paths_gbm(SEED, 100.0, 0.04, 0.2, 0.02, 50, 0, n_paths)
+    want, v0 = orc.lsm_price(full3, 0.04, 100.0, 1.0, 0.02, False, 2, want_v0=True)
+    assert abs(lsm[0] - want) <= 1e-8 * want, (lsm, want)
+    assert abs(lsm[1] - v0.std(ddof=1) / math.sqrt(n_paths)) <= 1e-6 * lsm[1]
