@@ -58,9 +58,12 @@ const char* mcg_version(void);
 int mcg_device_count(int* count);
 
 /* ---- context ---------------------------------------------------------------------------- */
-/* external_stream: a hipStream_t to launch on (e.g. torch's current stream), or NULL to let the
- * ctx create its own non-blocking stream. */
-int mcg_init(mcg_ctx** ctx, int device, void* external_stream);
+/* mcg_init: the ctx creates its own non-blocking stream.
+ * mcg_init_on_stream: the ctx launches on the caller's hipStream_t (e.g. torch's current stream);
+ * NULL there means the legacy default stream.  Use this form when a collective installed with
+ * mcg_set_allreduce enqueues work on that same stream. */
+int mcg_init(mcg_ctx** ctx, int device);
+int mcg_init_on_stream(mcg_ctx** ctx, int device, void* stream);
 int mcg_finalize(mcg_ctx* ctx);
 int mcg_synchronize(mcg_ctx* ctx);
 int mcg_trim(mcg_ctx* ctx); /* release cached device buffers */

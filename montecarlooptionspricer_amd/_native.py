@@ -3,6 +3,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "lib", "libmcgpu.so")
@@ -38,13 +39,23 @@ def load_library():
     if not os.path.exists(_LIB):
         raise McgError(f"{_LIB} not found: build it with `make lib` (or __graft_entry__.build()); "
                        "this package has no CPU fallback")
+    # One process can host only ONE HIP runtime.  torch wheels bundle their own libamdhip64 (same
+    # SONAME as /opt/rocm's): if torch is imported first, libmcgpu binds to that copy and both
+    # coexist; the other order gives torch "No HIP GPUs are available".  So when torch is
+    # installed, import it before dlopen'ing libmcgpu (MCG_NO_TORCH_PRELOAD=1 skips this).
+    if "torch" not in sys.modules and not os.environ.get("MCG_NO_TORCH_PRELOAD"):
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     L = C.CDLL(_LIB)
     dp = C.POINTER(C.c_double)
     vp = C.c_void_p
     L.mcg_last_error.restype = C.c_char_p
     L.mcg_version.restype = C.c_char_p
     L.mcg_device_count.argtypes = [C.POINTER(C.c_int)]
-    L.mcg_init.argtypes = [C.POINTER(vp), C.c_int, vp]
+    L.mcg_init.argtypes = [C.POINTER(vp), C.c_int]
+    L.mcg_init_on_stream.argtypes = [C.POINTER(vp), C.c_int, vp]
     L.mcg_finalize.argtypes = [vp]
     L.mcg_synchronize.argtypes = [vp]
     L.mcg_trim.argtypes = [vp]

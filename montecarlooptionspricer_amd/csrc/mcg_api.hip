@@ -199,7 +199,7 @@ int mcg_device_count(int* count) {
     return MCG_OK;
 }
 
-int mcg_init(mcg_ctx** out, int device, void* external_stream) {
+static int init_impl(mcg_ctx** out, int device, bool adopt, void* external_stream) {
     if (!out) return fail(MCG_ERR_INVALID, "ctx out pointer is NULL");
     *out = nullptr;
     int n = 0;
@@ -221,7 +221,7 @@ int mcg_init(mcg_ctx** out, int device, void* external_stream) {
     if (!ctx) return fail(MCG_ERR_OOM, "host allocation failed");
     ctx->device = device;
     ctx->n_cus = prop.multiProcessorCount;
-    if (external_stream) {
+    if (adopt) {
         ctx->stream = (hipStream_t)external_stream;
         ctx->owns_stream = false;
     } else {
@@ -245,6 +245,10 @@ int mcg_init(mcg_ctx** out, int device, void* external_stream) {
     *out = ctx;
     return MCG_OK;
 }
+
+int mcg_init(mcg_ctx** out, int device) { return init_impl(out, device, false, nullptr); }
+
+int mcg_init_on_stream(mcg_ctx** out, int device, void* stream) { return init_impl(out, device, true, stream); }
 
 int mcg_finalize(mcg_ctx* ctx) {
     if (!ctx) return MCG_OK;

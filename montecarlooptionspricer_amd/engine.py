@@ -76,7 +76,10 @@ class PathEngine:
     def __init__(self, device: int = 0, stream: Optional[int] = None):
         self._L = N.load_library()
         self._ctx = C.c_void_p()
-        check(self._L.mcg_init(C.byref(self._ctx), int(device), C.c_void_p(stream) if stream else None))
+        if stream is None:
+            check(self._L.mcg_init(C.byref(self._ctx), int(device)))
+        else:  # adopt the caller's stream; 0 is the legacy default stream (torch's default)
+            check(self._L.mcg_init_on_stream(C.byref(self._ctx), int(device), C.c_void_p(int(stream))))
         self._cb = None  # keep the ctypes callback alive
         self.device = device
 

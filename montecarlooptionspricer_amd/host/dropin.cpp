@@ -28,7 +28,7 @@ struct ThreadCtx {
         if (!ctx) {
             int dev = 0;
             if (const char* e = std::getenv("MCG_DEVICE")) dev = std::atoi(e);
-            if (mcg_init(&ctx, dev, nullptr) != MCG_OK) throw std::runtime_error(mcg_last_error());
+            if (mcg_init(&ctx, dev) != MCG_OK) throw std::runtime_error(mcg_last_error());
         }
         return ctx;
     }
