@@ -96,26 +96,14 @@ __global__ __launch_bounds__(256) void k_lsm_sweep(LsmArgs a) {
     }
 }
 
-// partials[n_blocks][nm] -> moments[nm]; one block, fixed order.
-__global__ __launch_bounds__(256) void k_lsm_reduce(const double* partials, int n_blocks, int nm, double* moments) {
-    __shared__ double red[256];
-    for (int q = 0; q < nm; ++q) {
-        double s = 0.0;
-        for (int b = threadIdx.x; b < n_blocks; b += 256) s += partials[(int64_t)b * nm + q];
-        s = wave_sum(s);
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-        __syncthreads();
-        if (threadIdx.x == 0) moments[q] = (red[0] + red[1]) + (red[2] + red[3]);
-        __syncthreads();
-    }
-}
-
-// Solve the normal equations of the scaled basis from the (all-reduced) moments.
-// G[a][b] = m[a+b], rhs[a] = m[2p+1+a].  Equilibrate, cyclic Jacobi eigen-decomposition,
-// pseudo-inverse with relative eigenvalue cut 1e-12 (genuinely rank-deficient dates only).
-__global__ void k_lsm_solve(const double* moments, int nb, double* coef) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    double G[9][9], Q[9][9], rhs[9], d[9];
+// Solve the normal equations of the scaled basis from the (all-reduced) moments; one thread.
+// G[a][b] = m[a+b], rhs[a] = m[2p+1+a], equilibrated to unit diagonal.
+// Fast path: LDL^T without pivoting when every pivot stays above 1e-10 (the usual, well-conditioned
+// date: ~1 us).  Otherwise (one ITM path, all paths equal at j = 0, ...): cyclic Jacobi
+// eigen-decomposition and a pseudo-inverse with relative eigenvalue cut 1e-12, which yields the
+// projection the reference's min-norm SVD solve gives at the data points.
+__device__ void lsm_solve_one(const double* moments, int nb, double* coef) {
+    double G[9][9], Q[9][9], rhs[9], d[9], sol[9];
     const double count = moments[0];
     coef[9] = count;
     for (int a = 0; a < 9; ++a) coef[a] = 0.0;
@@ -126,11 +114,43 @@ __global__ void k_lsm_solve(const double* moments, int nb, double* coef) {
     }
     for (int a = 0; a < nb; ++a) {
         rhs[a] = moments[2 * nb - 1 + a] * d[a];
-        for (int b = 0; b < nb; ++b) {
-            G[a][b] = moments[a + b] * d[a] * d[b];
-            Q[a][b] = a == b ? 1.0 : 0.0;
+        for (int b = 0; b < nb; ++b) G[a][b] = moments[a + b] * d[a] * d[b];
+    }
+    // ---- fast path: LDL^T in Q (L below the diagonal, D on it) ----
+    bool ok = true;
+    for (int j = 0; j < nb && ok; ++j) {
+        double dj = G[j][j];
+        for (int k = 0; k < j; ++k) dj -= Q[j][k] * Q[j][k] * Q[k][k];
+        if (!(dj > 1e-10)) {
+            ok = false;
+            break;
+        }
+        Q[j][j] = dj;
+        const double inv = 1.0 / dj;
+        for (int i = j + 1; i < nb; ++i) {
+            double v = G[i][j];
+            for (int k = 0; k < j; ++k) v -= Q[i][k] * Q[j][k] * Q[k][k];
+            Q[i][j] = v * inv;
         }
     }
+    if (ok) {
+        for (int i = 0; i < nb; ++i) {  // L y = rhs
+            double v = rhs[i];
+            for (int k = 0; k < i; ++k) v -= Q[i][k] * sol[k];
+            sol[i] = v;
+        }
+        for (int i = 0; i < nb; ++i) sol[i] /= Q[i][i];
+        for (int i = nb - 1; i >= 0; --i) {  // L^T x = y
+            double v = sol[i];
+            for (int k = i + 1; k < nb; ++k) v -= Q[k][i] * sol[k];
+            sol[i] = v;
+        }
+        for (int a = 0; a < nb; ++a) coef[a] = sol[a] * d[a];
+        return;
+    }
+    // ---- rank-deficient / ill-conditioned date: Jacobi pseudo-inverse ----
+    for (int a = 0; a < nb; ++a)
+        for (int b = 0; b < nb; ++b) Q[a][b] = a == b ? 1.0 : 0.0;
     for (int sweep = 0; sweep < 50; ++sweep) {
         double off = 0.0;
         for (int p = 0; p < nb; ++p)
@@ -164,7 +184,6 @@ __global__ void k_lsm_solve(const double* moments, int nb, double* coef) {
     double lmax = 0.0;
     for (int a = 0; a < nb; ++a) lmax = fmax(lmax, G[a][a]);
     const double cut = lmax * 1e-12;
-    double sol[9];
     for (int a = 0; a < nb; ++a) sol[a] = 0.0;
     for (int e = 0; e < nb; ++e) {
         const double lam = G[e][e];
@@ -175,6 +194,28 @@ __global__ void k_lsm_solve(const double* moments, int nb, double* coef) {
         for (int a = 0; a < nb; ++a) sol[a] += w * Q[a][e];
     }
     for (int a = 0; a < nb; ++a) coef[a] = sol[a] * d[a];
+}
+
+// One block.  do_reduce: partials[n_blocks][nm] -> moments[nm] in a fixed order (wave w sums moments
+// w, w+4, ...: lanes stride over the blocks, then a wavefront butterfly).  do_solve: moments -> coef.
+// Single GPU: both in one launch.  Sharded: reduce, all-reduce of `moments`, then solve.
+__global__ __launch_bounds__(256) void k_lsm_reduce_solve(const double* partials, int n_blocks, int nm, int nb,
+                                                          double* moments, double* coef, int do_reduce, int do_solve) {
+    __shared__ double sm[32];
+    if (do_reduce) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        for (int q = wave; q < nm; q += 4) {
+            double s = 0.0;
+            for (int b = lane; b < n_blocks; b += 64) s += partials[(int64_t)b * nm + q];
+            s = wave_sum(s);
+            if (lane == 0) {
+                moments[q] = s;  // for the all-reduce / the host
+                sm[q] = s;       // for the solve below (same block: hand over through LDS)
+            }
+        }
+        __syncthreads();
+    }
+    if (do_solve && threadIdx.x == 0) lsm_solve_one(do_reduce ? sm : moments, nb, coef);
 }
 
 // sum V, sum V^2 -> partials[grid][2]
@@ -256,17 +297,21 @@ int run_lsm(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double maturit
     for (int j = M - 2; j >= 0; --j) {
         const bool reg = regress_at(j);
         if (reg) {
-            {
-                TimedLaunch t(ctx, MCG_K_LSM_SOLVE);
-                hipLaunchKernelGGL(k_lsm_reduce, dim3(1), dim3(256), 0, ctx->stream, ctx->partials, grid, nm, moments);
-            }
             if (ctx->allreduce) {
+                {
+                    TimedLaunch t(ctx, MCG_K_LSM_SOLVE);
+                    hipLaunchKernelGGL(k_lsm_reduce_solve, dim3(1), dim3(256), 0, ctx->stream, ctx->partials, grid, nm,
+                                       nb, moments, coef, 1, 0);
+                }
                 if (ctx->allreduce(ctx->allreduce_user, moments, nm, (void*)ctx->stream) != 0)
                     return fail(MCG_ERR_COMM, "all-reduce of LSM moments failed at date %d", j);
-            }
-            {
                 TimedLaunch t(ctx, MCG_K_LSM_SOLVE);
-                hipLaunchKernelGGL(k_lsm_solve, dim3(1), dim3(64), 0, ctx->stream, moments, nb, coef);
+                hipLaunchKernelGGL(k_lsm_reduce_solve, dim3(1), dim3(256), 0, ctx->stream, ctx->partials, grid, nm, nb,
+                                   moments, coef, 0, 1);
+            } else {
+                TimedLaunch t(ctx, MCG_K_LSM_SOLVE);
+                hipLaunchKernelGGL(k_lsm_reduce_solve, dim3(1), dim3(256), 0, ctx->stream, ctx->partials, grid, nm, nb,
+                                   moments, coef, 1, 1);
             }
         }
         a.upd = reg ? UPD_REGRESS : UPD_DISCOUNT;

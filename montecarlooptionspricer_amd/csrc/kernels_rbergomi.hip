@@ -4,19 +4,40 @@
 //   Z -> X = sqrt(2H) eta Re(FFT^-(phi (.) Z)/Mz)   (:347-348, :264-292)
 //   v_n = xi exp(X_n - 0.5 eta^2 t_n^{2H})          (:349, :294-309)
 //   S_{n+1} = S_n exp((r - v_n/2) dt + sqrt(max(0,v_n)) dW_n),  dW_n ~ N(0, dt)  (:354-364)
-// Device algorithm: the law of X is reproduced by the real Volterra (circular-convolution) form
+//
+// Device algorithm.  The law of X is reproduced by the real Volterra (circular-convolution) form
 //   X_n = sum_{j<Mz} kappa_{(n-j) mod Mz} eps_j,  eps ~ iid N(0,1)       (host/volterra.cpp)
-// with kappa staged in LDS (periodically extended so a tile of TN outputs reads a contiguous
-// window) and the compensator table next to it.  One path per lane; the per-lane noise eps lives
-// in a step-major scratch slab (coalesced 512-B wave accesses), X tiles of TN steps are
-// accumulated in registers, consumed immediately by the price stepping and never stored.
-// Stores of S are step-major like the GBM kernel.  Terminal payoff reduction as in GBM.
+// which is a contraction over j -- the one place on this path where a matrix instruction fits:
+//   X[n][path] = sum_j C[n][j] * eps[j][path],  C[n][j] = kappa_{(n-j) mod Mz}   (circulant).
+// One wavefront owns 16 paths.  Per 4 values of j it issues one v_mfma_f64_16x16x4_f64 per 16-step
+// tile: A = a 16x4 slice of C read from the LDS-staged, periodically extended weight vector (one
+// ds_read_b64 per lane per MFMA, conflict-free), B = the 4x16 slice of eps that the lanes have just
+// generated from Philox (one normal per lane: no noise is ever stored), D = 16 steps x 16 paths of X
+// accumulated in registers (16 tiles = 256 steps per pass; longer grids run in several passes and
+// regenerate eps).  On gfx950 the fp64 MFMA runs at the fp64 VALU rate (64 cycles per instruction,
+// measured in tools/ubench_mfma_f64.hip, and it does not overlap fp64 VALU work), so this kernel
+// is bound by Mz*steps fp64 FMAs per path, not by HBM; what the MFMA buys is operand delivery:
+// 1 LDS read per 1024 FMAs and no per-lane noise buffer.
+//
+// MFMA register layout on gfx950 (probed, tools/probe_mfma_layout.hip): A lane l = A[l%16][l/16],
+// B lane l = B[l/16][l%16], D lane l reg v = D[4v + l/16][l%16].  Row i of A is given the time
+// index n = 16t + 4(i%4) + i/4, so that D lane (g = l/16, c = l%16) reg v holds
+// X[n = 16t + 4g + v][path c]: four CONSECUTIVE steps of one path per lane.
+//
+// Price stepping happens in that layout, in log space: each lane forms its four increments, a
+// 4-element in-lane prefix plus a wavefront-shuffle scan over the four lane groups gives
+// log S_n for all 16 steps of the tile, S_n = exp(.) is stored step-major (each store instruction
+// writes four full 128-B lines).  Terminal payoff reduction as in the GBM kernel.
 #include "devmath.hpp"
+#include "fastmath.hpp"
 #include "mcg_internal.hpp"
 
 namespace mcg {
 
-constexpr int RB_TN = 8;  // outputs per register tile
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+constexpr int RB_NT = 8;    // 16-step tiles accumulated per pass (128 steps)
+constexpr int RB_PAD = 24;  // periodic extension of the weight vector in LDS
 
 struct RbArgs {
     double* out;
@@ -26,70 +47,121 @@ struct RbArgs {
     int M;  // Mz
     uint64_t path_begin;
     uint32_t k0, k1;
-    double S0, r, xi, dt, sqdt;
+    double S0, logS0, r, xi, dt, sqdt;
     const double* kappa;  // [M]
     const double* comp;   // [n_steps]
-    double* eps;          // scratch [M][lds]
-    int64_t lds;
+    const double2* log_tab;
     double K;
     int is_call;
     double* partials;
 };
 
+// One pass over NT consecutive 16-step tiles starting at step n_base: accumulate X by MFMA, then
+// advance the price through those steps.  Tiles (or single steps) beyond n_steps are computed but
+// neither stored nor added to the running log-price.
+template <int NT>
+__device__ __forceinline__ void rb_pass(const RbArgs& a, const double* kext, const double* comp, const double2* tab,
+                                        int n_base, int g, int c, int a_off, uint64_t id, bool live, double* col,
+                                        double& logS) {
+    const int M = a.M;
+    v4d acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = v4d{0.0, 0.0, 0.0, 0.0};
+
+    const int n_kp = (M + 7) >> 3;
+    for (int kp = 0; kp < n_kp; ++kp) {
+        // this lane's two noise values: j0 = 8kp + 2g, j1 = j0 + 1  (Philox block j0/2)
+        double e0, e1;
+        fm::normal_pair_fast(a.k0, a.k1, id, (uint32_t)(4 * kp + g), STREAM_VOL, tab, e0, e1);
+        const int j0 = 8 * kp + 2 * g;
+        if (j0 >= M) e0 = 0.0;  // only when Mz < 8
+        if (j0 + 1 >= M) e1 = 0.0;
+        const int base = (n_base - 8 * kp) & (M - 1);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const double w = kext[((base + 16 * t) & (M - 1)) + a_off];
+            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(w, e0, acc[t], 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const double w = kext[((base + 16 * t) & (M - 1)) + a_off - 1];
+            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(w, e1, acc[t], 0, 0, 0);
+        }
+    }
+
+    // price stepping; lane (g, c) owns steps nl .. nl+3 of path c in every tile
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int nl = n_base + 16 * t + 4 * g;
+        double z[4];
+        fm::normal_pair_fast(a.k0, a.k1, id, (uint32_t)(nl >> 1), STREAM_PRICE, tab, z[0], z[1]);
+        fm::normal_pair_fast(a.k0, a.k1, id, (uint32_t)((nl >> 1) + 1), STREAM_PRICE, tab, z[2], z[3]);
+        double pre[4];
+        double run = 0.0;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int n = nl + v;
+            const bool valid = n < a.n_steps;
+            const double var = fm::scaled_exp(a.xi, acc[t][v] + (valid ? comp[n] : 0.0));
+            const double sd = fm::sqrt_pos(fmax(var, 1e-300)) * a.sqdt;
+            const double inc = fma(sd, z[v], (a.r - 0.5 * var) * a.dt);
+            run += valid ? inc : 0.0;
+            pre[v] = run;
+        }
+        // inclusive scan of the group totals over g = 0..3 (lanes c, c+16, c+32, c+48)
+        double incl = run;
+        const double up16 = __shfl_up(incl, 16, 64);
+        if (g >= 1) incl += up16;
+        const double up32 = __shfl_up(incl, 32, 64);
+        if (g >= 2) incl += up32;
+        const double lead = logS + (incl - run);
+        const double tile_total = __shfl(incl, 48 + c, 64);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int n = nl + v;
+            const double S = fm::scaled_exp(1.0, lead + pre[v]);
+            if (live && n < a.n_steps) __builtin_nontemporal_store(S, col + (int64_t)(n + 1) * a.ld);
+        }
+        logS += tile_total;
+    }
+}
+
 template <bool PAYOFF>
 __global__ __launch_bounds__(256) void k_rbergomi_paths(RbArgs a) {
     extern __shared__ double smem[];
+    __shared__ double2 tab[fm::LOG_TAB_ENTRIES];
     const int M = a.M;
-    double* kext = smem;                    // [M + 2*TN], kext[i] = kappa[(i - TN) mod M]
-    double* comp = smem + M + 2 * RB_TN;    // [n_steps]
-    for (int i = threadIdx.x; i < M + 2 * RB_TN; i += 256) kext[i] = a.kappa[(i - RB_TN + M) & (M - 1)];
+    double* kext = smem;                 // [M + RB_PAD], kext[i] = kappa[(i - 8) mod M]
+    double* comp = smem + M + RB_PAD;    // [n_steps]
+    for (int i = threadIdx.x; i < M + RB_PAD; i += 256) kext[i] = a.kappa[(i - 8 + 8 * M) & (M - 1)];
     for (int i = threadIdx.x; i < a.n_steps; i += 256) comp[i] = a.comp[i];
+    fm::load_log_table(tab, a.log_tab);
     __syncthreads();
 
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const bool live = i < a.n_paths;
-    const uint64_t id = a.path_begin + (uint64_t)i;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, c = lane & 15;
+    const int64_t p = (int64_t)blockIdx.x * 64 + wave * 16 + c;
+    const bool live = p < a.n_paths;
+    const uint64_t id = a.path_begin + (uint64_t)p;
+    // A operand: this lane supplies row i = c, i.e. local step 4(c%4) + c/4, for k-slot g
+    const int a_off = 4 * (c & 3) + (c >> 2) - 2 * g + 8;
 
-    // volatility-driver noise for this lane
-    double* eps = a.eps + i;
-    for (int b = 0; 2 * b < M; ++b) {
-        double z0, z1;
-        normal_pair(a.k0, a.k1, id, (uint32_t)b, STREAM_VOL, z0, z1);
-        eps[(int64_t)(2 * b) * a.lds] = z0;
-        if (2 * b + 1 < M) eps[(int64_t)(2 * b + 1) * a.lds] = z1;
-    }
+    double* col = a.out + p;
+    if (live && g == 0) __builtin_nontemporal_store(a.S0, col);
+    double logS = a.logS0;
 
-    double* col = a.out + i;
-    double S = a.S0;
-    if (live) __builtin_nontemporal_store(S, col);
-    double zc[2] = {0.0, 0.0};
-    for (int n0 = 0; n0 < a.n_steps; n0 += RB_TN) {
-        double acc[RB_TN];
-#pragma unroll
-        for (int t = 0; t < RB_TN; ++t) acc[t] = 0.0;
-        for (int j = 0; j < M; ++j) {
-            const double e = eps[(int64_t)j * a.lds];
-            const double* w = kext + (((n0 - j) & (M - 1)) + RB_TN);
-#pragma unroll
-            for (int t = 0; t < RB_TN; ++t) acc[t] = fma(w[t], e, acc[t]);
-        }
-#pragma unroll
-        for (int t = 0; t < RB_TN; ++t) {
-            const int n = n0 + t;
-            if (n < a.n_steps) {
-                const double v = a.xi * exp(acc[t] + comp[n]);
-                if ((n & 1) == 0) normal_pair(a.k0, a.k1, id, (uint32_t)(n >> 1), STREAM_PRICE, zc[0], zc[1]);
-                const double drift = (a.r - 0.5 * v) * a.dt;
-                const double sd = sqrt(fmax(0.0, v)) * a.sqdt;
-                S = S * exp(fma(sd, zc[n & 1], drift));
-                col += a.ld;
-                if (live) __builtin_nontemporal_store(S, col);
-            }
-        }
-    }
+    int n_base = 0;
+    for (; n_base + RB_NT * 16 <= a.n_steps; n_base += RB_NT * 16)
+        rb_pass<RB_NT>(a, kext, comp, tab, n_base, g, c, a_off, id, live, col, logS);
+    const int tiles_left = (a.n_steps - n_base + 15) >> 4;  // 0..RB_NT-1, wave-uniform
+    if (tiles_left > 4) rb_pass<8>(a, kext, comp, tab, n_base, g, c, a_off, id, live, col, logS);
+    else if (tiles_left > 2) rb_pass<4>(a, kext, comp, tab, n_base, g, c, a_off, id, live, col, logS);
+    else if (tiles_left > 0) rb_pass<2>(a, kext, comp, tab, n_base, g, c, a_off, id, live, col, logS);
+
     if (PAYOFF) {
         __shared__ double red[2 * 4];
-        const double pay = live ? payoff_of(a.is_call != 0, S, a.K) : 0.0;
+        const double ST = fm::scaled_exp(1.0, logS);
+        const double pay = (live && g == 0) ? payoff_of(a.is_call != 0, ST, a.K) : 0.0;
         double v[2] = {pay, pay * pay};
         block_sum<2, 4>(v, red);
         if (threadIdx.x == 0) {
@@ -101,17 +173,15 @@ __global__ __launch_bounds__(256) void k_rbergomi_paths(RbArgs a) {
 
 int launch_rbergomi(mcg_ctx* ctx, mcg_paths* P, uint64_t seed, double S0, double r, double xi, double H, double eta,
                     double dt, bool want_payoff, double K, int is_call) {
+    if (!(S0 > 0.0)) return fail(MCG_ERR_INVALID, "rBergomi needs S0 > 0 (log-space stepping)");
     std::vector<double> kappa, comp;
     int rc = host_rbergomi_weights(H, eta, dt, P->n_steps, kappa, comp);
     if (rc) return rc;
     const int M = (int)kappa.size();
-    const int64_t n_blocks = (P->n_paths + 255) / 256;
+    const int64_t n_blocks = (P->n_paths + 63) / 64;
     if (n_blocks > 0x7fffffffLL) return fail(MCG_ERR_INVALID, "n_paths too large for one launch");
-    const int64_t lds = n_blocks * 256;
 
     rc = ensure_cap(ctx, &ctx->weights, &ctx->weights_cap, (size_t)M + (size_t)P->n_steps);
-    if (rc) return rc;
-    rc = ensure_cap(ctx, &ctx->scratch, &ctx->scratch_cap, (size_t)M * (size_t)lds);
     if (rc) return rc;
     if (want_payoff) {
         rc = ensure_cap(ctx, &ctx->partials, &ctx->partials_cap, (size_t)(2 * n_blocks));
@@ -133,18 +203,18 @@ int launch_rbergomi(mcg_ctx* ctx, mcg_paths* P, uint64_t seed, double S0, double
     a.k0 = (uint32_t)seed;
     a.k1 = (uint32_t)(seed >> 32);
     a.S0 = S0;
+    a.logS0 = std::log(S0);
     a.r = r;
     a.xi = xi;
     a.dt = dt;
     a.sqdt = std::sqrt(dt);
     a.kappa = ctx->weights;
     a.comp = ctx->weights + M;
-    a.eps = ctx->scratch;
-    a.lds = lds;
+    a.log_tab = (const double2*)ctx->log_tab;
     a.K = K;
     a.is_call = is_call;
     a.partials = ctx->partials;
-    const size_t smem = ((size_t)M + 2 * RB_TN + (size_t)P->n_steps) * sizeof(double);
+    const size_t smem = ((size_t)M + RB_PAD + (size_t)P->n_steps) * sizeof(double);
     {
         TimedLaunch t(ctx, MCG_K_RBERGOMI);
         if (want_payoff)
