@@ -153,10 +153,11 @@ int mcg_timing_get(mcg_ctx* ctx, int kernel /* enum mcg_kernel */, double* total
                    int64_t* launches);
 
 /* Test hook: evaluate one device math routine of the path kernels elementwise (csrc/fastmath.hpp).
- * fn 0: y[2i] = 1*e^x          fn 1: y[2i] = -2 ln x (x in (0,1])       fn 2: y[2i] = sqrt(x)
- * fn 3: x holds raw 64-bit words (w3:w2); y[2i], y[2i+1] = cos, sin(2 pi u2)
- * fn 4: x holds a path id as a double; y[2i], y[2i+1] = normal pair (seed = 1, block 0, stream 0)
- * fn 5: as 4 through the reference-grade (ocml) implementation.  y has 2n doubles. */
+ * y has 4n doubles; element i's results start at y[4i].
+ * fn 0: y[0] = 1*e^x          fn 1: y[0] = -2 ln x (x in (0,1])       fn 2: y[0] = sqrt(x)
+ * fn 3: x holds a 32-bit Philox word wb as a double; y[0], y[1] = cos, sin(2 pi ((wb>>8)+1/2) 2^-24)
+ * fn 4: x holds a path id as a double; y[0..3] = the four normals of block 0, stream 0, seed 1
+ * fn 5: as 4 through the reference-grade (device library) implementation. */
 int mcg_debug_eval(mcg_ctx* ctx, int fn, const double* x, double* y, int64_t n);
 
 #ifdef __cplusplus

@@ -8,17 +8,24 @@
 
 namespace mcg {
 
-// One Philox block -> two N(0,1) deviates (Box-Muller; philox.hpp states the contract).
-__device__ __forceinline__ void normal_pair(uint32_t k0, uint32_t k1, uint64_t path, uint32_t block,
-                                            uint32_t stream, double& z0, double& z1) {
+// One Philox block -> four N(0,1) deviates through the device library's log/sincospi/sqrt
+// (philox.hpp states the contract).  Reference-grade twin of fm::normal_quad_fast; used by the
+// debug hook only.
+__device__ __forceinline__ void normal_quad_ref(uint32_t k0, uint32_t k1, uint64_t path, uint32_t block,
+                                                uint32_t stream, double (&z)[4]) {
     const Philox4 w = philox4x32_10((uint32_t)path, (uint32_t)(path >> 32), block, stream, k0, k1);
-    const double u1 = u01_from_bits(w.w0, w.w1);
-    const double u2 = u01_from_bits(w.w2, w.w3);
-    const double rad = sqrt(-2.0 * log(u1));
-    double s, c;
-    sincospi(2.0 * u2, &s, &c);
-    z0 = rad * c;
-    z1 = rad * s;
+    const uint32_t wa[2] = {w.w0, w.w2}, wb[2] = {w.w1, w.w3};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const uint64_t a40 = ((uint64_t)(wb[h] & 0xFFu) << 32) | wa[h];
+        const double u = ((double)a40 + 0.5) * 0x1p-40;
+        const double f = ((double)(wb[h] >> 8) + 0.5) * 0x1p-24;
+        const double rad = sqrt(-2.0 * log(u));
+        double s, c;
+        sincospi(2.0 * f, &s, &c);
+        z[2 * h] = rad * c;
+        z[2 * h + 1] = rad * s;
+    }
 }
 
 // include/core/common.h:8-14

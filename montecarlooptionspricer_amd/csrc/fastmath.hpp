@@ -8,8 +8,8 @@
 //   scaled_exp(S, a)        S * e^a           any finite a (overflow -> inf, underflow -> 0)
 //   neg2log(u, tab)         -2 ln u           u in (0, 1]; 128-entry {1/c, -2 ln c} table in LDS
 //   sqrt_pos(x)             sqrt(x)           x in [1e-300, 1e300], no denormal/negative handling
-//   sincos_octant(w2, w3)   cos/sin(2 pi u2)  u2 = ((w3:w2 >> 12) + 1/2) 2^-52, from the raw words
-//   normal_pair_fast(...)   the Box-Muller pair of philox.hpp's contract built from the above
+//   sincos_octant(wb)       cos/sin(2 pi f)   f = ((wb >> 8) + 1/2) 2^-24, from the raw Philox word
+//   normal_quad_fast(...)   the four normals of one Philox block (philox.hpp's contract)
 //
 // Polynomials: interpolation at Chebyshev nodes in 60-digit arithmetic, rounded to binary64
 // (tools/gen_coeffs.py prints them with their achieved max error).
@@ -39,9 +39,17 @@ __device__ __forceinline__ double fma_sc(double q, double r, double C) {
 // e^r = 1 + r + r^2 q(r) with q of degree 9 on |r| <= ln2/2 (max rel err 2^-55.8),
 // result = ldexp(S + S*(e^r - 1), k).  18 fp64-class instructions.
 __device__ __forceinline__ double scaled_exp(double S, double a) {
-    const double kd = __builtin_rint(a * 0x1.71547652b82fep+0);
-    double r = __builtin_fma(kd, -0x1.62e42fee00000p-1, a);
-    r = __builtin_fma(kd, -0x1.a39ef35793c76p-33, r);
+    // Wave-uniform shortcut: when every lane has |a| <= 0.34 (< ln2/2) the range reduction is the
+    // identity (k = 0, r = a) and is skipped for the whole wave -- bit-identical to the general path,
+    // and the common case for a price step (|drift + vol z| ~ 1e-2).
+    const bool reduce = __builtin_amdgcn_ballot_w64(!(__builtin_fabs(a) <= 0.34)) != 0ull;
+    double kd = 0.0, r = a;
+    if (reduce) {
+        asm volatile("" ::);  // keep this a real (scalar) branch: hipcc would otherwise if-convert it
+        kd = __builtin_rint(a * 0x1.71547652b82fep+0);
+        r = __builtin_fma(kd, -0x1.62e42fee00000p-1, a);
+        r = __builtin_fma(kd, -0x1.a39ef35793c76p-33, r);
+    }
     double q = 0x1.af38a9b0ec855p-26;
     q = fma_sc(q, r, 0x1.289185613a3d6p-22);
     q = fma_sc(q, r, 0x1.71de0dae63bb3p-19);
@@ -53,8 +61,12 @@ __device__ __forceinline__ double scaled_exp(double S, double a) {
     q = fma_sc(q, r, 0x1.5555555555556p-3);
     q = fma_sc(q, r, 0x1.0000000000001p-1);
     const double em1 = __builtin_fma(r * r, q, r);  // e^r - 1
-    const double v = __builtin_fma(S, em1, S);
-    return __builtin_ldexp(v, (int)kd);  // v_cvt_i32_f64 saturates; v_ldexp_f64 clamps
+    double v = __builtin_fma(S, em1, S);
+    if (reduce) {
+        asm volatile("" ::);
+        v = __builtin_ldexp(v, (int)kd);  // v_cvt_i32_f64 saturates; v_ldexp_f64 clamps
+    }
+    return v;
 }
 
 // -2 ln u for u in (0,1].  u = z * 2^k with z in [0.6875, 1.375) (so u near 1 has k = 0 and no
@@ -72,10 +84,10 @@ __device__ __forceinline__ double neg2log(double u, const double2* tab) {
     const double r = __builtin_fma(z, e.x, -1.0);
     const double r2 = r * r;
     double p = 0x1.2493c2a2efcc3p-3;
-    p = __builtin_fma(p, r, -0x1.5556fe0374498p-3);
-    p = __builtin_fma(p, r, 0x1.999999991c5b3p-3);
-    p = __builtin_fma(p, r, -0x1.ffffffff7319dp-3);
-    p = __builtin_fma(p, r, 0x1.5555555555555p-2);
+    p = fma_sc(p, r, -0x1.5556fe0374498p-3);
+    p = fma_sc(p, r, 0x1.999999991c5b3p-3);
+    p = fma_sc(p, r, -0x1.ffffffff7319dp-3);
+    p = fma_sc(p, r, 0x1.5555555555555p-2);
     const double l1p = __builtin_fma(r2 * r, p, __builtin_fma(r2, -0.5, r));  // log1p(r)
     // -2 ln u = -2 k ln2 + (-2 ln c) - 2 log1p(r)
     const double base = __builtin_fma((double)k, -0x1.62e42fefa39efp+0, e.y);
@@ -94,57 +106,61 @@ __device__ __forceinline__ double sqrt_pos(double x) {
     return __builtin_fma(d, h, g);
 }
 
-// cos(2 pi u2), sin(2 pi u2) with u2 = ((w3:w2 >> 12) + 1/2) * 2^-52, straight from the Philox words:
-// 8 u2 = q + x, q = top 3 bits (octant), x = (rem + 1/2) 2^-49 in (0,1); odd octants use 1 - x, which
-// is the bitwise complement of rem.  sin/cos(pi/4 * y) on [0,1] by polynomials in y^2 (max rel err
-// 2^-54 / 2^-55), then the octant symmetries as sign-bit xors and one swap.
-__device__ __forceinline__ void sincos_octant(uint32_t w2, uint32_t w3, double& c_out, double& s_out) {
-    const uint32_t odd = 0u - ((w3 >> 29) & 1u);           // all ones in odd octants
-    uint32_t mhi = (w3 >> 9) & 0xFFFFFu;                    // mantissa bits 51..32 = rem bits 48..29
-    uint32_t mlo = (w3 << 23) | ((w2 >> 9) & 0x7FFFF8u);    // mantissa bits 31..3 = rem bits 28..0
-    mhi ^= odd & 0xFFFFFu;
-    mlo ^= odd & 0xFFFFFFF8u;
-    const double y = (from_words(0x3FF00000u | mhi, mlo) - 1.0) + 0x1p-50;
+// cos(2 pi f), sin(2 pi f) with f = ((wb >> 8) + 1/2) * 2^-24, straight from the Philox word:
+// 8 f = q + y, q = top 3 bits (octant), y = (rem + 1/2) 2^-21 in (0,1) with rem the low 21 bits; odd
+// octants use 1 - y, which is the bitwise complement of rem.  sin/cos(pi/4 * y) on [0,1] by
+// polynomials in y^2 (max rel err 2^-54 / 2^-55), then the octant symmetries as sign-bit xors and
+// one swap.
+__device__ __forceinline__ void sincos_octant(uint32_t wb, double& c_out, double& s_out) {
+    const uint32_t odd = 0u - ((wb >> 29) & 1u);  // all ones in odd octants
+    const uint32_t rem = ((wb >> 8) ^ odd) & 0x1FFFFFu;
+    const double y = __builtin_fma((double)rem, 0x1p-21, 0x1p-22);
     const double w = y * y;
     double ps = 0x1.e4a9d9166f052p-38;
-    ps = __builtin_fma(ps, w, -0x1.e3027dea82bd7p-30);
-    ps = __builtin_fma(ps, w, 0x1.50783208843ebp-22);
-    ps = __builtin_fma(ps, w, -0x1.32d2cce500387p-15);
-    ps = __builtin_fma(ps, w, 0x1.466bc6775a476p-9);
-    ps = __builtin_fma(ps, w, -0x1.4abbce625be52p-4);
-    const double sn = y * __builtin_fma(ps, w, 0x1.921fb54442d18p-1);
+    ps = fma_sc(ps, w, -0x1.e3027dea82bd7p-30);
+    ps = fma_sc(ps, w, 0x1.50783208843ebp-22);
+    ps = fma_sc(ps, w, -0x1.32d2cce500387p-15);
+    ps = fma_sc(ps, w, 0x1.466bc6775a476p-9);
+    ps = fma_sc(ps, w, -0x1.4abbce625be52p-4);
+    const double sn = y * fma_sc(ps, w, 0x1.921fb54442d18p-1);
     double pc = -0x1.b2f3eb054afcdp-42;
-    pc = __builtin_fma(pc, w, 0x1.f9ce245cada0bp-34);
-    pc = __builtin_fma(pc, w, -0x1.a6d1eef479be1p-26);
-    pc = __builtin_fma(pc, w, 0x1.e1f5068688d5bp-19);
-    pc = __builtin_fma(pc, w, -0x1.55d3c7e3cb241p-12);
-    pc = __builtin_fma(pc, w, 0x1.03c1f081b5ac0p-6);
-    pc = __builtin_fma(pc, w, -0x1.3bd3cc9be45dep-2);
+    pc = fma_sc(pc, w, 0x1.f9ce245cada0bp-34);
+    pc = fma_sc(pc, w, -0x1.a6d1eef479be1p-26);
+    pc = fma_sc(pc, w, 0x1.e1f5068688d5bp-19);
+    pc = fma_sc(pc, w, -0x1.55d3c7e3cb241p-12);
+    pc = fma_sc(pc, w, 0x1.03c1f081b5ac0p-6);
+    pc = fma_sc(pc, w, -0x1.3bd3cc9be45dep-2);
     const double cs = __builtin_fma(pc, w, 1.0);
-    // octant q = w3 >> 29: swap for q in {1,2,5,6} (bit0 ^ bit1), cos < 0 for q in {2,3,4,5}
+    // octant q = wb >> 29: swap for q in {1,2,5,6} (bit0 ^ bit1), cos < 0 for q in {2,3,4,5}
     // (bit1 ^ bit2), sin < 0 for q >= 4 (bit2)
-    const bool swap = (((w3 >> 29) ^ (w3 >> 30)) & 1u) != 0u;
+    const bool swap = (((wb >> 29) ^ (wb >> 30)) & 1u) != 0u;
     const double cc = swap ? sn : cs;
     const double ss = swap ? cs : sn;
-    const uint32_t sign_c = (w3 ^ (w3 << 1)) & 0x80000000u;
-    const uint32_t sign_s = w3 & 0x80000000u;
+    const uint32_t sign_c = (wb ^ (wb << 1)) & 0x80000000u;
+    const uint32_t sign_s = wb & 0x80000000u;
     c_out = from_words((uint32_t)__double2hiint(cc) ^ sign_c, (uint32_t)__double2loint(cc));
     s_out = from_words((uint32_t)__double2hiint(ss) ^ sign_s, (uint32_t)__double2loint(ss));
 }
 
-// Same contract as mcg::normal_pair (philox.hpp), built from the pieces above.
-__device__ __forceinline__ void normal_pair_fast(uint32_t k0, uint32_t k1, uint64_t path, uint32_t block,
-                                                 uint32_t stream, const double2* log_tab, double& z0, double& z1) {
-    const Philox4 w = philox4x32_10((uint32_t)path, (uint32_t)(path >> 32), block, stream, k0, k1);
-    const double u1 = u01_from_bits(w.w0, w.w1);
-    const double rad = sqrt_pos(neg2log(u1, log_tab));
+// One Box-Muller pair from 64 Philox bits (philox.hpp contract).
+__device__ __forceinline__ void box_muller_pair(uint32_t wa, uint32_t wb, const double2* log_tab, double& z0,
+                                                double& z1) {
+    const double rad = sqrt_pos(neg2log(radius_u01(wa, wb), log_tab));
     double c, s;
-    sincos_octant(w.w2, w.w3, c, s);
+    sincos_octant(wb, c, s);
     z0 = rad * c;
     z1 = rad * s;
 }
 
-// Cooperative copy of the log table (global, 2 KiB) into LDS; call before the first normal_pair_fast
+// One Philox block -> four N(0,1) deviates.
+__device__ __forceinline__ void normal_quad_fast(uint32_t k0, uint32_t k1, uint64_t path, uint32_t block,
+                                                 uint32_t stream, const double2* log_tab, double (&z)[4]) {
+    const Philox4 w = philox4x32_10((uint32_t)path, (uint32_t)(path >> 32), block, stream, k0, k1);
+    box_muller_pair(w.w0, w.w1, log_tab, z[0], z[1]);
+    box_muller_pair(w.w2, w.w3, log_tab, z[2], z[3]);
+}
+
+// Cooperative copy of the log table (global, 2 KiB) into LDS; call before the first normal_quad_fast
 // and follow with __syncthreads().
 __device__ __forceinline__ void load_log_table(double2* lds_tab, const double2* __restrict__ gtab) {
     for (int i = threadIdx.x; i < LOG_TAB_ENTRIES; i += blockDim.x) lds_tab[i] = gtab[i];

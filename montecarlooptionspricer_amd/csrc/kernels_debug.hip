@@ -15,20 +15,21 @@ __global__ __launch_bounds__(256) void k_debug_eval(int fn, const double* x, dou
     if (i >= n) return;
     const double v = x[i];
     double a = 0.0, b = 0.0;
+    double z[4] = {0.0, 0.0, 0.0, 0.0};
     switch (fn) {
         case 0: a = fm::scaled_exp(1.0, v); break;
         case 1: a = fm::neg2log(v, tab); break;
         case 2: a = fm::sqrt_pos(v); break;
-        case 3: {
-            const uint64_t w = (uint64_t)__double_as_longlong(v);
-            fm::sincos_octant((uint32_t)w, (uint32_t)(w >> 32), a, b);
-            break;
-        }
-        case 4: fm::normal_pair_fast(1u, 0u, (uint64_t)v, 0u, STREAM_PRICE, tab, a, b); break;
-        default: normal_pair(1u, 0u, (uint64_t)v, 0u, STREAM_PRICE, a, b); break;
+        case 3: fm::sincos_octant((uint32_t)v, a, b); break;
+        case 4: fm::normal_quad_fast(1u, 0u, (uint64_t)v, 0u, STREAM_PRICE, tab, z); break;
+        default: normal_quad_ref(1u, 0u, (uint64_t)v, 0u, STREAM_PRICE, z); break;
     }
-    y[2 * i] = a;
-    y[2 * i + 1] = b;
+    if (fn < 4) {
+        z[0] = a;
+        z[1] = b;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) y[4 * i + e] = z[e];
 }
 
 }  // namespace mcg
@@ -40,7 +41,7 @@ extern "C" int mcg_debug_eval(mcg_ctx* ctx, int fn, const double* x, double* y, 
     MCG_HIP(hipSetDevice(ctx->device));
     double *dx = nullptr, *dy = nullptr;
     MCG_HIP(hipMalloc((void**)&dx, (size_t)n * sizeof(double)));
-    if (hipMalloc((void**)&dy, (size_t)n * 2 * sizeof(double)) != hipSuccess) {
+    if (hipMalloc((void**)&dy, (size_t)n * 4 * sizeof(double)) != hipSuccess) {
         (void)hipFree(dx);
         return fail(MCG_ERR_OOM, "hipMalloc failed");
     }
@@ -50,7 +51,7 @@ extern "C" int mcg_debug_eval(mcg_ctx* ctx, int fn, const double* x, double* y, 
     if (rc == MCG_OK) {
         hipLaunchKernelGGL(k_debug_eval, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, fn, dx, dy, n,
                            (const double2*)ctx->log_tab);
-        if (hipMemcpyAsync(y, dy, (size_t)n * 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        if (hipMemcpyAsync(y, dy, (size_t)n * 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
             hipStreamSynchronize(ctx->stream) != hipSuccess)
             rc = fail(MCG_ERR_HIP, "debug eval failed: %s", hipGetErrorString(hipGetLastError()));
     }

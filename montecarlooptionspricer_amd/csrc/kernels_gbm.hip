@@ -1,4 +1,4 @@
-// GBM path generation for gfx950: one path per lane, Philox normals, S kept in a register,
+// GBM path generation for gfx950: one path per lane, Philox normals (four per block), S in a register,
 // step-major stores so a wavefront writes 64 consecutive doubles (512 B, four full 128-B lines)
 // per time step, and a wavefront-shuffle reduction of the terminal payoff.
 //
@@ -37,24 +37,33 @@ __global__ __launch_bounds__(256) void k_gbm_paths(GbmArgs a) {
     const uint64_t id = a.path_begin + (uint64_t)i;
     double* col = a.out + i;
     double S = a.S0;
-    if (live) __builtin_nontemporal_store(S, col);
-    const int n_pairs = a.n_steps >> 1;
-    for (int b = 0; b < n_pairs; ++b) {
+    __builtin_nontemporal_store(S, col);
+    // One Philox block feeds two Box-Muller pairs = four steps.  The loop runs per PAIR with the
+    // Philox call under a wave-uniform branch on even pairs, so the compiled body holds one copy of
+    // the log / sincos / exp code (two copies push the polynomial constants out of the SGPR file).
+    const int n_pairs = (a.n_steps + 1) >> 1;
+    Philox4 w = {0u, 0u, 0u, 0u};
+#pragma unroll 1
+    for (int pr = 0; pr < n_pairs; ++pr) {
+        uint32_t wa, wb;
+        if ((pr & 1) == 0) {
+            w = philox4x32_10((uint32_t)id, (uint32_t)(id >> 32), (uint32_t)(pr >> 1), STREAM_PRICE, a.k0, a.k1);
+            wa = w.w0;
+            wb = w.w1;
+        } else {
+            wa = w.w2;
+            wb = w.w3;
+        }
         double z0, z1;
-        fm::normal_pair_fast(a.k0, a.k1, id, (uint32_t)b, STREAM_PRICE, tab, z0, z1);
+        fm::box_muller_pair(wa, wb, tab, z0, z1);
         S = fm::scaled_exp(S, fma(a.vol, z0, a.drift));
         col += a.ld;
-        if (live) __builtin_nontemporal_store(S, col);
-        S = fm::scaled_exp(S, fma(a.vol, z1, a.drift));
-        col += a.ld;
-        if (live) __builtin_nontemporal_store(S, col);
-    }
-    if (a.n_steps & 1) {
-        double z0, z1;
-        fm::normal_pair_fast(a.k0, a.k1, id, (uint32_t)n_pairs, STREAM_PRICE, tab, z0, z1);
-        S = fm::scaled_exp(S, fma(a.vol, z0, a.drift));
-        col += a.ld;
-        if (live) __builtin_nontemporal_store(S, col);
+        __builtin_nontemporal_store(S, col);
+        if (2 * pr + 1 < a.n_steps) {  // wave-uniform: false only for the last pair of an odd grid
+            S = fm::scaled_exp(S, fma(a.vol, z1, a.drift));
+            col += a.ld;
+            __builtin_nontemporal_store(S, col);
+        }
     }
     if (PAYOFF) {
         __shared__ double red[2 * 4];

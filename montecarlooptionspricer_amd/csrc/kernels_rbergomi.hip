@@ -12,7 +12,7 @@
 // One wavefront owns 16 paths.  Per 4 values of j it issues one v_mfma_f64_16x16x4_f64 per 16-step
 // tile: A = a 16x4 slice of C read from the LDS-staged, periodically extended weight vector (one
 // ds_read_b64 per lane per MFMA, conflict-free), B = the 4x16 slice of eps that the lanes have just
-// generated from Philox (one normal per lane: no noise is ever stored), D = 16 steps x 16 paths of X
+// generated from Philox (each lane's Philox block feeds four consecutive MFMAs: no noise is ever stored), D = 16 steps x 16 paths of X
 // accumulated in registers (16 tiles = 256 steps per pass; longer grids run in several passes and
 // regenerate eps).  On gfx950 the fp64 MFMA runs at the fp64 VALU rate (64 cycles per instruction,
 // measured in tools/ubench_mfma_f64.hip, and it does not overlap fp64 VALU work), so this kernel
@@ -37,7 +37,7 @@ namespace mcg {
 typedef double v4d __attribute__((ext_vector_type(4)));
 
 constexpr int RB_NT = 8;    // 16-step tiles accumulated per pass (128 steps)
-constexpr int RB_PAD = 24;  // periodic extension of the weight vector in LDS
+constexpr int RB_PAD = 32;  // periodic extension of the weight vector in LDS
 
 struct RbArgs {
     double* out;
@@ -68,24 +68,21 @@ __device__ __forceinline__ void rb_pass(const RbArgs& a, const double* kext, con
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = v4d{0.0, 0.0, 0.0, 0.0};
 
-    const int n_kp = (M + 7) >> 3;
-    for (int kp = 0; kp < n_kp; ++kp) {
-        // this lane's two noise values: j0 = 8kp + 2g, j1 = j0 + 1  (Philox block j0/2)
-        double e0, e1;
-        fm::normal_pair_fast(a.k0, a.k1, id, (uint32_t)(4 * kp + g), STREAM_VOL, tab, e0, e1);
-        const int j0 = 8 * kp + 2 * g;
-        if (j0 >= M) e0 = 0.0;  // only when Mz < 8
-        if (j0 + 1 >= M) e1 = 0.0;
-        const int base = (n_base - 8 * kp) & (M - 1);
+    const int n_kq = (M + 15) >> 4;
+    for (int kq = 0; kq < n_kq; ++kq) {
+        // this lane's four noise values: j = 16kq + 4g + e, e = 0..3 (one Philox block, number 4kq + g)
+        double eps[4];
+        fm::normal_quad_fast(a.k0, a.k1, id, (uint32_t)(4 * kq + g), STREAM_VOL, tab, eps);
+        const int j0 = 16 * kq + 4 * g;
+        const int base = (n_base - 16 * kq) & (M - 1);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const double w = kext[((base + 16 * t) & (M - 1)) + a_off];
-            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(w, e0, acc[t], 0, 0, 0);
-        }
+        for (int e = 0; e < 4; ++e) {
+            const double ev = (j0 + e < M) ? eps[e] : 0.0;  // only matters when Mz < 16
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const double w = kext[((base + 16 * t) & (M - 1)) + a_off - 1];
-            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(w, e1, acc[t], 0, 0, 0);
+            for (int t = 0; t < NT; ++t) {
+                const double w = kext[((base + 16 * t) & (M - 1)) + a_off - e];
+                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(w, ev, acc[t], 0, 0, 0);
+            }
         }
     }
 
@@ -93,9 +90,8 @@ __device__ __forceinline__ void rb_pass(const RbArgs& a, const double* kext, con
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int nl = n_base + 16 * t + 4 * g;
-        double z[4];
-        fm::normal_pair_fast(a.k0, a.k1, id, (uint32_t)(nl >> 1), STREAM_PRICE, tab, z[0], z[1]);
-        fm::normal_pair_fast(a.k0, a.k1, id, (uint32_t)((nl >> 1) + 1), STREAM_PRICE, tab, z[2], z[3]);
+        double z[4];  // steps nl..nl+3 are exactly Philox block nl/4 of the price stream
+        fm::normal_quad_fast(a.k0, a.k1, id, (uint32_t)(nl >> 2), STREAM_PRICE, tab, z);
         double pre[4];
         double run = 0.0;
 #pragma unroll
@@ -131,9 +127,9 @@ __global__ __launch_bounds__(256) void k_rbergomi_paths(RbArgs a) {
     extern __shared__ double smem[];
     __shared__ double2 tab[fm::LOG_TAB_ENTRIES];
     const int M = a.M;
-    double* kext = smem;                 // [M + RB_PAD], kext[i] = kappa[(i - 8) mod M]
+    double* kext = smem;                 // [M + RB_PAD], kext[i] = kappa[(i - 16) mod M]
     double* comp = smem + M + RB_PAD;    // [n_steps]
-    for (int i = threadIdx.x; i < M + RB_PAD; i += 256) kext[i] = a.kappa[(i - 8 + 8 * M) & (M - 1)];
+    for (int i = threadIdx.x; i < M + RB_PAD; i += 256) kext[i] = a.kappa[(i - 16 + 16 * M) & (M - 1)];
     for (int i = threadIdx.x; i < a.n_steps; i += 256) comp[i] = a.comp[i];
     fm::load_log_table(tab, a.log_tab);
     __syncthreads();
@@ -144,7 +140,8 @@ __global__ __launch_bounds__(256) void k_rbergomi_paths(RbArgs a) {
     const bool live = p < a.n_paths;
     const uint64_t id = a.path_begin + (uint64_t)p;
     // A operand: this lane supplies row i = c, i.e. local step 4(c%4) + c/4, for k-slot g
-    const int a_off = 4 * (c & 3) + (c >> 2) - 2 * g + 8;
+    // (noise index j = 16kq + 4g + e): weight index = step - j, shifted by the 16-entry extension
+    const int a_off = 4 * (c & 3) + (c >> 2) - 4 * g + 16;
 
     double* col = a.out + p;
     if (live && g == 0) __builtin_nontemporal_store(a.S0, col);

@@ -122,8 +122,10 @@ int paths_new(mcg_ctx* ctx, int64_t n_paths, int n_steps, uint64_t path_begin, m
     P->ctx = ctx;
     P->n_paths = n_paths;
     P->n_steps = n_steps;
-    P->ld = (n_paths + 63) / 64 * 64;  // rows start 512-B aligned
-    if (P->ld == 0) P->ld = 64;
+    // rows start 2 KiB aligned and are padded to a whole 256-thread block, so generator kernels
+    // store unconditionally (columns >= n_paths are scratch and never read back)
+    P->ld = (n_paths + 255) / 256 * 256;
+    if (P->ld == 0) P->ld = 256;
     P->path_begin = path_begin;
     P->bytes = (size_t)P->ld * (size_t)(n_steps + 1) * sizeof(double);
     void* p = nullptr;

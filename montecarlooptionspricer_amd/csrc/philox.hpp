@@ -1,13 +1,20 @@
 // Counter-based RNG for the path engine: Philox4x32-10 (Salmon et al., SC'11) and the
 // block -> two-normals map shared by every kernel.  Device-only code for gfx950.
 //
-// RNG contract (DESIGN.md "RNG contract"; the oracle's normal_pair mirrors it bit for bit up to
+// RNG contract (DESIGN.md "RNG contract"; the oracle's normal_quad mirrors it bit for bit up to
 // libm-vs-device rounding of log/sincos):
 //   key     = (seed_lo, seed_hi)
 //   counter = (path_lo, path_hi, block, stream)       stream 0: price driver, 1: volatility driver
-//   words   = philox4x32_10(counter, key)
-//   u1 = ((w1:w0 >> 12) + 1/2) * 2^-52,  u2 = ((w3:w2 >> 12) + 1/2) * 2^-52      (both in (0,1))
-//   z0 = sqrt(-2 ln u1) cos(2 pi u2),  z1 = sqrt(-2 ln u1) sin(2 pi u2)
+//   words   = philox4x32_10(counter, key) = (w0, w1, w2, w3)
+//   one block -> FOUR standard normals, two Box-Muller pairs, 64 bits each:
+//     pair A from (w0, w1), pair B from (w2, w3); for a pair (wa, wb):
+//       radius uniform  u = ((wb & 0xFF) * 2^32 + wa + 1/2) * 2^-40      40 bits, in (0,1)
+//       angle fraction  f = ((wb >> 8) + 1/2) * 2^-24                     24 bits, in (0,1)
+//       z_even = sqrt(-2 ln u) cos(2 pi f),  z_odd = sqrt(-2 ln u) sin(2 pi f)
+//   element e of block b is draw number 4b + e of its (path, stream): step n of the price driver uses
+//   block n >> 2, element n & 3.  (40 radius bits reach 7.5 sigma; 2^24 equally spaced angles leave
+//   the marginal law of z exact to far below fp64 resolution -- the angle average is a trapezoid
+//   rule on a smooth periodic integrand.)
 // A path's draws depend only on (seed, global path id): shards of one job reproduce the
 // single-GPU stream exactly.
 #pragma once
@@ -42,12 +49,12 @@ __device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint3
     return Philox4{c0, c1, c2, c3};
 }
 
-// 52 mantissa bits -> (a + 1/2) * 2^-52 in (0,1).  Built by bit-pasting into [1,2): exact.
-__device__ __forceinline__ double u01_from_bits(uint32_t lo, uint32_t hi) {
-    const uint32_t mhi = 0x3FF00000u | (hi >> 12);
-    const uint32_t mlo = (hi << 20) | (lo >> 12);
-    const double d = __hiloint2double((int)mhi, (int)mlo);  // 1 + a*2^-52
-    return (d - 1.0) + 0x1p-53;
+// Radius uniform of a pair: 40 bits a = (wb & 0xFF):wa -> (a + 1/2) * 2^-40 in (0,1).
+// Pasted into the mantissa of a double in [1,2) with the half as the next bit: one exact subtract.
+__device__ __forceinline__ double radius_u01(uint32_t wa, uint32_t wb) {
+    const uint32_t mhi = 0x3FF00000u | ((wb & 0xFFu) << 12) | (wa >> 20);
+    const uint32_t mlo = (wa << 12) | 0x800u;
+    return __hiloint2double((int)mhi, (int)mlo) - 1.0;
 }
 
 }  // namespace mcg

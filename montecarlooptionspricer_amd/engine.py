@@ -201,9 +201,9 @@ class PathEngine:
         return m.value, se.value
 
     def debug_eval(self, fn: int, x: np.ndarray) -> np.ndarray:
-        """Test hook (mcg_debug_eval): one device math routine elementwise; returns [n][2]."""
+        """Test hook (mcg_debug_eval): one device math routine elementwise; returns [n][4]."""
         x = np.ascontiguousarray(x, dtype=np.float64)
-        y = np.empty((len(x), 2), dtype=np.float64)
+        y = np.empty((len(x), 4), dtype=np.float64)
         check(self._L.mcg_debug_eval(self._ctx, int(fn), x.ctypes.data_as(C.POINTER(C.c_double)),
                                      y.ctypes.data_as(C.POINTER(C.c_double)), len(x)))
         return y

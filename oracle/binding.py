@@ -71,7 +71,7 @@ class Oracle:
                                                                   C.c_uint64, _dp]
         L.orc_generate_paths_mt_omp.restype = C.c_int
         L.orc_philox4x32_10.argtypes = [_u32p, _u32p, _u32p]
-        L.orc_normal_pair.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, _dp]
+        L.orc_normal_quad.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, _dp]
         L.orc_paths_gbm.argtypes = [C.c_uint64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int,
                                     C.c_uint64, C.c_long, _dp, C.c_size_t]
         L.orc_paths_gbm.restype = C.c_int
@@ -182,9 +182,9 @@ class Oracle:
         self.L.orc_philox4x32_10(c, k, o)
         return [int(x) for x in o]
 
-    def normal_pair(self, seed, path, block, stream):
-        z = np.empty(2)
-        self.L.orc_normal_pair(seed, path, block, stream, _p(z))
+    def normal_quad(self, seed, path, block, stream):
+        z = np.empty(4)
+        self.L.orc_normal_quad(seed, path, block, stream, _p(z))
         return z
 
     def paths_gbm(self, seed, S0, r, sigma, dt, steps, path_begin, n_paths):

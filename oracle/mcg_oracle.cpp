@@ -199,25 +199,25 @@ void philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]
     std::memcpy(out, c, sizeof(c));
 }
 
-// 52 random mantissa bits -> u = (a + 1/2) * 2^-52 in (0,1), exact in binary64.
-inline double u01_from_bits(uint32_t lo, uint32_t hi) {
-    const uint64_t a = (((uint64_t)hi << 32) | lo) >> 12;
-    return ((double)a + 0.5) * 0x1p-52;
-}
-
-// One Philox block -> two standard normals (Box-Muller, radius from words 0-1, angle from 2-3).
-void normal_pair(uint64_t seed, uint64_t path, uint32_t block, uint32_t stream, double* z0,
-                 double* z1) {
+// One Philox block -> FOUR standard normals: two Box-Muller pairs of 64 bits each.  For a pair
+// (wa, wb): radius uniform u = ((wb & 0xFF)*2^32 + wa + 1/2) * 2^-40, angle fraction
+// f = ((wb >> 8) + 1/2) * 2^-24, z_even = sqrt(-2 ln u) cos(2 pi f), z_odd = ... sin(2 pi f).
+// Pair A = (w0, w1), pair B = (w2, w3).  Element e of block b is draw 4b + e of its (path, stream).
+void normal_quad(uint64_t seed, uint64_t path, uint32_t block, uint32_t stream, double z[4]) {
     const uint32_t ctr[4] = {(uint32_t)path, (uint32_t)(path >> 32), block, stream};
     const uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
     uint32_t x[4];
     philox4x32_10(ctr, key, x);
-    const double u1 = u01_from_bits(x[0], x[1]);
-    const double u2 = u01_from_bits(x[2], x[3]);
-    const double rad = std::sqrt(-2.0 * std::log(u1));
-    const double th = 2.0 * M_PI * u2;
-    *z0 = rad * std::cos(th);
-    *z1 = rad * std::sin(th);
+    for (int h = 0; h < 2; ++h) {
+        const uint32_t wa = x[2 * h], wb = x[2 * h + 1];
+        const uint64_t a40 = ((uint64_t)(wb & 0xFFu) << 32) | wa;
+        const double u = ((double)a40 + 0.5) * 0x1p-40;
+        const double f = ((double)(wb >> 8) + 0.5) * 0x1p-24;
+        const double rad = std::sqrt(-2.0 * std::log(u));
+        const double th = 2.0 * M_PI * f;
+        z[2 * h] = rad * std::cos(th);
+        z[2 * h + 1] = rad * std::sin(th);
+    }
 }
 
 enum : uint32_t { STREAM_PRICE = 0, STREAM_VOL = 1 };
@@ -486,11 +486,12 @@ void orc_philox4x32_10(const uint32_t* ctr4, const uint32_t* key2, uint32_t* out
     philox4x32_10(ctr4, key2, out4);
 }
 
-void orc_normal_pair(uint64_t seed, uint64_t path, uint32_t block, uint32_t stream, double* z2) {
-    normal_pair(seed, path, block, stream, &z2[0], &z2[1]);
+void orc_normal_quad(uint64_t seed, uint64_t path, uint32_t block, uint32_t stream, double* z4) {
+    normal_quad(seed, path, block, stream, z4);
 }
 
-// GBM = the stepping loop of RoughVolatility.cpp:354-364 with v == sigma^2.  One normal per step
+// GBM = the stepping loop of RoughVolatility.cpp:354-364 with v == sigma^2.  One normal per step,
+// step n = element n&3 of Philox block n>>2
 // (the reference's rho-mix of two independent normals is itself N(0,1)).
 // out is step-major: out[j*ld + p], j = 0..steps, p = 0..n_paths-1 (global id path_begin + p).
 int orc_paths_gbm(uint64_t seed, double S0, double r, double sigma, double dt, int steps,
@@ -501,10 +502,10 @@ int orc_paths_gbm(uint64_t seed, double S0, double r, double sigma, double dt, i
     for (long p = 0; p < n_paths; ++p) {
         double S = S0;
         out[p] = S;
-        double z[2] = {0, 0};
+        double z[4] = {0, 0, 0, 0};
         for (int n = 0; n < steps; ++n) {
-            if ((n & 1) == 0) normal_pair(seed, path_begin + p, (uint32_t)(n >> 1), STREAM_PRICE, &z[0], &z[1]);
-            S = S * std::exp(std::fma(vol, z[n & 1], drift));
+            if ((n & 3) == 0) normal_quad(seed, path_begin + p, (uint32_t)(n >> 2), STREAM_PRICE, z);
+            S = S * std::exp(std::fma(vol, z[n & 3], drift));
             out[(size_t)(n + 1) * ld + p] = S;
         }
     }
@@ -547,24 +548,24 @@ int orc_paths_rbergomi(uint64_t seed, double S0, double r, double xi, double H, 
     (void)rho;  // inert in the reference (W1, W2 independent of Z); kept for interface parity
     if (steps < 1 || n_paths < 0) return 1;
     const size_t M = next_pow2((size_t)steps);
-    std::vector<double> kappa(M), comp(steps), eps(M + 1);
+    std::vector<double> kappa(M), comp(steps), eps(M + 4);
     orc_rbergomi_weights(H, eta, dt, steps, kappa.data(), comp.data());
     const double sqdt = std::sqrt(dt);
     for (long p = 0; p < n_paths; ++p) {
         const uint64_t id = path_begin + p;
-        for (size_t j = 0; j < M; j += 2) normal_pair(seed, id, (uint32_t)(j >> 1), STREAM_VOL, &eps[j], &eps[j + 1]);
+        for (size_t j = 0; j < M; j += 4) normal_quad(seed, id, (uint32_t)(j >> 2), STREAM_VOL, &eps[j]);
         double S = S0;
         out[p] = S;
-        double z[2] = {0, 0};
+        double z[4] = {0, 0, 0, 0};
         for (int n = 0; n < steps; ++n) {
             double X = 0.0;
             for (size_t j = 0; j < M; ++j) X = std::fma(kappa[((size_t)n - j) & (M - 1)], eps[j], X);
             if (X_out) X_out[(size_t)p * steps + n] = X;
             const double v = xi * std::exp(X + comp[n]);
-            if ((n & 1) == 0) normal_pair(seed, id, (uint32_t)(n >> 1), STREAM_PRICE, &z[0], &z[1]);
+            if ((n & 3) == 0) normal_quad(seed, id, (uint32_t)(n >> 2), STREAM_PRICE, z);
             const double drift = (r - 0.5 * v) * dt;
             const double sd = std::sqrt(std::max(0.0, v)) * sqdt;
-            S = S * std::exp(std::fma(sd, z[n & 1], drift));
+            S = S * std::exp(std::fma(sd, z[n & 3], drift));
             out[(size_t)(n + 1) * ld + p] = S;
         }
     }

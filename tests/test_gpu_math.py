@@ -64,32 +64,33 @@ def test_sqrt_pos(eng):
 
 def test_sincos_octant(eng):
     rs = np.random.RandomState(3)
-    words = rs.randint(0, 2 ** 63, size=6000, dtype=np.uint64) * 2 + rs.randint(0, 2, size=6000).astype(np.uint64)
-    edge = np.array([0, 2 ** 64 - 1, 1 << 61, (1 << 61) - 1, 3 << 61, (5 << 61) + 4095, 7 << 61, 1 << 12], dtype=np.uint64)
+    words = rs.randint(0, 2 ** 32, size=6000, dtype=np.uint64)
+    edge = np.array([0, 2 ** 32 - 1, 1 << 29, (1 << 29) - 1, 3 << 29, (5 << 29) + 255, 7 << 29, 1 << 8, 255],
+                    dtype=np.uint64)
     words = np.concatenate([words, edge])
-    x = words.view(np.float64)
-    y = eng.debug_eval(3, x)
+    y = eng.debug_eval(3, words.astype(np.float64))
     worst = 0.0
-    for w, (c, s) in zip(words, y):
-        a = int(w) >> 12
-        ang = 2 * mp.pi * (mp.mpf(a) + mp.mpf(1) / 2) / mp.mpf(2) ** 52
+    for w, (c, s, _, _) in zip(words, y):
+        ang = 2 * mp.pi * (mp.mpf(int(w) >> 8) + mp.mpf(1) / 2) / mp.mpf(2) ** 24
         worst = max(worst, ulp_err(c, mp.cos(ang)), ulp_err(s, mp.sin(ang)))
     assert worst <= 2.0, worst
 
 
-def test_normal_pair_fast_matches_contract(eng):
+def test_normal_quad_fast_matches_contract(eng):
     orc = Oracle()
     ids = np.arange(0, 5000, dtype=np.float64)
     fast = eng.debug_eval(4, ids)
     slow = eng.debug_eval(5, ids)
-    want = np.array([orc.normal_pair(1, int(i), 0, 0) for i in ids])
+    want = np.array([orc.normal_quad(1, int(i), 0, 0) for i in ids])
     assert np.max(np.abs(fast - want)) < 1e-14
     assert np.max(np.abs(slow - want)) < 1e-14
     # and in high precision for a few
     for i in range(0, 5000, 500):
         w = orc.philox([i, 0, 0, 0], [1, 0])
-        u1 = (mp.mpf((w[1] << 32 | w[0]) >> 12) + mp.mpf(1) / 2) / mp.mpf(2) ** 52
-        u2 = (mp.mpf((w[3] << 32 | w[2]) >> 12) + mp.mpf(1) / 2) / mp.mpf(2) ** 52
-        r = mp.sqrt(-2 * mp.log(u1))
-        assert abs(mp.mpf(fast[i, 0]) - r * mp.cos(2 * mp.pi * u2)) < mp.mpf("4e-15")
-        assert abs(mp.mpf(fast[i, 1]) - r * mp.sin(2 * mp.pi * u2)) < mp.mpf("4e-15")
+        for h in range(2):
+            wa, wb = w[2 * h], w[2 * h + 1]
+            u = (mp.mpf(((wb & 0xFF) << 32) | wa) + mp.mpf(1) / 2) / mp.mpf(2) ** 40
+            f = (mp.mpf(wb >> 8) + mp.mpf(1) / 2) / mp.mpf(2) ** 24
+            r = mp.sqrt(-2 * mp.log(u))
+            assert abs(mp.mpf(fast[i, 2 * h]) - r * mp.cos(2 * mp.pi * f)) < mp.mpf("4e-15")
+            assert abs(mp.mpf(fast[i, 2 * h + 1]) - r * mp.sin(2 * mp.pi * f)) < mp.mpf("4e-15")
