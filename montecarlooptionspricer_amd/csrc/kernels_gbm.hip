@@ -27,7 +27,9 @@ struct GbmArgs {
     const double2* log_tab;  // fm::LOG_TAB_HOST on the device
 };
 
-template <bool PAYOFF>
+// SMALL: the host has checked |drift| + vol * 7.55 <= 0.125, so every step's exponent fits
+// fm::scaled_exp_small (no range reduction, two fewer polynomial terms).
+template <bool PAYOFF, bool SMALL>
 __global__ __launch_bounds__(256) void k_gbm_paths(GbmArgs a) {
     __shared__ double2 tab[fm::LOG_TAB_ENTRIES];
     fm::load_log_table(tab, a.log_tab);
@@ -56,11 +58,11 @@ __global__ __launch_bounds__(256) void k_gbm_paths(GbmArgs a) {
         }
         double z0, z1;
         fm::box_muller_pair(wa, wb, tab, z0, z1);
-        S = fm::scaled_exp(S, fma(a.vol, z0, a.drift));
+        S = SMALL ? fm::scaled_exp_small(S, fma(a.vol, z0, a.drift)) : fm::scaled_exp(S, fma(a.vol, z0, a.drift));
         col += a.ld;
         __builtin_nontemporal_store(S, col);
         if (2 * pr + 1 < a.n_steps) {  // wave-uniform: false only for the last pair of an odd grid
-            S = fm::scaled_exp(S, fma(a.vol, z1, a.drift));
+            S = SMALL ? fm::scaled_exp_small(S, fma(a.vol, z1, a.drift)) : fm::scaled_exp(S, fma(a.vol, z1, a.drift));
             col += a.ld;
             __builtin_nontemporal_store(S, col);
         }
@@ -156,10 +158,12 @@ int launch_gbm(mcg_ctx* ctx, mcg_paths* P, uint64_t seed, double S0, double r, d
     a.log_tab = (const double2*)ctx->log_tab;
     {
         TimedLaunch t(ctx, MCG_K_GBM);
-        if (want_payoff)
-            hipLaunchKernelGGL(k_gbm_paths<true>, dim3((unsigned)n_blocks), dim3(256), 0, ctx->stream, a);
-        else
-            hipLaunchKernelGGL(k_gbm_paths<false>, dim3((unsigned)n_blocks), dim3(256), 0, ctx->stream, a);
+        const bool small = std::fabs(a.drift) + std::fabs(a.vol) * fm::MAX_ABS_NORMAL <= fm::SMALL_EXP_BOUND;
+        const dim3 grid((unsigned)n_blocks), block(256);
+        if (want_payoff && small) hipLaunchKernelGGL((k_gbm_paths<true, true>), grid, block, 0, ctx->stream, a);
+        else if (want_payoff) hipLaunchKernelGGL((k_gbm_paths<true, false>), grid, block, 0, ctx->stream, a);
+        else if (small) hipLaunchKernelGGL((k_gbm_paths<false, true>), grid, block, 0, ctx->stream, a);
+        else hipLaunchKernelGGL((k_gbm_paths<false, false>), grid, block, 0, ctx->stream, a);
     }
     MCG_HIP(hipGetLastError());
     if (want_payoff) {
