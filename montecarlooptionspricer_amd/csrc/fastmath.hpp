@@ -170,6 +170,17 @@ __device__ __forceinline__ void box_muller_pair(uint32_t wa, uint32_t wb, const 
     z1 = rad * s;
 }
 
+// The same pair, already scaled and shifted: a0 = shift + scale*z0, a1 = shift + scale*z1
+// (the exponent of a price step).  Folding scale into the radius saves one multiply per pair.
+__device__ __forceinline__ void box_muller_pair_affine(uint32_t wa, uint32_t wb, const double2* log_tab, double scale,
+                                                       double shift, double& a0, double& a1) {
+    const double rad = scale * sqrt_pos(neg2log(radius_u01(wa, wb), log_tab));
+    double c, s;
+    sincos_octant(wb, c, s);
+    a0 = __builtin_fma(rad, c, shift);
+    a1 = __builtin_fma(rad, s, shift);
+}
+
 // One Philox block -> four N(0,1) deviates.
 __device__ __forceinline__ void normal_quad_fast(uint32_t k0, uint32_t k1, uint64_t path, uint32_t block,
                                                  uint32_t stream, const double2* log_tab, double (&z)[4]) {

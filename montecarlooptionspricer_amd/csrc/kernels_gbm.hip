@@ -56,13 +56,13 @@ __global__ __launch_bounds__(256) void k_gbm_paths(GbmArgs a) {
             wa = w.w2;
             wb = w.w3;
         }
-        double z0, z1;
-        fm::box_muller_pair(wa, wb, tab, z0, z1);
-        S = SMALL ? fm::scaled_exp_small(S, fma(a.vol, z0, a.drift)) : fm::scaled_exp(S, fma(a.vol, z0, a.drift));
+        double e0, e1;  // exponents drift + vol*z of the pair's two steps
+        fm::box_muller_pair_affine(wa, wb, tab, a.vol, a.drift, e0, e1);
+        S = SMALL ? fm::scaled_exp_small(S, e0) : fm::scaled_exp(S, e0);
         col += a.ld;
         __builtin_nontemporal_store(S, col);
         if (2 * pr + 1 < a.n_steps) {  // wave-uniform: false only for the last pair of an odd grid
-            S = SMALL ? fm::scaled_exp_small(S, fma(a.vol, z1, a.drift)) : fm::scaled_exp(S, fma(a.vol, z1, a.drift));
+            S = SMALL ? fm::scaled_exp_small(S, e1) : fm::scaled_exp(S, e1);
             col += a.ld;
             __builtin_nontemporal_store(S, col);
         }
