@@ -374,3 +374,13 @@ def test_torch_distributed_and_builtin_rccl_world_size_one():
         base.close()
     finally:
         dist.destroy_process_group()
+
+
+def test_gbm_large_steps_take_the_general_exp_path(eng, orc):
+    """sigma*sqrt(dt) large enough that the host cannot bound |drift + vol z| by 0.125: the kernel
+    variant with full range reduction runs, and must match the oracle just the same."""
+    for sigma, dt, steps in [(0.8, 0.05, 40), (3.0, 0.25, 12), (0.2, 0.02, 50)]:
+        P = eng.gbm(SEED, 100.0, 0.04, sigma, dt, steps, 777, path_begin=5)
+        want = orc.paths_gbm(SEED, 100.0, 0.04, sigma, dt, steps, 5, 777)
+        assert rel_err(P.to_host_step_major(), want) < 1e-11
+        P.free()
