@@ -36,7 +36,7 @@ namespace mcg {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
-constexpr int RB_NT = 8;    // 16-step tiles accumulated per pass (128 steps)
+constexpr int RB_NT = 16;   // 16-step tiles accumulated per pass (256 steps)
 constexpr int RB_PAD = 32;  // periodic extension of the weight vector in LDS
 
 struct RbArgs {
@@ -151,7 +151,8 @@ __global__ __launch_bounds__(256) void k_rbergomi_paths(RbArgs a) {
     for (; n_base + RB_NT * 16 <= a.n_steps; n_base += RB_NT * 16)
         rb_pass<RB_NT>(a, kext, comp, tab, n_base, g, c, a_off, id, live, col, logS);
     const int tiles_left = (a.n_steps - n_base + 15) >> 4;  // 0..RB_NT-1, wave-uniform
-    if (tiles_left > 4) rb_pass<8>(a, kext, comp, tab, n_base, g, c, a_off, id, live, col, logS);
+    if (tiles_left > 8) rb_pass<16>(a, kext, comp, tab, n_base, g, c, a_off, id, live, col, logS);
+    else if (tiles_left > 4) rb_pass<8>(a, kext, comp, tab, n_base, g, c, a_off, id, live, col, logS);
     else if (tiles_left > 2) rb_pass<4>(a, kext, comp, tab, n_base, g, c, a_off, id, live, col, logS);
     else if (tiles_left > 0) rb_pass<2>(a, kext, comp, tab, n_base, g, c, a_off, id, live, col, logS);
 
