@@ -46,3 +46,13 @@ clean:
 	$(MAKE) -C oracle clean
 
 .PHONY: all lib oracle clean
+
+# C++ drop-in driver (tests/cpp): compiled against the reference-shaped headers with plain g++,
+# linked to libmcgpu.so; run by tests/test_gpu_cpp_dropin.py on the GPU box.
+build/dropin_driver: tests/cpp/dropin_driver.cpp $(LIB) $(HDRS)
+	@mkdir -p build
+	g++ -O2 -std=c++17 -fopenmp -Iinclude tests/cpp/dropin_driver.cpp -o $@ \
+	    -L$(PKG)/lib -lmcgpu -Wl,-rpath,'$$ORIGIN/../$(PKG)/lib'
+
+cpp: build/dropin_driver
+.PHONY: cpp
