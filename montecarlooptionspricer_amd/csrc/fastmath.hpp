@@ -8,7 +8,7 @@
 //   scaled_exp(S, a)        S * e^a           any finite a (overflow -> inf, underflow -> 0)
 //   neg2log(u, tab)         -2 ln u           u in (0, 1]; 128-entry {1/c, -2 ln c} table in LDS
 //   sqrt_pos(x)             sqrt(x)           x in [1e-300, 1e300], no denormal/negative handling
-//   sincos_octant(wb)       cos/sin(2 pi f)   f = ((wb >> 8) + 1/2) 2^-24, from the raw Philox word
+//   sincos_table(wb, tab)   cos/sin(2 pi f)   f = ((wb >> 8) + 1/2) 2^-24, from the raw Philox word; 512-entry table
 //   normal_quad_fast(...)   the four normals of one Philox block (philox.hpp's contract)
 //
 // Polynomials: interpolation at Chebyshev nodes in 60-digit arithmetic, rounded to binary64
@@ -22,7 +22,15 @@
 namespace mcg {
 namespace fm {
 
-constexpr int LOG_TAB_ENTRIES = 128;  // x 16 B = 2 KiB of LDS per workgroup
+constexpr int LOG_TAB_ENTRIES = 128;     // x 16 B = 2 KiB of LDS per workgroup
+constexpr int SINCOS_TAB_ENTRIES = 512;  // x 16 B = 8 KiB
+
+// The two lookup tables as they sit in LDS (and, back to back, in the device buffer they are
+// staged from: fm::LOG_TAB_HOST followed by fm::SINCOS_TAB_HOST).
+struct Tables {
+    double2 log[LOG_TAB_ENTRIES];        // {1/c_i, -2 ln c_i}
+    double2 sincos[SINCOS_TAB_ENTRIES];  // {cos, sin}(2 pi i / 512)
+};
 
 __device__ __forceinline__ double from_words(uint32_t hi, uint32_t lo) { return __hiloint2double((int)hi, (int)lo); }
 
@@ -124,74 +132,57 @@ __device__ __forceinline__ double sqrt_pos(double x) {
 }
 
 // cos(2 pi f), sin(2 pi f) with f = ((wb >> 8) + 1/2) * 2^-24, straight from the Philox word:
-// 8 f = q + y, q = top 3 bits (octant), y = (rem + 1/2) 2^-21 in (0,1) with rem the low 21 bits; odd
-// octants use 1 - y, which is the bitwise complement of rem.  sin/cos(pi/4 * y) on [0,1] by
-// polynomials in y^2 (max rel err 2^-54 / 2^-55), then the octant symmetries as sign-bit xors and
-// one swap.
-__device__ __forceinline__ void sincos_octant(uint32_t wb, double& c_out, double& s_out) {
-    const uint32_t odd = 0u - ((wb >> 29) & 1u);  // all ones in odd octants
-    const uint32_t rem = ((wb >> 8) ^ odd) & 0x1FFFFFu;
-    const double y = __builtin_fma((double)rem, 0x1p-21, 0x1p-22);
-    const double w = y * y;
-    double ps = 0x1.e4a9d9166f052p-38;
-    ps = fma_sc(ps, w, -0x1.e3027dea82bd7p-30);
-    ps = fma_sc(ps, w, 0x1.50783208843ebp-22);
-    ps = fma_sc(ps, w, -0x1.32d2cce500387p-15);
-    ps = fma_sc(ps, w, 0x1.466bc6775a476p-9);
-    ps = fma_sc(ps, w, -0x1.4abbce625be52p-4);
-    const double sn = y * fma_sc(ps, w, 0x1.921fb54442d18p-1);
-    double pc = -0x1.b2f3eb054afcdp-42;
-    pc = fma_sc(pc, w, 0x1.f9ce245cada0bp-34);
-    pc = fma_sc(pc, w, -0x1.a6d1eef479be1p-26);
-    pc = fma_sc(pc, w, 0x1.e1f5068688d5bp-19);
-    pc = fma_sc(pc, w, -0x1.55d3c7e3cb241p-12);
-    pc = fma_sc(pc, w, 0x1.03c1f081b5ac0p-6);
-    pc = fma_sc(pc, w, -0x1.3bd3cc9be45dep-2);
-    const double cs = __builtin_fma(pc, w, 1.0);
-    // octant q = wb >> 29: swap for q in {1,2,5,6} (bit0 ^ bit1), cos < 0 for q in {2,3,4,5}
-    // (bit1 ^ bit2), sin < 0 for q >= 4 (bit2)
-    const bool swap = (((wb >> 29) ^ (wb >> 30)) & 1u) != 0u;
-    const double cc = swap ? sn : cs;
-    const double ss = swap ? cs : sn;
-    const uint32_t sign_c = (wb ^ (wb << 1)) & 0x80000000u;
-    const uint32_t sign_s = wb & 0x80000000u;
-    c_out = from_words((uint32_t)__double2hiint(cc) ^ sign_c, (uint32_t)__double2loint(cc));
-    s_out = from_words((uint32_t)__double2hiint(ss) ^ sign_s, (uint32_t)__double2loint(ss));
+// 2 pi f = 2 pi i/512 + delta with i the top 9 angle bits and delta = 2 pi (low15 + 1/2) 2^-24 in
+// (0, 0.01228).  (cos, sin)(2 pi i/512) come from a 512-entry LDS table (correctly rounded),
+// sin/cos(delta) from 3-term series (truncation 8e-18 / 1e-20), combined by the angle-addition
+// formulas: 13 fp64 instructions and no octant logic.
+__device__ __forceinline__ void sincos_table(uint32_t wb, const double2* sc_tab, double& c_out, double& s_out) {
+    const double2 e = sc_tab[wb >> 23];
+    const double delta = __builtin_fma((double)((wb >> 8) & 0x7FFFu), 0x1.921fb54442d18p-22, 0x1.921fb54442d18p-23);
+    const double d2 = delta * delta;
+    const double ts = __builtin_fma(d2, 0x1.1111111111111p-7, -0x1.5555555555555p-3);  // 1/120, -1/6
+    const double sd = __builtin_fma(delta * d2, ts, delta);
+    double tc = __builtin_fma(d2, -0x1.6c16c16c16c17p-10, 0x1.5555555555555p-5);        // -1/720, 1/24
+    tc = __builtin_fma(tc, d2, -0.5);
+    const double cd = __builtin_fma(tc, d2, 1.0);
+    c_out = __builtin_fma(e.x, cd, -(e.y * sd));
+    s_out = __builtin_fma(e.y, cd, e.x * sd);
 }
 
 // One Box-Muller pair from 64 Philox bits (philox.hpp contract).
-__device__ __forceinline__ void box_muller_pair(uint32_t wa, uint32_t wb, const double2* log_tab, double& z0,
+__device__ __forceinline__ void box_muller_pair(uint32_t wa, uint32_t wb, const Tables* tab, double& z0,
                                                 double& z1) {
-    const double rad = sqrt_pos(neg2log(radius_u01(wa, wb), log_tab));
+    const double rad = sqrt_pos(neg2log(radius_u01(wa, wb), tab->log));
     double c, s;
-    sincos_octant(wb, c, s);
+    sincos_table(wb, tab->sincos, c, s);
     z0 = rad * c;
     z1 = rad * s;
 }
 
 // The same pair, already scaled and shifted: a0 = shift + scale*z0, a1 = shift + scale*z1
 // (the exponent of a price step).  Folding scale into the radius saves one multiply per pair.
-__device__ __forceinline__ void box_muller_pair_affine(uint32_t wa, uint32_t wb, const double2* log_tab, double scale,
+__device__ __forceinline__ void box_muller_pair_affine(uint32_t wa, uint32_t wb, const Tables* tab, double scale,
                                                        double shift, double& a0, double& a1) {
-    const double rad = scale * sqrt_pos(neg2log(radius_u01(wa, wb), log_tab));
+    const double rad = scale * sqrt_pos(neg2log(radius_u01(wa, wb), tab->log));
     double c, s;
-    sincos_octant(wb, c, s);
+    sincos_table(wb, tab->sincos, c, s);
     a0 = __builtin_fma(rad, c, shift);
     a1 = __builtin_fma(rad, s, shift);
 }
 
 // One Philox block -> four N(0,1) deviates.
 __device__ __forceinline__ void normal_quad_fast(uint32_t k0, uint32_t k1, uint64_t path, uint32_t block,
-                                                 uint32_t stream, const double2* log_tab, double (&z)[4]) {
+                                                 uint32_t stream, const Tables* tab, double (&z)[4]) {
     const Philox4 w = philox4x32_10((uint32_t)path, (uint32_t)(path >> 32), block, stream, k0, k1);
-    box_muller_pair(w.w0, w.w1, log_tab, z[0], z[1]);
-    box_muller_pair(w.w2, w.w3, log_tab, z[2], z[3]);
+    box_muller_pair(w.w0, w.w1, tab, z[0], z[1]);
+    box_muller_pair(w.w2, w.w3, tab, z[2], z[3]);
 }
 
-// Cooperative copy of the log table (global, 2 KiB) into LDS; call before the first normal_quad_fast
-// and follow with __syncthreads().
-__device__ __forceinline__ void load_log_table(double2* lds_tab, const double2* __restrict__ gtab) {
-    for (int i = threadIdx.x; i < LOG_TAB_ENTRIES; i += blockDim.x) lds_tab[i] = gtab[i];
+// Cooperative copy of both tables (global, 10 KiB) into LDS; call before the first normal and
+// follow with __syncthreads().
+__device__ __forceinline__ void load_tables(Tables* lds, const double2* __restrict__ gtab) {
+    double2* dst = reinterpret_cast<double2*>(lds);
+    for (int i = threadIdx.x; i < LOG_TAB_ENTRIES + SINCOS_TAB_ENTRIES; i += blockDim.x) dst[i] = gtab[i];
 }
 
 }  // namespace fm

@@ -8,8 +8,9 @@ namespace mcg {
 
 __global__ __launch_bounds__(256) void k_debug_eval(int fn, const double* x, double* y, int64_t n,
                                                     const double2* gtab) {
-    __shared__ double2 tab[fm::LOG_TAB_ENTRIES];
-    fm::load_log_table(tab, gtab);
+    __shared__ fm::Tables tabs;
+    const fm::Tables* tab = &tabs;
+    fm::load_tables(&tabs, gtab);
     __syncthreads();
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -18,9 +19,9 @@ __global__ __launch_bounds__(256) void k_debug_eval(int fn, const double* x, dou
     double z[4] = {0.0, 0.0, 0.0, 0.0};
     switch (fn) {
         case 0: a = fm::scaled_exp(1.0, v); break;
-        case 1: a = fm::neg2log(v, tab); break;
+        case 1: a = fm::neg2log(v, tab->log); break;
         case 2: a = fm::sqrt_pos(v); break;
-        case 3: fm::sincos_octant((uint32_t)v, a, b); break;
+        case 3: fm::sincos_table((uint32_t)v, tab->sincos, a, b); break;
         case 4: fm::normal_quad_fast(1u, 0u, (uint64_t)v, 0u, STREAM_PRICE, tab, z); break;
         default: normal_quad_ref(1u, 0u, (uint64_t)v, 0u, STREAM_PRICE, z); break;
     }

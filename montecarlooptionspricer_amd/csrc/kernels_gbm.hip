@@ -31,8 +31,9 @@ struct GbmArgs {
 // fm::scaled_exp_small (no range reduction, two fewer polynomial terms).
 template <bool PAYOFF, bool SMALL>
 __global__ __launch_bounds__(256) void k_gbm_paths(GbmArgs a) {
-    __shared__ double2 tab[fm::LOG_TAB_ENTRIES];
-    fm::load_log_table(tab, a.log_tab);
+    __shared__ fm::Tables tabs;
+    const fm::Tables* tab = &tabs;
+    fm::load_tables(&tabs, a.log_tab);
     __syncthreads();
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const bool live = i < a.n_paths;

@@ -60,7 +60,7 @@ struct RbArgs {
 // advance the price through those steps.  Tiles (or single steps) beyond n_steps are computed but
 // neither stored nor added to the running log-price.
 template <int NT>
-__device__ __forceinline__ void rb_pass(const RbArgs& a, const double* kext, const double* comp, const double2* tab,
+__device__ __forceinline__ void rb_pass(const RbArgs& a, const double* kext, const double* comp, const fm::Tables* tab,
                                         int n_base, int g, int c, int a_off, uint64_t id, bool live, double* col,
                                         double& logS) {
     const int M = a.M;
@@ -125,13 +125,14 @@ __device__ __forceinline__ void rb_pass(const RbArgs& a, const double* kext, con
 template <bool PAYOFF>
 __global__ __launch_bounds__(256) void k_rbergomi_paths(RbArgs a) {
     extern __shared__ double smem[];
-    __shared__ double2 tab[fm::LOG_TAB_ENTRIES];
+    __shared__ fm::Tables tabs;
+    const fm::Tables* tab = &tabs;
     const int M = a.M;
     double* kext = smem;                 // [M + RB_PAD], kext[i] = kappa[(i - 16) mod M]
     double* comp = smem + M + RB_PAD;    // [n_steps]
     for (int i = threadIdx.x; i < M + RB_PAD; i += 256) kext[i] = a.kappa[(i - 16 + 16 * M) & (M - 1)];
     for (int i = threadIdx.x; i < a.n_steps; i += 256) comp[i] = a.comp[i];
-    fm::load_log_table(tab, a.log_tab);
+    fm::load_tables(&tabs, a.log_tab);
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

@@ -55,7 +55,7 @@ struct mcg_ctx {
     double* lsm_v = nullptr;     // LSM value vector
     size_t lsm_v_cap = 0;
     double* scratch = nullptr;   // rBergomi per-lane noise scratch
-    double* log_tab = nullptr;   // device copy of fm::LOG_TAB_HOST (2 KiB), staged to LDS by the kernels
+    double* log_tab = nullptr;   // device copy of fm::LOG_TAB_HOST + fm::SINCOS_TAB_HOST (10 KiB), staged to LDS
     size_t scratch_cap = 0;
 
     // collective

@@ -123,5 +123,21 @@ def log_table(path):
         f.write("};\n} }\n")
 
 
+def sincos_table(path):
+    """512 directions (cos, sin)(2 pi i / 512) for fastmath.hpp::sincos_table."""
+    with open(path, "a") as f:
+        f.write("\n// {cos, sin}(2 pi i / 512), i = 0..511 (correctly rounded)\n")
+        f.write("namespace mcg { namespace fm {\nstatic const double SINCOS_TAB_HOST[1024] = {\n")
+        for i in range(512):
+            th = 2 * mp.pi * i / 512
+            f.write(f"    {float(mp.cos(th)).hex()}, {float(mp.sin(th)).hex()},\n")
+        f.write("};\n} }\n")
+    d = 2 * mp.pi / 512
+    print("sincos table: delta max", mp.nstr(d, 8), " sin trunc err", mp.nstr(d ** 7 / 5040, 3), " cos trunc err", mp.nstr(d ** 8 / 40320, 3))
+    print("  2pi*2^-24 =", float(2 * mp.pi / 2 ** 24).hex(), " pi*2^-24 =", float(mp.pi / 2 ** 24).hex())
+
+
 import os
-log_table(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "montecarlooptionspricer_amd", "csrc", "fastmath_tables.hpp"))
+_tab = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "montecarlooptionspricer_amd", "csrc", "fastmath_tables.hpp")
+log_table(_tab)
+sincos_table(_tab)
