@@ -80,6 +80,8 @@ def main() -> None:
     ap.add_argument("--time-steps", type=int, default=252)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--collective", default=os.environ.get("MCG_COLLECTIVE", "torch"), choices=["torch", "rccl"])
+    ap.add_argument("--backend", default=os.environ.get("MCG_DIST_BACKEND", "nccl"), choices=["nccl", "gloo"],
+                    help="torch.distributed backend; gloo lets several ranks share one GPU (rehearsal only)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -95,14 +97,15 @@ def main() -> None:
     from montecarlooptionspricer_amd.sharding import shard_range
 
     dist = None
+    device = local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(device)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(local_rank)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
 
     S0, K, r, sigma, dt = 100.0, 100.0, 0.04, 0.2, 1.0 / 252.0
     n_steps, seed = args.time_steps, 20251031
@@ -111,7 +114,7 @@ def main() -> None:
     begin, count = shard_range(total_paths, rank, world)
 
     stream = torch.cuda.current_stream().cuda_stream if world > 1 else None
-    eng = mc.PathEngine(local_rank, stream=stream)
+    eng = mc.PathEngine(device, stream=stream)
     if world > 1:
         if args.collective == "rccl":
             def bcast(uid):
