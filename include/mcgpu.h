@@ -50,7 +50,8 @@ enum mcg_kernel {
     MCG_K_LSM_SWEEP = 3,  /* LSM per-date update+moments kernels            */
     MCG_K_LSM_SOLVE = 4,  /* LSM per-date reduce+solve kernels              */
     MCG_K_TRANSPOSE = 5,  /* layout change for the host class API           */
-    MCG_K_COUNT = 6
+    MCG_K_ASYM = 6,       /* AsymptoticAnalysis boundary scan               */
+    MCG_K_COUNT = 7
 };
 
 const char* mcg_last_error(void);
@@ -126,6 +127,13 @@ int mcg_price_european(mcg_ctx* ctx, const mcg_paths* paths, double K, double r,
 int mcg_price_lsm(mcg_ctx* ctx, const mcg_paths* paths, double r, double K, double maturity,
                   double dt, int is_call, int poly_order, double* mean, double* std_err);
 
+/* AsymptoticAnalysis::PredictOptionPrice (src/models/AsymptoticAnalysisPricer.cpp:38-113) on a
+ * device-resident matrix: mean over paths of the best discounted payoff among the dates (t <= maturity)
+ * at which S lies beyond the short-time exercise boundary.  sigma <= 0 is MCG_ERR_INVALID with the
+ * reference's message "AsymptoticAnalysis: Volatility must be positive."   */
+int mcg_price_asymptotic(mcg_ctx* ctx, const mcg_paths* paths, double r, double K, double maturity,
+                         double dt, int is_call, double sigma, double dividend, double* price);
+
 /* ---- host-side pieces of the class-level API (a2/a3 of SURVEY.md section 8) --------------- */
 /* RoughVolatility.cpp:324-331: out5 = {xi, H, eta, rho, S0}. */
 int mcg_estimate_params(const double* hist, size_t n, double out5[5]);
@@ -144,6 +152,11 @@ int mcg_compat_generate_paths(const double* hist, size_t n, int forward_steps, i
 int mcg_compat_lsm_price(const double* row_major, int64_t n_paths, int n_cols, double r,
                          double strike, double maturity, double dt, int is_call, int poly_order,
                          double* price);
+/* AsymptoticAnalysis::PredictOptionPrice(pricePaths, r, strike, maturity, dt, isCall, sigma, dividend);
+ * like the reference, empty or ragged input prices to 0.0 (status MCG_OK). */
+int mcg_compat_asymptotic_price(const double* row_major, int64_t n_paths, int n_cols, double r,
+                                double strike, double maturity, double dt, int is_call, double sigma,
+                                double dividend, double* price);
 
 /* ---- measurement ------------------------------------------------------------------------ */
 /* When enabled, every kernel launch is bracketed by HIP events on the ctx stream. */

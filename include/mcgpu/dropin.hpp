@@ -7,6 +7,7 @@
 //   class RoughVolatility  <->  reference include/models/RoughVolatility.h:9-19
 //   class LSM              <->  reference include/models/LSMPricer.h:5-15
 //   PayoffFunction         <->  reference include/core/common.h:8-14
+//   class AsymptoticAnalysis <-> reference include/models/AsymptoticAnalysisPricer.h:5-16
 //
 // Error behaviour mirrors the reference: std::runtime_error("Historical prices vector too small.")
 // (RoughVolatility.cpp:317-319) and std::runtime_error("LSM::PredictOptionPrice: Empty pricePaths.")
@@ -43,6 +44,15 @@ public:
     // Longstaff-Schwartz (value-iteration variant of the reference) on host-provided paths.
     double PredictOptionPrice(const std::vector<std::vector<double>>& pricePaths, double r, double strike,
                               double maturity, double dt, bool isCall, int polyOrder);
+};
+
+class AsymptoticAnalysis {
+public:
+    // Short-time asymptotic exercise boundary pricer (reference include/models/AsymptoticAnalysisPricer.h:5-16).
+    // Returns 0.0 for empty or ragged input like the reference; throws
+    // std::runtime_error("AsymptoticAnalysis: Volatility must be positive.") when sigma <= 0.
+    double PredictOptionPrice(const std::vector<std::vector<double>>& pricePaths, double r, double strike,
+                              double maturity, double dt, bool isCall, double sigma, double dividend);
 };
 
 #endif  // MCGPU_DROPIN_HPP

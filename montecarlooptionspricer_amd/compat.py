@@ -56,3 +56,18 @@ class LSM:
         check(L.mcg_compat_lsm_price(a.ctypes.data_as(_dp), a.shape[0], a.shape[1], r, strike, maturity, dt,
                                      int(bool(isCall)), int(polyOrder), C.byref(price)))
         return price.value
+
+
+class AsymptoticAnalysis:
+    """<-> /root/reference/include/models/AsymptoticAnalysisPricer.h:5-16."""
+
+    def PredictOptionPrice(self, pricePaths, r: float, strike: float, maturity: float, dt: float, isCall: bool,
+                           sigma: float, dividend: float) -> float:
+        L = N.load_library()
+        a = np.ascontiguousarray(pricePaths, dtype=np.float64)
+        if a.ndim != 2:
+            a = a.reshape(0, 0)
+        price = C.c_double()
+        check(L.mcg_compat_asymptotic_price(a.ctypes.data_as(_dp), a.shape[0], a.shape[1], r, strike, maturity, dt,
+                                            int(bool(isCall)), sigma, dividend, C.byref(price)))
+        return price.value

@@ -510,6 +510,17 @@ int mcg_price_lsm(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double m
     return run_lsm(ctx, P, r, K, maturity, dt, is_call, poly_order, mean, std_err);
 }
 
+int mcg_price_asymptotic(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double maturity, double dt, int is_call,
+                         double sigma, double dividend, double* price) {
+    if (!ctx || !P || !price) return fail(MCG_ERR_INVALID, "ctx/paths/price is NULL");
+    if (P->ctx != ctx) return fail(MCG_ERR_INVALID, "paths belong to a different ctx");
+    *price = 0.0;
+    if (P->n_paths < 1 && !ctx->allreduce) return MCG_OK;  // AsymptoticAnalysisPricer.cpp:47-49
+    if (sigma <= 0.0) return fail(MCG_ERR_INVALID, "AsymptoticAnalysis: Volatility must be positive.");  // :50-52
+    MCG_HIP(hipSetDevice(ctx->device));
+    return run_asymptotic(ctx, P, r, K, maturity, dt, is_call, sigma, dividend, price);
+}
+
 // ---- host-only pieces --------------------------------------------------------------------------
 int mcg_estimate_params(const double* hist, size_t n, double out5[5]) {
     if (!out5) return fail(MCG_ERR_INVALID, "out5 is NULL");

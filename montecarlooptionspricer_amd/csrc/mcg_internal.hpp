@@ -122,7 +122,12 @@ int finish_sums(mcg_ctx* ctx, int64_t n_blocks, int64_t n_local, double out3[3])
 int run_lsm(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double maturity, double dt, int is_call,
             int poly_order, double* mean, double* std_err);
 
-// host-side math (host/volterra.cpp, host/estimators.cpp)
+int run_asymptotic(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double maturity, double dt, int is_call,
+                   double sigma, double dividend, double* price);
+
+// host-side math (host/volterra.cpp, host/estimators.cpp, host/asymptotic.cpp)
+void host_asymptotic_tables(int n_cols, double r, double K, double maturity, double dt, int is_call, double sigma,
+                            double dividend, std::vector<double>& bnd, std::vector<double>& disc);
 int host_estimate_params(const double* hist, size_t n, double out5[5]);
 int host_rbergomi_weights(double H, double eta, double dt, int n_steps, std::vector<double>& kappa,
                           std::vector<double>& comp);

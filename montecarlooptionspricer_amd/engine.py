@@ -200,6 +200,14 @@ class PathEngine:
                                     C.byref(m), C.byref(se)))
         return m.value, se.value
 
+    def price_asymptotic(self, paths: PathMatrix, r: float, K: float, maturity: float, dt: float, is_call: bool,
+                         sigma: float, dividend: float) -> float:
+        paths._alive()
+        p = C.c_double()
+        check(self._L.mcg_price_asymptotic(self._ctx, paths._h, r, K, maturity, dt, int(bool(is_call)), sigma, dividend,
+                                           C.byref(p)))
+        return p.value
+
     def debug_eval(self, fn: int, x: np.ndarray) -> np.ndarray:
         """Test hook (mcg_debug_eval): one device math routine elementwise; returns [n][4]."""
         x = np.ascontiguousarray(x, dtype=np.float64)

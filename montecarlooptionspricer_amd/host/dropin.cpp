@@ -3,6 +3,7 @@
 //
 //   RoughVolatility::GenerateStockPricePaths  <->  /root/reference/src/models/RoughVolatility.cpp:312-368
 //   LSM::PredictOptionPrice                   <->  /root/reference/src/models/LSMPricer.cpp:19-102
+//   AsymptoticAnalysis::PredictOptionPrice    <->  /root/reference/src/models/AsymptoticAnalysisPricer.cpp:38-113
 #include <atomic>
 #include <cmath>
 #include <cstdlib>
@@ -111,7 +112,48 @@ double LSM::PredictOptionPrice(const std::vector<std::vector<double>>& pricePath
     return price;
 }
 
+double AsymptoticAnalysis::PredictOptionPrice(const std::vector<std::vector<double>>& pricePaths, double r,
+                                              double strike, double maturity, double dt, bool isCall, double sigma,
+                                              double dividend) {
+    if (pricePaths.empty() || pricePaths[0].empty()) return 0.0;                     // :47-49
+    if (sigma <= 0.0) throw std::runtime_error("AsymptoticAnalysis: Volatility must be positive.");  // :50-52
+    const size_t N = pricePaths.size(), M = pricePaths[0].size();
+    for (const auto& row : pricePaths)
+        if (row.size() != M) return 0.0;                                               // :57-61
+    try {
+        std::vector<double> flat(N * M);
+        for (size_t i = 0; i < N; ++i) std::copy(pricePaths[i].begin(), pricePaths[i].end(), flat.begin() + i * M);
+        mcg_ctx* ctx = t_ctx.get();
+        PathsGuard g;
+        if (mcg_paths_from_host(ctx, flat.data(), (int64_t)N, (int)M, &g.p) != MCG_OK) raise_last();
+        double price = 0.0;
+        if (mcg_price_asymptotic(ctx, g.p, r, strike, maturity, dt, isCall ? 1 : 0, sigma, dividend, &price) != MCG_OK)
+            raise_last();
+        return price;
+    } catch (const std::bad_alloc&) {
+        return 0.0;  // the reference swallows every exception of its main loop and returns 0 (:110-112)
+    }
+}
+
 extern "C" {
+
+int mcg_compat_asymptotic_price(const double* row_major, int64_t n_paths, int n_cols, double r, double strike,
+                                double maturity, double dt, int is_call, double sigma, double dividend,
+                                double* price) {
+    try {
+        std::vector<std::vector<double>> m;
+        if (row_major && n_paths > 0 && n_cols > 0) {
+            m.resize((size_t)n_paths);
+            for (int64_t i = 0; i < n_paths; ++i) m[i].assign(row_major + i * n_cols, row_major + (i + 1) * n_cols);
+        }
+        AsymptoticAnalysis aa;
+        const double v = aa.PredictOptionPrice(m, r, strike, maturity, dt, is_call != 0, sigma, dividend);
+        if (price) *price = v;
+        return MCG_OK;
+    } catch (const std::exception& e) {
+        return mcg::fail(MCG_ERR_INVALID, "%s", e.what());
+    }
+}
 
 int mcg_compat_set_seed(uint64_t seed, int enabled) {
     g_seed.store(seed);

@@ -86,6 +86,9 @@ class Oracle:
         L.orc_lsm_price.argtypes = [_dp, C.c_size_t, C.c_size_t, C.c_long, C.c_int, C.c_double, C.c_double,
                                     C.c_double, C.c_double, C.c_int, C.c_int, _dp, _dp]
         L.orc_lsm_price.restype = C.c_int
+        L.orc_asymptotic_price.argtypes = [_dp, C.c_size_t, C.c_size_t, C.c_long, C.c_int] + [C.c_double] * 4 + \
+            [C.c_int, C.c_double, C.c_double, _dp]
+        L.orc_asymptotic_price.restype = C.c_int
         L.orc_num_threads.restype = C.c_int
 
     # -- estimators / spectral ------------------------------------------------------------------
@@ -247,6 +250,23 @@ class Oracle:
             raise RuntimeError("orc_lsm_price failed rc=%d" % rc)
         return (price.value, v0) if want_v0 else price.value
 
+    def asymptotic_price(self, paths, r, K, maturity, dt, is_call, sigma, dividend, step_major=True):
+        a = np.ascontiguousarray(paths, dtype=np.float64)
+        if a.ndim != 2 or a.size == 0:
+            return 0.0
+        if step_major:
+            n_cols, n_paths = a.shape
+            ps, ss = 1, n_paths
+        else:
+            n_paths, n_cols = a.shape
+            ps, ss = n_cols, 1
+        price = C.c_double()
+        rc = self.L.orc_asymptotic_price(_p(a), ps, ss, n_paths, n_cols, r, K, maturity, dt, int(bool(is_call)),
+                                         sigma, dividend, C.byref(price))
+        if rc:
+            raise RuntimeError("AsymptoticAnalysis: Volatility must be positive.")
+        return price.value
+
     def num_threads(self):
         return int(self.L.orc_num_threads())
 
@@ -275,6 +295,10 @@ class Reference:
         L.ref_generate_paths.restype = C.c_int
         L.ref_generate_paths_omp.argtypes = [_dp, C.c_size_t, C.c_int, C.c_long, C.c_int, _dp]
         L.ref_generate_paths_omp.restype = C.c_int
+        if hasattr(L, "ref_asymptotic_price"):
+            L.ref_asymptotic_price.argtypes = [_dp, C.c_long, C.c_int] + [C.c_double] * 4 + [C.c_int, C.c_double, C.c_double,
+                                                                                    _dp, C.c_char_p, C.c_size_t]
+            L.ref_asymptotic_price.restype = C.c_int
 
     def estimators(self, hist):
         h = np.ascontiguousarray(hist, dtype=np.float64)
@@ -332,6 +356,17 @@ class Reference:
         if rc:
             raise RuntimeError(err.value.decode())
         return out
+
+    def asymptotic_price(self, row_major, r, K, maturity, dt, is_call, sigma, dividend):
+        a = np.ascontiguousarray(row_major, dtype=np.float64)
+        n, m = (a.shape if a.ndim == 2 else (0, 0))
+        price = C.c_double()
+        err = C.create_string_buffer(256)
+        rc = self.L.ref_asymptotic_price(_p(a) if a.size else None, n, m, r, K, maturity, dt, int(bool(is_call)), sigma,
+                                         dividend, C.byref(price), err, 256)
+        if rc:
+            raise RuntimeError(err.value.decode())
+        return price.value
 
     def generate_paths_omp(self, hist, steps, total_paths, chunk):
         h = np.ascontiguousarray(hist, dtype=np.float64)

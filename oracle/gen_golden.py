@@ -86,6 +86,26 @@ def main() -> None:
            "call": np.array([ref.payoff(True, a, b) for a, b in zip(s, k)]),
            "put": np.array([ref.payoff(False, a, b) for a, b in zip(s, k)])}
     np.savez(os.path.join(OUT, "payoff.npz"), **pay)
+    # (7) AsymptoticAnalysis::PredictOptionPrice (src/models/AsymptoticAnalysisPricer.cpp:38-113):
+    # deterministic given the path matrix.  Inputs are stored with the outputs.
+    rs = np.random.RandomState(11)
+    base = 100.0 * np.exp(np.cumsum(0.02 * rs.standard_normal((300, 41)), axis=1))
+    base[:, 0] = 100.0
+    dirty = base.copy()
+    dirty[5, 7] = np.nan
+    dirty[9, 30] = np.inf
+    asy = {"paths": base, "paths_dirty": dirty}
+    cases = []
+    for which, is_call, maturity, dt, sigma, div, K in [
+            (0, 0, 40 / 252.0, 1 / 252.0, 0.2, 0.08, 100.0), (0, 1, 40 / 252.0, 1 / 252.0, 0.2, 0.08, 100.0),
+            (0, 0, 15 / 252.0, 1 / 252.0, 0.35, 0.0, 105.0), (0, 1, 0.5, 0.02, 0.15, 0.03, 95.0),
+            (1, 0, 40 / 252.0, 1 / 252.0, 0.2, 0.08, 100.0), (1, 1, 2.0, 0.05, 0.5, 0.01, 90.0),
+            (0, 0, 1e-12, 1 / 252.0, 0.2, 0.08, 100.0)]:
+        m = dirty if which else base
+        cases.append([which, is_call, maturity, dt, sigma, div, K, 0.04,
+                      ref.asymptotic_price(m, 0.04, K, maturity, dt, bool(is_call), sigma, div)])
+    asy["cases"] = np.array(cases)
+    np.savez(os.path.join(OUT, "asymptotic.npz"), **asy)
     print("golden fixtures written to", OUT)
     for f in sorted(os.listdir(OUT)):
         print("  ", f, os.path.getsize(os.path.join(OUT, f)), "bytes")

@@ -662,6 +662,58 @@ int orc_lsm_price(const double* paths, size_t path_stride, size_t step_stride, l
     return 0;
 }
 
+// src/models/AsymptoticAnalysisPricer.cpp:8-36 -- short-time exercise boundary K +/- 0.5 sigma sqrt(eps ln(1/eps)),
+// eps = T - t, with the carry correction for eps < 0.01; K itself when eps < 1e-10.
+static double asym_boundary(bool call, double t, double T, double K, double r, double D, double sigma) {
+    const double eps = T - t;
+    if (eps < 1e-10) return K;
+    const double c0 = 0.5 * sigma * std::sqrt(eps * std::log(1.0 / eps));
+    double b = call ? K - c0 : K + c0;
+    if (eps < 0.01) {
+        if (call) b += 0.5 * (D - r) * eps;
+        else b -= 0.5 * (r - D) * eps;
+    }
+    return b;
+}
+
+// AsymptoticAnalysis::PredictOptionPrice (src/models/AsymptoticAnalysisPricer.cpp:38-113): per path the
+// best discounted payoff over the dates (t <= maturity) at which S is beyond the boundary; mean over
+// paths.  Returns 0 (price may be 0.0 for empty input, :47-49) or 1 when sigma <= 0 (the reference
+// throws "AsymptoticAnalysis: Volatility must be positive.", :50-52).
+int orc_asymptotic_price(const double* paths, size_t path_stride, size_t step_stride, long n_paths, int n_cols,
+                         double r, double K, double maturity, double dt, int is_call, double sigma, double dividend,
+                         double* price) {
+    *price = 0.0;
+    if (n_paths < 1 || n_cols < 1) return 0;
+    if (sigma <= 0.0) return 1;
+    const bool call = is_call != 0;
+    double sum = 0.0;
+    long valid = 0;
+    for (long i = 0; i < n_paths; ++i) {
+        double best = 0.0;
+        for (int j = 0; j < n_cols; ++j) {
+            const double t = j * dt;
+            if (t > maturity) break;
+            const double S = paths[(size_t)i * path_stride + (size_t)j * step_stride];
+            if (std::isnan(S) || std::isinf(S)) continue;
+            const double b = asym_boundary(call, t, maturity, K, r, dividend, sigma);
+            const bool in = call ? (S > b) : (S < b);
+            if (in) {
+                const double pay = payoff_of(call, S, K);
+                if (std::isnan(pay) || std::isinf(pay)) continue;
+                const double d = std::exp(-r * t) * pay;
+                if (d > best) best = d;
+            }
+        }
+        if (!std::isnan(best) && !std::isinf(best)) {
+            sum += best;
+            ++valid;
+        }
+    }
+    *price = valid > 0 ? sum / valid : 0.0;
+    return 0;
+}
+
 int orc_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

@@ -25,6 +25,7 @@
 #include "models/RoughVolatility.h"
 #undef private
 #include "core/common.h"
+#include "models/AsymptoticAnalysisPricer.h"
 
 namespace {
 using cvec = std::vector<std::complex<double>>;
@@ -151,6 +152,26 @@ int ref_generate_paths_omp(const double* hist, size_t n, int steps, long total_p
     }
     *sum_ST = acc;
     return threads;
+}
+
+// AsymptoticAnalysis::PredictOptionPrice (src/models/AsymptoticAnalysisPricer.cpp:38-113) on a
+// row-major [n][m] matrix.  Returns 0, or 1 when the reference throws (message in err).
+int ref_asymptotic_price(const double* row_major, long n, int m, double r, double strike, double maturity,
+                         double dt, int is_call, double sigma, double dividend, double* price, char* err,
+                         size_t errlen) {
+    try {
+        std::vector<std::vector<double>> paths((size_t)std::max<long>(n, 0));
+        for (long i = 0; i < n; ++i) paths[i].assign(row_major + (size_t)i * m, row_major + (size_t)(i + 1) * m);
+        AsymptoticAnalysis aa;
+        *price = aa.PredictOptionPrice(paths, r, strike, maturity, dt, is_call != 0, sigma, dividend);
+        return 0;
+    } catch (const std::exception& e) {
+        if (err && errlen) {
+            std::strncpy(err, e.what(), errlen - 1);
+            err[errlen - 1] = 0;
+        }
+        return 1;
+    }
 }
 
 }  // extern "C"

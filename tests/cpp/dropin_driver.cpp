@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "core/common.h"
+#include "models/AsymptoticAnalysisPricer.h"
 #include "models/LSMPricer.h"
 #include "models/RoughVolatility.h"
 
@@ -33,6 +34,7 @@ int main(int argc, char** argv) {
 #pragma omp parallel for schedule(dynamic) reduction(+ : failures)
     for (int row = 0; row < n_rows; ++row) {
         LSM lsm;                  // per row, per thread (PredictionGen.cpp:566-570)
+        AsymptoticAnalysis aa;
         RoughVolatility roughVol;
         try {
             const int steps = 10 + 5 * (row % 7);
@@ -44,6 +46,8 @@ int main(int argc, char** argv) {
                 for (double px : p)
                     if (!std::isfinite(px)) throw std::runtime_error("non-finite path");   // :753-766
             const double v = lsm.PredictOptionPrice(paths, r, strike, maturity, dt, false, 2);   // :790
+            const double asym = aa.PredictOptionPrice(paths, r, strike, maturity, dt, false, 0.2, 0.08);   // :788
+            if (!(asym >= 0.0) || !(asym < strike)) throw std::runtime_error("asymptotic price out of range");
             double eu = 0.0;
             for (auto& p : paths) eu += PayoffFunction(false, p.back(), strike);
             eu = std::exp(-r * maturity) * eu / paths.size();

@@ -384,3 +384,27 @@ def test_gbm_large_steps_take_the_general_exp_path(eng, orc):
         want = orc.paths_gbm(SEED, 100.0, 0.04, sigma, dt, steps, 5, 777)
         assert rel_err(P.to_host_step_major(), want) < 1e-11
         P.free()
+
+
+# ------------------------------------------------------------------------------------------------
+# AsymptoticAnalysis
+# ------------------------------------------------------------------------------------------------
+def test_asymptotic_matches_reference_goldens_and_oracle(eng, orc):
+    import os
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "asymptotic.npz"))
+    aa = mc.AsymptoticAnalysis()
+    for which, is_call, maturity, dt, sigma, div, K, r, want in d["cases"]:
+        m = d["paths_dirty"] if which else d["paths"]
+        got = aa.PredictOptionPrice(m, r, K, maturity, dt, bool(is_call), sigma, div)   # class API, host paths
+        assert abs(got - want) <= 1e-13 * max(abs(want), 1e-300), (got, want)
+    # device-resident path, larger: 200k x 64 GBM
+    P = eng.gbm(SEED, 100.0, 0.04, 0.2, DT, 64, 200_000)
+    host = P.to_host_step_major()
+    for is_call in (False, True):
+        got = eng.price_asymptotic(P, 0.04, 100.0, 64 * DT, DT, is_call, 0.2, 0.08)
+        want = orc.asymptotic_price(host, 0.04, 100.0, 64 * DT, DT, is_call, 0.2, 0.08)
+        assert abs(got - want) <= 1e-12 * want, (got, want)
+    P.free()
+    assert aa.PredictOptionPrice(np.zeros((0, 0)), 0.04, 100.0, 1.0, DT, False, 0.2, 0.0) == 0.0
+    with pytest.raises(mc.McgError, match="AsymptoticAnalysis: Volatility must be positive."):
+        aa.PredictOptionPrice(d["paths"], 0.04, 100.0, 1.0, DT, False, 0.0, 0.0)

@@ -110,3 +110,18 @@ def test_live_reference_random_inputs(orc):
     q = orc.estimate_params(h)
     for k in ("xi", "H", "eta", "rho", "S0"):
         assert p[k] == q[k]
+
+
+def test_asymptotic_pricer_bit_exact(orc):
+    """AsymptoticAnalysis::PredictOptionPrice (src/models/AsymptoticAnalysisPricer.cpp:38-113) against the
+    compiled reference on stored path matrices, incl. NaN/inf entries and a maturity shorter than the grid."""
+    d = np.load(os.path.join(G, "asymptotic.npz"))
+    for which, is_call, maturity, dt, sigma, div, K, r, want in d["cases"]:
+        m = d["paths_dirty"] if which else d["paths"]
+        got = orc.asymptotic_price(m, r, K, maturity, dt, bool(is_call), sigma, div, step_major=False)
+        assert got == want, (got, want)
+        # layout-independent
+        assert orc.asymptotic_price(np.ascontiguousarray(m.T), r, K, maturity, dt, bool(is_call), sigma, div) == want
+    assert orc.asymptotic_price(np.zeros((0, 0)), 0.04, 100.0, 1.0, 0.1, False, 0.2, 0.0) == 0.0   # :47-49
+    with pytest.raises(RuntimeError, match="AsymptoticAnalysis: Volatility must be positive."):       # :50-52
+        orc.asymptotic_price(d["paths"], 0.04, 100.0, 1.0, 0.1, False, 0.0, 0.0, step_major=False)
