@@ -51,7 +51,8 @@ enum mcg_kernel {
     MCG_K_LSM_SOLVE = 4,  /* LSM per-date reduce+solve kernels              */
     MCG_K_TRANSPOSE = 5,  /* layout change for the host class API           */
     MCG_K_ASYM = 6,       /* AsymptoticAnalysis boundary scan               */
-    MCG_K_COUNT = 7
+    MCG_K_MARTINGALE = 7, /* MartingaleOptimization primal/offset/dual scans */
+    MCG_K_COUNT = 8
 };
 
 const char* mcg_last_error(void);
@@ -134,6 +135,14 @@ int mcg_price_lsm(mcg_ctx* ctx, const mcg_paths* paths, double r, double K, doub
 int mcg_price_asymptotic(mcg_ctx* ctx, const mcg_paths* paths, double r, double K, double maturity,
                          double dt, int is_call, double sigma, double dividend, double* price);
 
+/* MartingaleOptimization::PredictOptionPrice (src/models/MartingaleOptimizationPricer.cpp:21-189):
+ * 0.5 * (primal + dual) after max_iterations iterations; lower/upper (optional) receive the two bounds.
+ * poly_order in [0, 8]; max_iterations <= 0 is MCG_ERR_INVALID with the reference's message.
+ *  */
+int mcg_price_martingale(mcg_ctx* ctx, const mcg_paths* paths, double r, double K, double maturity,
+                         double dt, int is_call, int poly_order, int max_iterations, double* price,
+                         double* lower, double* upper);
+
 /* ---- host-side pieces of the class-level API (a2/a3 of SURVEY.md section 8) --------------- */
 /* RoughVolatility.cpp:324-331: out5 = {xi, H, eta, rho, S0}. */
 int mcg_estimate_params(const double* hist, size_t n, double out5[5]);
@@ -154,6 +163,10 @@ int mcg_compat_lsm_price(const double* row_major, int64_t n_paths, int n_cols, d
                          double* price);
 /* AsymptoticAnalysis::PredictOptionPrice(pricePaths, r, strike, maturity, dt, isCall, sigma, dividend);
  * like the reference, empty or ragged input prices to 0.0 (status MCG_OK). */
+/* MartingaleOptimization::PredictOptionPrice(pricePaths, r, strike, maturity, dt, isCall, polyOrder, maxIterations) */
+int mcg_compat_martingale_price(const double* row_major, int64_t n_paths, int n_cols, double r,
+                                double strike, double maturity, double dt, int is_call, int poly_order,
+                                int max_iterations, double* price);
 int mcg_compat_asymptotic_price(const double* row_major, int64_t n_paths, int n_cols, double r,
                                 double strike, double maturity, double dt, int is_call, double sigma,
                                 double dividend, double* price);

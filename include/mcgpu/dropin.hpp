@@ -8,6 +8,7 @@
 //   class LSM              <->  reference include/models/LSMPricer.h:5-15
 //   PayoffFunction         <->  reference include/core/common.h:8-14
 //   class AsymptoticAnalysis <-> reference include/models/AsymptoticAnalysisPricer.h:5-16
+//   class MartingaleOptimization <-> reference include/models/MartingaleOptimizationPricer.h:7-18
 //
 // Error behaviour mirrors the reference: std::runtime_error("Historical prices vector too small.")
 // (RoughVolatility.cpp:317-319) and std::runtime_error("LSM::PredictOptionPrice: Empty pricePaths.")
@@ -53,6 +54,14 @@ public:
     // std::runtime_error("AsymptoticAnalysis: Volatility must be positive.") when sigma <= 0.
     double PredictOptionPrice(const std::vector<std::vector<double>>& pricePaths, double r, double strike,
                               double maturity, double dt, bool isCall, double sigma, double dividend);
+};
+
+class MartingaleOptimization {
+public:
+    // Primal/dual martingale bounds (reference include/models/MartingaleOptimizationPricer.h:7-18).  Throws
+    // std::runtime_error("MartingaleOptimization: Empty pricePaths.") / ("... maxIterations must be positive.").
+    double PredictOptionPrice(const std::vector<std::vector<double>>& pricePaths, double r, double strike,
+                              double maturity, double dt, bool isCall, int polyOrder, int maxIterations = 5);
 };
 
 #endif  // MCGPU_DROPIN_HPP

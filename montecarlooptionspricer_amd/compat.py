@@ -71,3 +71,18 @@ class AsymptoticAnalysis:
         check(L.mcg_compat_asymptotic_price(a.ctypes.data_as(_dp), a.shape[0], a.shape[1], r, strike, maturity, dt,
                                             int(bool(isCall)), sigma, dividend, C.byref(price)))
         return price.value
+
+
+class MartingaleOptimization:
+    """<-> /root/reference/include/models/MartingaleOptimizationPricer.h:7-18."""
+
+    def PredictOptionPrice(self, pricePaths, r: float, strike: float, maturity: float, dt: float, isCall: bool,
+                           polyOrder: int, maxIterations: int = 5) -> float:
+        L = N.load_library()
+        a = np.ascontiguousarray(pricePaths, dtype=np.float64)
+        if a.ndim != 2:
+            a = a.reshape(0, 0)
+        price = C.c_double()
+        check(L.mcg_compat_martingale_price(a.ctypes.data_as(_dp), a.shape[0], a.shape[1], r, strike, maturity, dt,
+                                            int(bool(isCall)), int(polyOrder), int(maxIterations), C.byref(price)))
+        return price.value

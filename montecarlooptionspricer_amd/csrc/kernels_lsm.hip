@@ -102,12 +102,12 @@ __global__ __launch_bounds__(256) void k_lsm_sweep(LsmArgs a) {
 // date: ~1 us).  Otherwise (one ITM path, all paths equal at j = 0, ...): cyclic Jacobi
 // eigen-decomposition and a pseudo-inverse with relative eigenvalue cut 1e-12, which yields the
 // projection the reference's min-norm SVD solve gives at the data points.
-__device__ void lsm_solve_one(const double* moments, int nb, double* coef) {
+__device__ void lsm_solve_one(const double* moments, int nb, double min_count, double* coef) {
     double G[9][9], Q[9][9], rhs[9], d[9], sol[9];
     const double count = moments[0];
     coef[9] = count;
     for (int a = 0; a < 9; ++a) coef[a] = 0.0;
-    if (!(count > 0.0)) return;
+    if (!(count >= min_count) || !(count > 0.0)) return;  // too few samples: coefficients stay 0
     for (int a = 0; a < nb; ++a) {
         const double g = moments[2 * a];
         d[a] = g > 0.0 ? 1.0 / sqrt(g) : 0.0;
@@ -200,7 +200,8 @@ __device__ void lsm_solve_one(const double* moments, int nb, double* coef) {
 // w, w+4, ...: lanes stride over the blocks, then a wavefront butterfly).  do_solve: moments -> coef.
 // Single GPU: both in one launch.  Sharded: reduce, all-reduce of `moments`, then solve.
 __global__ __launch_bounds__(256) void k_lsm_reduce_solve(const double* partials, int n_blocks, int nm, int nb,
-                                                          double* moments, double* coef, int do_reduce, int do_solve) {
+                                                          double* moments, double* coef, int do_reduce, int do_solve,
+                                                          double min_count) {
     __shared__ double sm[32];
     if (do_reduce) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -215,7 +216,7 @@ __global__ __launch_bounds__(256) void k_lsm_reduce_solve(const double* partials
         }
         __syncthreads();
     }
-    if (do_solve && threadIdx.x == 0) lsm_solve_one(do_reduce ? sm : moments, nb, coef);
+    if (do_solve && threadIdx.x == 0) lsm_solve_one(do_reduce ? sm : moments, nb, min_count, coef);
 }
 
 // sum V, sum V^2 -> partials[grid][2]
@@ -232,6 +233,31 @@ __global__ __launch_bounds__(256) void k_lsm_final(const double* V, int64_t n, d
         partials[2 * (int64_t)blockIdx.x] = v[0];
         partials[2 * (int64_t)blockIdx.x + 1] = v[1];
     }
+}
+
+// partials[grid][nm] -> moments (fixed order) -> optional all-reduce -> coefficients in ctx->scalars.
+// Shared by the LSM sweep and the MartingaleOptimization refit.
+int lsm_reduce_allreduce_solve(mcg_ctx* ctx, int grid, int nm, int nb, double min_count) {
+    double* moments = ctx->scalars + SC_MOMENTS;
+    double* coef = ctx->scalars + SC_COEF;
+    if (ctx->allreduce) {
+        {
+            TimedLaunch t(ctx, MCG_K_LSM_SOLVE);
+            hipLaunchKernelGGL(k_lsm_reduce_solve, dim3(1), dim3(256), 0, ctx->stream, ctx->partials, grid, nm, nb,
+                               moments, coef, 1, 0, min_count);
+        }
+        if (ctx->allreduce(ctx->allreduce_user, moments, nm, (void*)ctx->stream) != 0)
+            return fail(MCG_ERR_COMM, "all-reduce of regression moments failed");
+        TimedLaunch t(ctx, MCG_K_LSM_SOLVE);
+        hipLaunchKernelGGL(k_lsm_reduce_solve, dim3(1), dim3(256), 0, ctx->stream, ctx->partials, grid, nm, nb, moments,
+                           coef, 0, 1, min_count);
+    } else {
+        TimedLaunch t(ctx, MCG_K_LSM_SOLVE);
+        hipLaunchKernelGGL(k_lsm_reduce_solve, dim3(1), dim3(256), 0, ctx->stream, ctx->partials, grid, nm, nb, moments,
+                           coef, 1, 1, min_count);
+    }
+    MCG_HIP(hipGetLastError());
+    return MCG_OK;
 }
 
 template <int NB>
@@ -268,7 +294,6 @@ int run_lsm(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double maturit
     rc = ensure_cap(ctx, &ctx->partials, &ctx->partials_cap, (size_t)grid * (size_t)std::max(nm, 2));
     if (rc) return rc;
 
-    double* moments = ctx->scalars + SC_MOMENTS;
     double* coef = ctx->scalars + SC_COEF;
     const double disc = std::exp(-r * dt);  // LSMPricer.cpp:46,:69,:92
     auto row = [&](int j) { return P->data + (int64_t)j * P->ld; };
@@ -297,22 +322,8 @@ int run_lsm(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double maturit
     for (int j = M - 2; j >= 0; --j) {
         const bool reg = regress_at(j);
         if (reg) {
-            if (ctx->allreduce) {
-                {
-                    TimedLaunch t(ctx, MCG_K_LSM_SOLVE);
-                    hipLaunchKernelGGL(k_lsm_reduce_solve, dim3(1), dim3(256), 0, ctx->stream, ctx->partials, grid, nm,
-                                       nb, moments, coef, 1, 0);
-                }
-                if (ctx->allreduce(ctx->allreduce_user, moments, nm, (void*)ctx->stream) != 0)
-                    return fail(MCG_ERR_COMM, "all-reduce of LSM moments failed at date %d", j);
-                TimedLaunch t(ctx, MCG_K_LSM_SOLVE);
-                hipLaunchKernelGGL(k_lsm_reduce_solve, dim3(1), dim3(256), 0, ctx->stream, ctx->partials, grid, nm, nb,
-                                   moments, coef, 0, 1);
-            } else {
-                TimedLaunch t(ctx, MCG_K_LSM_SOLVE);
-                hipLaunchKernelGGL(k_lsm_reduce_solve, dim3(1), dim3(256), 0, ctx->stream, ctx->partials, grid, nm, nb,
-                                   moments, coef, 1, 1);
-            }
+            int rcs = lsm_reduce_allreduce_solve(ctx, grid, nm, nb, 1.0);
+            if (rcs) return rcs;
         }
         a.upd = reg ? UPD_REGRESS : UPD_DISCOUNT;
         a.S_upd = row(j);

@@ -521,6 +521,17 @@ int mcg_price_asymptotic(mcg_ctx* ctx, const mcg_paths* P, double r, double K, d
     return run_asymptotic(ctx, P, r, K, maturity, dt, is_call, sigma, dividend, price);
 }
 
+int mcg_price_martingale(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double maturity, double dt, int is_call,
+                         int poly_order, int max_iterations, double* price, double* lower, double* upper) {
+    if (!ctx || !P || !price) return fail(MCG_ERR_INVALID, "ctx/paths/price is NULL");
+    if (P->ctx != ctx) return fail(MCG_ERR_INVALID, "paths belong to a different ctx");
+    if (P->n_paths < 1 && !ctx->allreduce) return fail(MCG_ERR_EMPTY_PATHS, "MartingaleOptimization: Empty pricePaths.");
+    if (max_iterations <= 0) return fail(MCG_ERR_INVALID, "MartingaleOptimization: maxIterations must be positive.");
+    if (poly_order < 0 || poly_order > 8) return fail(MCG_ERR_INVALID, "poly_order must be in [0,8] (got %d)", poly_order);
+    MCG_HIP(hipSetDevice(ctx->device));
+    return run_martingale(ctx, P, r, K, maturity, dt, is_call, poly_order, max_iterations, price, lower, upper);
+}
+
 // ---- host-only pieces --------------------------------------------------------------------------
 int mcg_estimate_params(const double* hist, size_t n, double out5[5]) {
     if (!out5) return fail(MCG_ERR_INVALID, "out5 is NULL");

@@ -122,6 +122,9 @@ int finish_sums(mcg_ctx* ctx, int64_t n_blocks, int64_t n_local, double out3[3])
 int run_lsm(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double maturity, double dt, int is_call,
             int poly_order, double* mean, double* std_err);
 
+int lsm_reduce_allreduce_solve(mcg_ctx* ctx, int grid, int nm, int nb, double min_count);
+int run_martingale(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double maturity, double dt, int is_call,
+                   int poly_order, int max_iterations, double* price, double* lower, double* upper);
 int run_asymptotic(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double maturity, double dt, int is_call,
                    double sigma, double dividend, double* price);
 

@@ -208,6 +208,15 @@ class PathEngine:
                                            C.byref(p)))
         return p.value
 
+    def price_martingale(self, paths: PathMatrix, r: float, K: float, maturity: float, dt: float, is_call: bool,
+                         poly_order: int, max_iterations: int = 5) -> Tuple[float, float, float]:
+        """(price, lower, upper) of MartingaleOptimization::PredictOptionPrice."""
+        paths._alive()
+        p, lo, up = C.c_double(), C.c_double(), C.c_double()
+        check(self._L.mcg_price_martingale(self._ctx, paths._h, r, K, maturity, dt, int(bool(is_call)), int(poly_order),
+                                           int(max_iterations), C.byref(p), C.byref(lo), C.byref(up)))
+        return p.value, lo.value, up.value
+
     def debug_eval(self, fn: int, x: np.ndarray) -> np.ndarray:
         """Test hook (mcg_debug_eval): one device math routine elementwise; returns [n][4]."""
         x = np.ascontiguousarray(x, dtype=np.float64)

@@ -4,6 +4,7 @@
 //   RoughVolatility::GenerateStockPricePaths  <->  /root/reference/src/models/RoughVolatility.cpp:312-368
 //   LSM::PredictOptionPrice                   <->  /root/reference/src/models/LSMPricer.cpp:19-102
 //   AsymptoticAnalysis::PredictOptionPrice    <->  /root/reference/src/models/AsymptoticAnalysisPricer.cpp:38-113
+//   MartingaleOptimization::PredictOptionPrice <-> /root/reference/src/models/MartingaleOptimizationPricer.cpp:21-189
 #include <atomic>
 #include <cmath>
 #include <cstdlib>
@@ -135,7 +136,50 @@ double AsymptoticAnalysis::PredictOptionPrice(const std::vector<std::vector<doub
     }
 }
 
+double MartingaleOptimization::PredictOptionPrice(const std::vector<std::vector<double>>& pricePaths, double r,
+                                                  double strike, double maturity, double dt, bool isCall, int polyOrder,
+                                                  int maxIterations) {
+    if (pricePaths.empty() || pricePaths[0].empty())
+        throw std::runtime_error("MartingaleOptimization: Empty pricePaths.");                      // :31-33
+    if (maxIterations <= 0) throw std::runtime_error("MartingaleOptimization: maxIterations must be positive.");  // :34-36
+    if (polyOrder < 0 || polyOrder > 8) throw std::invalid_argument("MartingaleOptimization: polyOrder must be in [0, 8]");
+    const size_t N = pricePaths.size(), M = pricePaths[0].size();
+    std::vector<double> flat(N * M);
+    for (size_t i = 0; i < N; ++i) {
+        if (pricePaths[i].size() < M) throw std::runtime_error("MartingaleOptimization: ragged pricePaths.");
+        std::copy(pricePaths[i].begin(), pricePaths[i].begin() + M, flat.begin() + i * M);
+    }
+    mcg_ctx* ctx = t_ctx.get();
+    PathsGuard g;
+    if (mcg_paths_from_host(ctx, flat.data(), (int64_t)N, (int)M, &g.p) != MCG_OK) raise_last();
+    double price = 0.0;
+    if (mcg_price_martingale(ctx, g.p, r, strike, maturity, dt, isCall ? 1 : 0, polyOrder, maxIterations, &price, nullptr,
+                             nullptr) != MCG_OK)
+        raise_last();
+    return price;
+}
+
 extern "C" {
+
+int mcg_compat_martingale_price(const double* row_major, int64_t n_paths, int n_cols, double r, double strike,
+                                double maturity, double dt, int is_call, int poly_order, int max_iterations,
+                                double* price) {
+    try {
+        std::vector<std::vector<double>> m;
+        if (row_major && n_paths > 0 && n_cols > 0) {
+            m.resize((size_t)n_paths);
+            for (int64_t i = 0; i < n_paths; ++i) m[i].assign(row_major + i * n_cols, row_major + (i + 1) * n_cols);
+        }
+        MartingaleOptimization mo;
+        const double v = mo.PredictOptionPrice(m, r, strike, maturity, dt, is_call != 0, poly_order, max_iterations);
+        if (price) *price = v;
+        return MCG_OK;
+    } catch (const std::exception& e) {
+        const std::string msg = e.what();
+        const int code = msg == "MartingaleOptimization: Empty pricePaths." ? MCG_ERR_EMPTY_PATHS : MCG_ERR_INVALID;
+        return mcg::fail(code, "%s", msg.c_str());
+    }
+}
 
 int mcg_compat_asymptotic_price(const double* row_major, int64_t n_paths, int n_cols, double r, double strike,
                                 double maturity, double dt, int is_call, double sigma, double dividend,

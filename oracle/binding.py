@@ -89,6 +89,9 @@ class Oracle:
         L.orc_asymptotic_price.argtypes = [_dp, C.c_size_t, C.c_size_t, C.c_long, C.c_int] + [C.c_double] * 4 + \
             [C.c_int, C.c_double, C.c_double, _dp]
         L.orc_asymptotic_price.restype = C.c_int
+        L.orc_martingale_price.argtypes = [_dp, C.c_size_t, C.c_size_t, C.c_long, C.c_int] + [C.c_double] * 4 + \
+            [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp]
+        L.orc_martingale_price.restype = C.c_int
         L.orc_num_threads.restype = C.c_int
 
     # -- estimators / spectral ------------------------------------------------------------------
@@ -266,6 +269,28 @@ class Oracle:
         if rc:
             raise RuntimeError("AsymptoticAnalysis: Volatility must be positive.")
         return price.value
+
+    def martingale_price(self, paths, r, K, maturity, dt, is_call, poly_order, max_iterations=5, step_major=True):
+        """(price, lower, upper)."""
+        a = np.ascontiguousarray(paths, dtype=np.float64)
+        if a.ndim != 2 or a.size == 0:
+            raise RuntimeError("MartingaleOptimization: Empty pricePaths.")
+        if step_major:
+            n_cols, n_paths = a.shape
+            ps, ss = 1, n_paths
+        else:
+            n_paths, n_cols = a.shape
+            ps, ss = n_cols, 1
+        p, lo, up = C.c_double(), C.c_double(), C.c_double()
+        rc = self.L.orc_martingale_price(_p(a), ps, ss, n_paths, n_cols, r, K, maturity, dt, int(bool(is_call)),
+                                         poly_order, max_iterations, C.byref(p), C.byref(lo), C.byref(up))
+        if rc == 1:
+            raise RuntimeError("MartingaleOptimization: Empty pricePaths.")
+        if rc == 2:
+            raise RuntimeError("MartingaleOptimization: maxIterations must be positive.")
+        if rc:
+            raise RuntimeError("orc_martingale_price failed rc=%d" % rc)
+        return p.value, lo.value, up.value
 
     def num_threads(self):
         return int(self.L.orc_num_threads())

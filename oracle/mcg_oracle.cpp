@@ -714,6 +714,98 @@ int orc_asymptotic_price(const double* paths, size_t path_stride, size_t step_st
     return 0;
 }
 
+// MartingaleOptimization::PredictOptionPrice (src/models/MartingaleOptimizationPricer.cpp:21-189), statement
+// for statement: maxIterations x { DoIteration (:69-124), UpdateMartingale (:126-176 + offset :178-183) }.
+// PARITY UNPINNED at the Eigen boundary (:166), like LSM: the least squares is our Jacobi-SVD min-norm solve.
+// Returns 0; 1 for empty input; 2 for maxIterations <= 0 (the reference throws in both cases).
+int orc_martingale_price(const double* paths, size_t path_stride, size_t step_stride, long n_paths, int n_cols,
+                         double r, double K, double maturity, double dt, int is_call, int poly_order,
+                         int max_iterations, double* price, double* lower, double* upper) {
+    if (n_paths < 1 || n_cols < 1) return 1;
+    if (max_iterations <= 0) return 2;
+    if (poly_order < 0 || poly_order > 15) return 3;
+    const bool call = is_call != 0;
+    const long N = n_paths;
+    const int M = n_cols, nb = poly_order + 1;
+    auto S = [&](long i, int j) { return paths[(size_t)i * path_stride + (size_t)j * step_stride]; };
+    auto dfac = [&](int j) {  // PathDiscountFactor, header :46-51
+        double t = j * dt;
+        if (t > maturity) t = maturity;
+        return std::exp(-r * t);
+    };
+    std::vector<double> coef(nb, 0.0);
+    double offset = 0.0;
+    auto evalM = [&](double s) {  // :178-187
+        double val = 0.0, power = 1.0;
+        for (int k = 0; k < nb; ++k) {
+            val += coef[k] * power;
+            power *= s;
+        }
+        return val;
+    };
+    std::vector<int> stop(N, 0);
+    double fin_lo = 0.0, fin_up = 0.0;
+    for (int iter = 1; iter <= max_iterations; ++iter) {
+        double sum_p = 0.0;
+        for (long i = 0; i < N; ++i) {  // :77-98
+            double best = 0.0;
+            int idx = 0;
+            for (int j = 0; j < M; ++j) {
+                if (j * dt > maturity) break;
+                const double d = payoff_of(call, S(i, j), K) * dfac(j);
+                if (d > best) {
+                    best = d;
+                    idx = j;
+                }
+            }
+            stop[i] = idx;
+            sum_p += best;
+        }
+        double sum_d = 0.0;
+        for (long i = 0; i < N; ++i) {  // :100-121
+            double best = 0.0;
+            for (int j = 0; j < M; ++j) {
+                if (j * dt > maturity) break;
+                const double s = S(i, j);
+                const double cand = payoff_of(call, s, K) * dfac(j) - (evalM(s) - offset);
+                if (cand > best) best = cand;
+            }
+            sum_d += best;
+        }
+        fin_lo = sum_p / N;
+        fin_up = sum_d / N;
+        // UpdateMartingale :126-176
+        const size_t rows = 2 * (size_t)N;
+        if ((long)rows >= nb) {
+            std::vector<double> A(rows * nb), b(rows);
+            for (long i = 0; i < N; ++i) {
+                const int js = stop[i], jo = (js + M / 2) % M;
+                const double xs[2] = {S(i, js), S(i, jo)};
+                const double ys[2] = {0.5 * (payoff_of(call, xs[0], K) * dfac(js)), 0.2 * (payoff_of(call, xs[1], K) * dfac(jo))};
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const size_t row = 2 * (size_t)i + s2;
+                    double pw = 1.0;
+                    for (int q = 0; q < nb; ++q) {
+                        A[(size_t)q * rows + row] = pw;
+                        pw = pw * xs[s2];
+                    }
+                    b[row] = ys[s2];
+                }
+            }
+            double c[16];
+            minnorm_lstsq(A, rows, nb, b, c);
+            for (int k = 0; k < nb; ++k) coef[k] = c[k];
+            double sum0 = 0.0;
+            for (long i = 0; i < N; ++i) sum0 += evalM(S(i, 0));
+            offset = sum0 / N;
+        }
+    }
+    *price = 0.5 * (fin_lo + fin_up);
+    if (lower) *lower = fin_lo;
+    if (upper) *upper = fin_up;
+    return 0;
+}
+
 int orc_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

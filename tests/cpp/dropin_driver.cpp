@@ -15,6 +15,7 @@
 #include "core/common.h"
 #include "models/AsymptoticAnalysisPricer.h"
 #include "models/LSMPricer.h"
+#include "models/MartingaleOptimizationPricer.h"
 #include "models/RoughVolatility.h"
 
 extern "C" int mcg_compat_set_seed(unsigned long long seed, int enabled);
@@ -35,6 +36,7 @@ int main(int argc, char** argv) {
     for (int row = 0; row < n_rows; ++row) {
         LSM lsm;                  // per row, per thread (PredictionGen.cpp:566-570)
         AsymptoticAnalysis aa;
+        MartingaleOptimization mo;
         RoughVolatility roughVol;
         try {
             const int steps = 10 + 5 * (row % 7);
@@ -48,6 +50,8 @@ int main(int argc, char** argv) {
             const double v = lsm.PredictOptionPrice(paths, r, strike, maturity, dt, false, 2);   // :790
             const double asym = aa.PredictOptionPrice(paths, r, strike, maturity, dt, false, 0.2, 0.08);   // :788
             if (!(asym >= 0.0) || !(asym < strike)) throw std::runtime_error("asymptotic price out of range");
+            const double mart = mo.PredictOptionPrice(paths, r, strike, maturity, dt, false, 2);            // :791
+            if (!(mart >= 0.0) || !(mart < strike)) throw std::runtime_error("martingale price out of range");
             double eu = 0.0;
             for (auto& p : paths) eu += PayoffFunction(false, p.back(), strike);
             eu = std::exp(-r * maturity) * eu / paths.size();

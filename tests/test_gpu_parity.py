@@ -408,3 +408,33 @@ def test_asymptotic_matches_reference_goldens_and_oracle(eng, orc):
     assert aa.PredictOptionPrice(np.zeros((0, 0)), 0.04, 100.0, 1.0, DT, False, 0.2, 0.0) == 0.0
     with pytest.raises(mc.McgError, match="AsymptoticAnalysis: Volatility must be positive."):
         aa.PredictOptionPrice(d["paths"], 0.04, 100.0, 1.0, DT, False, 0.0, 0.0)
+
+
+# ------------------------------------------------------------------------------------------------
+# MartingaleOptimization
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("is_call,poly,iters", [(False, 2, 5), (True, 2, 5), (False, 3, 2), (False, 2, 1), (False, 0, 4)])
+def test_martingale_matches_oracle(eng, orc, is_call, poly, iters):
+    P = eng.gbm(SEED, 100.0, 0.04, 0.2, DT, 40, 20_000)
+    host = P.to_host_step_major()
+    for maturity in (40 * DT, 25.5 * DT):
+        got = eng.price_martingale(P, 0.04, 100.0, maturity, DT, is_call, poly, iters)
+        want = orc.martingale_price(host, 0.04, 100.0, maturity, DT, is_call, poly, iters)
+        assert np.allclose(got, want, rtol=1e-8, atol=1e-12), (got, want)
+    P.free()
+
+
+def test_martingale_class_api_and_errors(orc):
+    hist = synthetic_history(300, seed=1)
+    mc.set_compat_seed(5)
+    paths = mc.RoughVolatility().GenerateStockPricePaths(hist, 40, 250)      # production shape: 250 paths per row
+    mc.set_compat_seed(None)
+    K = float(hist[-1])
+    mo = mc.MartingaleOptimization()
+    got = mo.PredictOptionPrice(paths, 0.04, K, 40 / 365.0, DT, False, 2)   # PredictionGen.cpp:791 (default 5 iterations)
+    want = orc.martingale_price(paths, 0.04, K, 40 / 365.0, DT, False, 2, 5, step_major=False)[0]
+    assert abs(got - want) <= 1e-8 * abs(want)
+    with pytest.raises(mc.McgError, match="MartingaleOptimization: Empty pricePaths."):
+        mo.PredictOptionPrice(np.zeros((0, 0)), 0.04, K, 1.0, DT, False, 2)
+    with pytest.raises(mc.McgError, match="MartingaleOptimization: maxIterations must be positive."):
+        mo.PredictOptionPrice(paths, 0.04, K, 1.0, DT, False, 2, 0)

@@ -218,3 +218,47 @@ def test_lsm_american_put_above_european(orc):
     am = orc.lsm_price(paths, 0.04, 100.0, 1.0, dt, False, 2)
     eu, se = orc.price_european(paths, 100.0, 0.04, 1.0, False)
     assert am > eu - 2 * se and am < eu + 1.5
+
+
+# ---- MartingaleOptimization --------------------------------------------------------------------
+def martingale_numpy(P, r, K, maturity, dt, is_call, poly, iters):
+    """Independent restatement of MartingaleOptimizationPricer.cpp:21-189 with LAPACK gelsd."""
+    pay = (lambda s: np.maximum(0.0, s - K)) if is_call else (lambda s: np.maximum(0.0, K - s))
+    N, M = P.shape
+    t = np.arange(M) * dt
+    dates = int(np.argmax(t > maturity)) if (t > maturity).any() else M
+    disc = np.exp(-r * np.minimum(t, maturity))
+    d = pay(P) * disc[None, :]
+    coef, offset = np.zeros(poly + 1), 0.0
+    lo = up = 0.0
+    for _ in range(iters):
+        dd = d[:, :dates]
+        best = np.maximum(dd.max(axis=1), 0.0) if dates else np.zeros(N)
+        stop = np.where(best > 0, dd.argmax(axis=1), 0) if dates else np.zeros(N, int)
+        lo = best.mean()
+        Mv = np.polynomial.polynomial.polyval(P[:, :dates], coef) - offset
+        up = np.maximum((dd - Mv).max(axis=1), 0.0).mean() if dates else 0.0
+        other = (stop + M // 2) % M
+        rows = np.arange(N)
+        X = np.empty(2 * N)
+        Y = np.empty(2 * N)
+        X[0::2], Y[0::2] = P[rows, stop], 0.5 * d[rows, stop]
+        X[1::2], Y[1::2] = P[rows, other], 0.2 * d[rows, other]
+        if 2 * N >= poly + 1:
+            A = np.vander(X, poly + 1, increasing=True)
+            coef, *_ = np.linalg.lstsq(A, Y, rcond=min(A.shape) * np.finfo(float).eps)
+            offset = np.polynomial.polynomial.polyval(P[:, 0], coef).mean()
+    return 0.5 * (lo + up), lo, up
+
+
+@pytest.mark.parametrize("is_call,poly,iters", [(False, 2, 5), (True, 2, 5), (False, 3, 2), (False, 2, 1), (False, 0, 3)])
+def test_martingale_oracle_vs_lapack(orc, is_call, poly, iters):
+    P = orc.paths_gbm(21, 100.0, 0.04, 0.2, DT, 40, 0, 3000).T.copy()     # [paths][cols]
+    for maturity in (40 * DT, 25.5 * DT):                                  # second: grid longer than maturity
+        got = orc.martingale_price(P, 0.04, 100.0, maturity, DT, is_call, poly, iters, step_major=False)
+        want = martingale_numpy(P, 0.04, 100.0, maturity, DT, is_call, poly, iters)
+        assert np.allclose(got, want, rtol=1e-9, atol=1e-12), (got, want)
+    with pytest.raises(RuntimeError, match="MartingaleOptimization: Empty pricePaths."):
+        orc.martingale_price(np.zeros((0, 0)), 0.04, 100.0, 1.0, DT, False, 2)
+    with pytest.raises(RuntimeError, match="MartingaleOptimization: maxIterations must be positive."):
+        orc.martingale_price(P, 0.04, 100.0, 1.0, DT, False, 2, 0, step_major=False)
