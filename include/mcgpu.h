@@ -52,7 +52,8 @@ enum mcg_kernel {
     MCG_K_TRANSPOSE = 5,  /* layout change for the host class API           */
     MCG_K_ASYM = 6,       /* AsymptoticAnalysis boundary scan               */
     MCG_K_MARTINGALE = 7, /* MartingaleOptimization primal/offset/dual scans */
-    MCG_K_COUNT = 8
+    MCG_K_BRANCHING = 8,  /* BranchingProcesses suffix-max + bounds kernels   */
+    MCG_K_COUNT = 9
 };
 
 const char* mcg_last_error(void);
@@ -143,6 +144,15 @@ int mcg_price_martingale(mcg_ctx* ctx, const mcg_paths* paths, double r, double 
                          double dt, int is_call, int poly_order, int max_iterations, double* price,
                          double* lower, double* upper);
 
+/* BranchingProcesses::PredictOptionPrice (src/models/BranchingProcessPricer.cpp:12-134): midpoint of the
+ * first-positive-payoff lower bound and the resampled-branch upper bound.  exercise_times are column indices
+ * (the reference's driver passes 0..steps-1, PredictionGen.cpp:780-783).  The reference resamples with an
+ * unseeded mt19937; here the resampling is Philox stream 2 of `seed`, so a call is reproducible.
+ * Error messages are the reference's.   */
+int mcg_price_branching(mcg_ctx* ctx, const mcg_paths* paths, double r, double K, double maturity,
+                        double dt, int is_call, int num_branches, const int* exercise_times,
+                        int n_exercise_times, uint64_t seed, double* price, double* lower, double* upper);
+
 /* ---- host-side pieces of the class-level API (a2/a3 of SURVEY.md section 8) --------------- */
 /* RoughVolatility.cpp:324-331: out5 = {xi, H, eta, rho, S0}. */
 int mcg_estimate_params(const double* hist, size_t n, double out5[5]);
@@ -167,6 +177,10 @@ int mcg_compat_lsm_price(const double* row_major, int64_t n_paths, int n_cols, d
 int mcg_compat_martingale_price(const double* row_major, int64_t n_paths, int n_cols, double r,
                                 double strike, double maturity, double dt, int is_call, int poly_order,
                                 int max_iterations, double* price);
+/* BranchingProcesses::PredictOptionPrice(pricePaths, r, strike, maturity, dt, isCall, numBranches, exerciseTimes) */
+int mcg_compat_branching_price(const double* row_major, int64_t n_paths, int n_cols, double r,
+                               double strike, double maturity, double dt, int is_call, int num_branches,
+                               const int* exercise_times, int n_exercise_times, double* price);
 int mcg_compat_asymptotic_price(const double* row_major, int64_t n_paths, int n_cols, double r,
                                 double strike, double maturity, double dt, int is_call, double sigma,
                                 double dividend, double* price);

@@ -9,6 +9,7 @@
 //   PayoffFunction         <->  reference include/core/common.h:8-14
 //   class AsymptoticAnalysis <-> reference include/models/AsymptoticAnalysisPricer.h:5-16
 //   class MartingaleOptimization <-> reference include/models/MartingaleOptimizationPricer.h:7-18
+//   class BranchingProcesses <-> reference include/models/BranchingProcessPricer.h:5-16
 //
 // Error behaviour mirrors the reference: std::runtime_error("Historical prices vector too small.")
 // (RoughVolatility.cpp:317-319) and std::runtime_error("LSM::PredictOptionPrice: Empty pricePaths.")
@@ -62,6 +63,16 @@ public:
     // std::runtime_error("MartingaleOptimization: Empty pricePaths.") / ("... maxIterations must be positive.").
     double PredictOptionPrice(const std::vector<std::vector<double>>& pricePaths, double r, double strike,
                               double maturity, double dt, bool isCall, int polyOrder, int maxIterations = 5);
+};
+
+class BranchingProcesses {
+public:
+    // Lower/upper bound midpoint by branch resampling (reference include/models/BranchingProcessPricer.h:5-16).
+    // Throws std::runtime_error("BranchingProcesses: Empty pricePaths." / "... No exercise times." /
+    // "... Strike must be positive.") like the reference.
+    double PredictOptionPrice(const std::vector<std::vector<double>>& pricePaths, double r, double strike,
+                              double maturity, double dt, bool isCall, int numBranches,
+                              const std::vector<int>& exerciseTimes);
 };
 
 #endif  // MCGPU_DROPIN_HPP

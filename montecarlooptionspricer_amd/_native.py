@@ -9,9 +9,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "lib", "libmcgpu.so")
 
 MCG_OK = 0
-K_GBM, K_RBERGOMI, K_PAYOFF, K_LSM_SWEEP, K_LSM_SOLVE, K_TRANSPOSE, K_ASYM, K_MARTINGALE = range(8)
+K_GBM, K_RBERGOMI, K_PAYOFF, K_LSM_SWEEP, K_LSM_SOLVE, K_TRANSPOSE, K_ASYM, K_MARTINGALE, K_BRANCHING = range(9)
 KERNEL_NAMES = {K_GBM: "gbm", K_RBERGOMI: "rbergomi", K_PAYOFF: "payoff", K_LSM_SWEEP: "lsm_sweep",
-                K_LSM_SOLVE: "lsm_solve", K_TRANSPOSE: "transpose", K_ASYM: "asymptotic", K_MARTINGALE: "martingale"}
+                K_LSM_SOLVE: "lsm_solve", K_TRANSPOSE: "transpose", K_ASYM: "asymptotic", K_MARTINGALE: "martingale", K_BRANCHING: "branching"}
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p)
 
@@ -81,6 +81,9 @@ def load_library():
     L.mcg_compat_asymptotic_price.argtypes = [dp, C.c_int64, C.c_int] + [C.c_double] * 4 + [C.c_int, C.c_double, C.c_double, dp]
     L.mcg_price_martingale.argtypes = [vp, vp] + [C.c_double] * 4 + [C.c_int, C.c_int, C.c_int, dp, dp, dp]
     L.mcg_compat_martingale_price.argtypes = [dp, C.c_int64, C.c_int] + [C.c_double] * 4 + [C.c_int, C.c_int, C.c_int, dp]
+    ip = C.POINTER(C.c_int)
+    L.mcg_price_branching.argtypes = [vp, vp] + [C.c_double] * 4 + [C.c_int, C.c_int, ip, C.c_int, C.c_uint64, dp, dp, dp]
+    L.mcg_compat_branching_price.argtypes = [dp, C.c_int64, C.c_int] + [C.c_double] * 4 + [C.c_int, C.c_int, ip, C.c_int, dp]
     L.mcg_estimate_params.argtypes = [dp, C.c_size_t, dp]
     L.mcg_rbergomi_weights.argtypes = [C.c_double, C.c_double, C.c_double, C.c_int, dp, dp, C.POINTER(C.c_int)]
     L.mcg_compat_set_seed.argtypes = [C.c_uint64, C.c_int]

@@ -86,3 +86,20 @@ class MartingaleOptimization:
         check(L.mcg_compat_martingale_price(a.ctypes.data_as(_dp), a.shape[0], a.shape[1], r, strike, maturity, dt,
                                             int(bool(isCall)), int(polyOrder), int(maxIterations), C.byref(price)))
         return price.value
+
+
+class BranchingProcesses:
+    """<-> /root/reference/include/models/BranchingProcessPricer.h:5-16."""
+
+    def PredictOptionPrice(self, pricePaths, r: float, strike: float, maturity: float, dt: float, isCall: bool,
+                           numBranches: int, exerciseTimes) -> float:
+        L = N.load_library()
+        a = np.ascontiguousarray(pricePaths, dtype=np.float64)
+        if a.ndim != 2:
+            a = a.reshape(0, 0)
+        ex = np.ascontiguousarray(exerciseTimes, dtype=np.int32).ravel()
+        price = C.c_double()
+        check(L.mcg_compat_branching_price(a.ctypes.data_as(_dp), a.shape[0], a.shape[1], r, strike, maturity, dt,
+                                           int(bool(isCall)), int(numBranches), ex.ctypes.data_as(C.POINTER(C.c_int)),
+                                           len(ex), C.byref(price)))
+        return price.value

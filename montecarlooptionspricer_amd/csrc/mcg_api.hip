@@ -532,6 +532,18 @@ int mcg_price_martingale(mcg_ctx* ctx, const mcg_paths* P, double r, double K, d
     return run_martingale(ctx, P, r, K, maturity, dt, is_call, poly_order, max_iterations, price, lower, upper);
 }
 
+int mcg_price_branching(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double maturity, double dt, int is_call,
+                        int num_branches, const int* exercise_times, int n_ex, uint64_t seed, double* price, double* lower,
+                        double* upper) {
+    if (!ctx || !P || !price) return fail(MCG_ERR_INVALID, "ctx/paths/price is NULL");
+    if (P->ctx != ctx) return fail(MCG_ERR_INVALID, "paths belong to a different ctx");
+    if (P->n_paths < 1 && !ctx->allreduce) return fail(MCG_ERR_EMPTY_PATHS, "BranchingProcesses: Empty pricePaths.");  // :22-24
+    if (!exercise_times || n_ex < 1) return fail(MCG_ERR_INVALID, "BranchingProcesses: No exercise times.");              // :25-27
+    if (K <= 0.0) return fail(MCG_ERR_INVALID, "BranchingProcesses: Strike must be positive.");                           // :28-30
+    MCG_HIP(hipSetDevice(ctx->device));
+    return run_branching(ctx, P, r, K, maturity, dt, is_call, num_branches, exercise_times, n_ex, seed, price, lower, upper);
+}
+
 // ---- host-only pieces --------------------------------------------------------------------------
 int mcg_estimate_params(const double* hist, size_t n, double out5[5]) {
     if (!out5) return fail(MCG_ERR_INVALID, "out5 is NULL");

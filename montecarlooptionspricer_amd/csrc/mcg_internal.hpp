@@ -125,6 +125,9 @@ int run_lsm(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double maturit
 int lsm_reduce_allreduce_solve(mcg_ctx* ctx, int grid, int nm, int nb, double min_count);
 int run_martingale(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double maturity, double dt, int is_call,
                    int poly_order, int max_iterations, double* price, double* lower, double* upper);
+int run_branching(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double maturity, double dt, int is_call,
+                  int num_branches, const int* exercise_times, int n_ex, uint64_t seed, double* price, double* lower,
+                  double* upper);
 int run_asymptotic(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double maturity, double dt, int is_call,
                    double sigma, double dividend, double* price);
 

@@ -217,6 +217,17 @@ class PathEngine:
                                            int(max_iterations), C.byref(p), C.byref(lo), C.byref(up)))
         return p.value, lo.value, up.value
 
+    def price_branching(self, paths: PathMatrix, r: float, K: float, maturity: float, dt: float, is_call: bool,
+                        num_branches: int, exercise_times, seed: int) -> Tuple[float, float, float]:
+        """(price, lower, upper) of BranchingProcesses::PredictOptionPrice; resampling = Philox stream 2 of seed."""
+        paths._alive()
+        ex = np.ascontiguousarray(exercise_times, dtype=np.int32)
+        p, lo, up = C.c_double(), C.c_double(), C.c_double()
+        check(self._L.mcg_price_branching(self._ctx, paths._h, r, K, maturity, dt, int(bool(is_call)), int(num_branches),
+                                          ex.ctypes.data_as(C.POINTER(C.c_int)), len(ex), int(seed), C.byref(p),
+                                          C.byref(lo), C.byref(up)))
+        return p.value, lo.value, up.value
+
     def debug_eval(self, fn: int, x: np.ndarray) -> np.ndarray:
         """Test hook (mcg_debug_eval): one device math routine elementwise; returns [n][4]."""
         x = np.ascontiguousarray(x, dtype=np.float64)

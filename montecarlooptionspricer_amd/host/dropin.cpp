@@ -5,6 +5,7 @@
 //   LSM::PredictOptionPrice                   <->  /root/reference/src/models/LSMPricer.cpp:19-102
 //   AsymptoticAnalysis::PredictOptionPrice    <->  /root/reference/src/models/AsymptoticAnalysisPricer.cpp:38-113
 //   MartingaleOptimization::PredictOptionPrice <-> /root/reference/src/models/MartingaleOptimizationPricer.cpp:21-189
+//   BranchingProcesses::PredictOptionPrice     <-> /root/reference/src/models/BranchingProcessPricer.cpp:12-134
 #include <atomic>
 #include <cmath>
 #include <cstdlib>
@@ -159,7 +160,51 @@ double MartingaleOptimization::PredictOptionPrice(const std::vector<std::vector<
     return price;
 }
 
+double BranchingProcesses::PredictOptionPrice(const std::vector<std::vector<double>>& pricePaths, double r,
+                                              double strike, double maturity, double dt, bool isCall, int numBranches,
+                                              const std::vector<int>& exerciseTimes) {
+    if (pricePaths.empty() || pricePaths[0].empty()) throw std::runtime_error("BranchingProcesses: Empty pricePaths.");
+    if (exerciseTimes.empty()) throw std::runtime_error("BranchingProcesses: No exercise times.");
+    if (strike <= 0.0) throw std::runtime_error("BranchingProcesses: Strike must be positive.");
+    const size_t N = pricePaths.size(), M = pricePaths[0].size();
+    std::vector<double> flat(N * M);
+    for (size_t i = 0; i < N; ++i) {
+        if (pricePaths[i].size() < M) throw std::runtime_error("BranchingProcesses: ragged pricePaths.");
+        std::copy(pricePaths[i].begin(), pricePaths[i].begin() + M, flat.begin() + i * M);
+    }
+    mcg_ctx* ctx = t_ctx.get();
+    PathsGuard g;
+    if (mcg_paths_from_host(ctx, flat.data(), (int64_t)N, (int)M, &g.p) != MCG_OK) raise_last();
+    double price = 0.0;
+    if (mcg_price_branching(ctx, g.p, r, strike, maturity, dt, isCall ? 1 : 0, numBranches, exerciseTimes.data(),
+                            (int)exerciseTimes.size(), next_seed(), &price, nullptr, nullptr) != MCG_OK)
+        raise_last();
+    return price;
+}
+
 extern "C" {
+
+int mcg_compat_branching_price(const double* row_major, int64_t n_paths, int n_cols, double r, double strike,
+                               double maturity, double dt, int is_call, int num_branches, const int* exercise_times,
+                               int n_exercise_times, double* price) {
+    try {
+        std::vector<std::vector<double>> m;
+        if (row_major && n_paths > 0 && n_cols > 0) {
+            m.resize((size_t)n_paths);
+            for (int64_t i = 0; i < n_paths; ++i) m[i].assign(row_major + i * n_cols, row_major + (i + 1) * n_cols);
+        }
+        std::vector<int> ex;
+        if (exercise_times && n_exercise_times > 0) ex.assign(exercise_times, exercise_times + n_exercise_times);
+        BranchingProcesses bp;
+        const double v = bp.PredictOptionPrice(m, r, strike, maturity, dt, is_call != 0, num_branches, ex);
+        if (price) *price = v;
+        return MCG_OK;
+    } catch (const std::exception& e) {
+        const std::string msg = e.what();
+        const int code = msg == "BranchingProcesses: Empty pricePaths." ? MCG_ERR_EMPTY_PATHS : MCG_ERR_INVALID;
+        return mcg::fail(code, "%s", msg.c_str());
+    }
+}
 
 int mcg_compat_martingale_price(const double* row_major, int64_t n_paths, int n_cols, double r, double strike,
                                 double maturity, double dt, int is_call, int poly_order, int max_iterations,

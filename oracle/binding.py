@@ -92,6 +92,9 @@ class Oracle:
         L.orc_martingale_price.argtypes = [_dp, C.c_size_t, C.c_size_t, C.c_long, C.c_int] + [C.c_double] * 4 + \
             [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp]
         L.orc_martingale_price.restype = C.c_int
+        L.orc_branching_price.argtypes = [_dp, C.c_size_t, C.c_size_t, C.c_long, C.c_int] + [C.c_double] * 4 + \
+            [C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_uint64, C.c_uint64, C.c_int, _dp]
+        L.orc_branching_price.restype = C.c_int
         L.orc_num_threads.restype = C.c_int
 
     # -- estimators / spectral ------------------------------------------------------------------
@@ -292,6 +295,29 @@ class Oracle:
             raise RuntimeError("orc_martingale_price failed rc=%d" % rc)
         return p.value, lo.value, up.value
 
+    def branching_price(self, paths, r, K, maturity, dt, is_call, num_branches, exercise_times, seed, mode="philox",
+                        path_begin=0, step_major=True):
+        """(price, lower, upper); mode "mt" = the reference's algorithm with an explicit seed, "philox" = device."""
+        a = np.ascontiguousarray(paths, dtype=np.float64)
+        if a.ndim != 2 or a.size == 0:
+            raise RuntimeError("BranchingProcesses: Empty pricePaths.")
+        if step_major:
+            n_cols, n_paths = a.shape
+            ps, ss = 1, n_paths
+        else:
+            n_paths, n_cols = a.shape
+            ps, ss = n_cols, 1
+        ex = np.ascontiguousarray(exercise_times, dtype=np.int32)
+        out = np.empty(3)
+        rc = self.L.orc_branching_price(_p(a), ps, ss, n_paths, n_cols, r, K, maturity, dt, int(bool(is_call)),
+                                        num_branches, ex.ctypes.data_as(C.POINTER(C.c_int)), len(ex), seed, path_begin,
+                                        0 if mode == "mt" else 1, _p(out))
+        msgs = {1: "BranchingProcesses: Empty pricePaths.", 2: "BranchingProcesses: No exercise times.",
+                3: "BranchingProcesses: Strike must be positive."}
+        if rc:
+            raise RuntimeError(msgs.get(rc, "orc_branching_price failed"))
+        return tuple(out)
+
     def num_threads(self):
         return int(self.L.orc_num_threads())
 
@@ -320,6 +346,10 @@ class Reference:
         L.ref_generate_paths.restype = C.c_int
         L.ref_generate_paths_omp.argtypes = [_dp, C.c_size_t, C.c_int, C.c_long, C.c_int, _dp]
         L.ref_generate_paths_omp.restype = C.c_int
+        if hasattr(L, "ref_branching_price"):
+            L.ref_branching_price.argtypes = [_dp, C.c_long, C.c_int] + [C.c_double] * 4 + [C.c_int, C.c_int, C.POINTER(C.c_int),
+                                                                                   C.c_int, _dp, C.c_char_p, C.c_size_t]
+            L.ref_branching_price.restype = C.c_int
         if hasattr(L, "ref_asymptotic_price"):
             L.ref_asymptotic_price.argtypes = [_dp, C.c_long, C.c_int] + [C.c_double] * 4 + [C.c_int, C.c_double, C.c_double,
                                                                                     _dp, C.c_char_p, C.c_size_t]
@@ -392,6 +422,19 @@ class Reference:
         if rc:
             raise RuntimeError(err.value.decode())
         return price.value
+
+    def branching_price(self, row_major, r, K, maturity, dt, is_call, num_branches, exercise_times):
+        """(price, lower, upper) from the compiled reference (upper bound unseeded)."""
+        a = np.ascontiguousarray(row_major, dtype=np.float64)
+        n, m = (a.shape if a.ndim == 2 else (0, 0))
+        ex = np.ascontiguousarray(exercise_times, dtype=np.int32)
+        out = np.empty(3)
+        err = C.create_string_buffer(256)
+        rc = self.L.ref_branching_price(_p(a) if a.size else None, n, m, r, K, maturity, dt, int(bool(is_call)),
+                                        num_branches, ex.ctypes.data_as(C.POINTER(C.c_int)), len(ex), _p(out), err, 256)
+        if rc:
+            raise RuntimeError(err.value.decode())
+        return tuple(out)
 
     def generate_paths_omp(self, hist, steps, total_paths, chunk):
         h = np.ascontiguousarray(hist, dtype=np.float64)

@@ -106,6 +106,15 @@ def main() -> None:
                       ref.asymptotic_price(m, 0.04, K, maturity, dt, bool(is_call), sigma, div)])
     asy["cases"] = np.array(cases)
     np.savez(os.path.join(OUT, "asymptotic.npz"), **asy)
+    # (8) BranchingProcesses lower bound (src/models/BranchingProcessPricer.cpp:41-72) -- deterministic; the upper
+    # bound resamples with an unseeded generator and is compared statistically in the tests instead.
+    br = []
+    ex_all = np.arange(40, dtype=np.int32)                  # the driver's 0..steps-1 (PredictionGen.cpp:780-783)
+    for is_call, maturity, K, ex in [(0, 40 / 252.0, 100.0, ex_all), (1, 40 / 252.0, 100.0, ex_all),
+                                     (0, 20.5 / 252.0, 103.0, ex_all), (0, 40 / 252.0, 100.0, ex_all[::5])]:
+        _, lo, _ = ref.branching_price(base, 0.04, K, maturity, 1 / 252.0, bool(is_call), 10, ex)
+        br.append([is_call, maturity, K, len(ex), lo])
+    np.savez(os.path.join(OUT, "branching.npz"), cases=np.array(br), ex_all=ex_all)
     print("golden fixtures written to", OUT)
     for f in sorted(os.listdir(OUT)):
         print("  ", f, os.path.getsize(os.path.join(OUT, f)), "bytes")

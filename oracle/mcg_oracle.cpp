@@ -806,6 +806,127 @@ int orc_martingale_price(const double* paths, size_t path_stride, size_t step_st
     return 0;
 }
 
+// BranchingProcesses::PredictOptionPrice (src/models/BranchingProcessPricer.cpp:12-134).
+//   mode 0 ("mt"): statement for statement, the unseeded std::random_device seed (:83-84) replaced by `seed`;
+//                  one generator, consumed in (path, date, branch) order like the reference's serial loop.
+//   mode 1 ("philox"): the device algorithm -- suffix-maximum matrix F[j][p] = max_{k>=j, t_k<=T} e^{-r t_k} pay,
+//                  continuation = mean_b F[t+1][rp_b], rp_b = mulhi(word, N) of Philox stream 2, counter
+//                  (path, date_index * ceil(B/4) + b/4) -- draw for draw.
+// out3 = {price, lower, upper}.  Returns 0; 1 empty paths; 2 no exercise times; 3 strike <= 0 (the reference
+// throws "BranchingProcesses: Empty pricePaths." / "No exercise times." / "Strike must be positive.").
+int orc_branching_price(const double* paths, size_t path_stride, size_t step_stride, long n_paths, int n_cols, double r,
+                        double K, double maturity, double dt, int is_call, int num_branches, const int* ex, int n_ex,
+                        uint64_t seed, uint64_t path_begin, int mode, double* out3) {
+    if (n_paths < 1 || n_cols < 1) return 1;
+    if (n_ex < 1) return 2;
+    if (K <= 0.0) return 3;
+    const bool call = is_call != 0;
+    const long N = n_paths;
+    const int M = n_cols;
+    auto S = [&](long i, int j) { return paths[(size_t)i * path_stride + (size_t)j * step_stride]; };
+    // lower bound :41-72
+    double sum_lo = 0.0;
+    for (long i = 0; i < N; ++i) {
+        double best = 0.0;
+        for (int e = 0; e < n_ex; ++e) {
+            const double t = ex[e] * dt;
+            if (t > maturity) break;
+            const double d = std::exp(-r * t) * payoff_of(call, S(i, ex[e]), K);
+            if (d > best) {
+                best = d;
+                break;
+            }
+        }
+        sum_lo += best;
+    }
+    double sum_up = 0.0;
+    if (mode == 0) {  // :74-134
+        std::mt19937 gen((uint32_t)(seed ^ (seed >> 32)));
+        std::uniform_int_distribution<> pathDist(0, (int)N - 1);
+        for (long i = 0; i < N; ++i) {
+            double best = 0.0;
+            for (int e = 0; e < n_ex; ++e) {
+                const int tI = ex[e];
+                const double t = tI * dt;
+                if (t > maturity) break;
+                const double now = std::exp(-r * t) * payoff_of(call, S(i, tI), K);
+                double cont = 0.0;
+                if (tI < ex[n_ex - 1]) {
+                    double sumF = 0.0;
+                    for (int b = 0; b < num_branches; ++b) {
+                        const int rp = pathDist(gen);
+                        double bf = 0.0;
+                        for (int k = tI + 1; k < M; ++k) {
+                            const double tk = k * dt;
+                            if (tk > maturity) break;
+                            const double d = std::exp(-r * (tk - t)) * payoff_of(call, S(rp, k), K);
+                            if (d > bf) bf = d;
+                        }
+                        sumF += bf;
+                    }
+                    cont = (sumF / num_branches) * std::exp(-r * t);
+                }
+                const double better = std::max(now, cont);
+                if (better > best) best = better;
+            }
+            sum_up += best;
+        }
+    } else {
+        std::vector<double> disc(M), F((size_t)M * N);
+        int n_dates = 0;
+        for (int j = 0; j < M; ++j) {
+            const double t = j * dt;
+            if (!(t > maturity) && n_dates == j) n_dates = j + 1;
+            disc[j] = std::exp(-r * t);
+        }
+        for (long p = 0; p < N; ++p) {
+            double run = 0.0;
+            for (int j = M - 1; j >= 0; --j) {
+                if (j < n_dates) {
+                    const double d = disc[j] * payoff_of(call, S(p, j), K);
+                    if (d > run) run = d;
+                }
+                F[(size_t)j * N + p] = run;
+            }
+        }
+        const int quads = (num_branches + 3) >> 2;
+        const double inv_b = num_branches > 0 ? 1.0 / (double)num_branches : 0.0;
+        const uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+        for (long p = 0; p < N; ++p) {
+            const uint64_t id = path_begin + (uint64_t)p;
+            double upper = 0.0;
+            int e_idx = 0;
+            for (int e = 0; e < n_ex; ++e, ++e_idx) {
+                const int tI = ex[e];
+                if (tI * dt > maturity) break;
+                const double now = disc[tI] * payoff_of(call, S(p, tI), K);
+                double better = now;
+                if (tI < ex[n_ex - 1] && num_branches > 0) {
+                    double sum = 0.0;
+                    for (int q = 0; q < quads; ++q) {
+                        const uint32_t ctr[4] = {(uint32_t)id, (uint32_t)(id >> 32), (uint32_t)(e_idx * quads + q), 2u};
+                        uint32_t w[4];
+                        philox4x32_10(ctr, key, w);
+                        for (int s2 = 0; s2 < 4; ++s2)
+                            if (4 * q + s2 < num_branches) {
+                                const uint32_t rp = (uint32_t)(((uint64_t)w[s2] * (uint64_t)(uint32_t)N) >> 32);
+                                sum += F[(size_t)(tI + 1) * N + rp];
+                            }
+                    }
+                    const double cont = sum * inv_b;
+                    if (cont > better) better = cont;
+                }
+                if (better > upper) upper = better;
+            }
+            sum_up += upper;
+        }
+    }
+    out3[1] = sum_lo / N;
+    out3[2] = sum_up / N;
+    out3[0] = 0.5 * (out3[1] + out3[2]);
+    return 0;
+}
+
 int orc_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

@@ -26,6 +26,9 @@
 #undef private
 #include "core/common.h"
 #include "models/AsymptoticAnalysisPricer.h"
+#define private public
+#include "models/BranchingProcessPricer.h"
+#undef private
 
 namespace {
 using cvec = std::vector<std::complex<double>>;
@@ -164,6 +167,40 @@ int ref_asymptotic_price(const double* row_major, long n, int m, double r, doubl
         for (long i = 0; i < n; ++i) paths[i].assign(row_major + (size_t)i * m, row_major + (size_t)(i + 1) * m);
         AsymptoticAnalysis aa;
         *price = aa.PredictOptionPrice(paths, r, strike, maturity, dt, is_call != 0, sigma, dividend);
+        return 0;
+    } catch (const std::exception& e) {
+        if (err && errlen) {
+            std::strncpy(err, e.what(), errlen - 1);
+            err[errlen - 1] = 0;
+        }
+        return 1;
+    }
+}
+
+// BranchingProcesses (src/models/BranchingProcessPricer.cpp:12-134) on a row-major [n][m] matrix.
+// out3 = {price, lower bound, upper bound}; the upper bound resamples with an UNSEEDED mt19937 (:83-85).
+// The bounds are private members, reached like RoughVolatility's helpers.  Returns 1 on a throw.
+int ref_branching_price(const double* row_major, long n, int m, double r, double strike, double maturity, double dt,
+                        int is_call, int num_branches, const int* ex, int n_ex, double* out3, char* err, size_t errlen) {
+    try {
+        std::vector<std::vector<double>> paths((size_t)std::max<long>(n, 0));
+        for (long i = 0; i < n; ++i) paths[i].assign(row_major + (size_t)i * m, row_major + (size_t)(i + 1) * m);
+        std::vector<int> times(ex, ex + std::max(n_ex, 0));
+        BranchingProcesses bp;
+#ifdef _OPENMP
+        // In the reference's driver the pricers run inside an outer `omp parallel` (PredictionGen.cpp:542), so
+        // their own `omp parallel for` loops are nested regions and execute on ONE thread.  Called from a
+        // serial context they would share one mt19937 between threads (:83-93, a data race that biases the
+        // upper bound: 14.30 vs 14.05 on the fixture).  Reproduce the driver's conditions.
+        const int saved_threads = omp_get_max_threads();
+        omp_set_num_threads(1);
+#endif
+        out3[0] = bp.PredictOptionPrice(paths, r, strike, maturity, dt, is_call != 0, num_branches, times);
+        out3[1] = bp.ComputeLowerBound(paths, r, strike, dt, is_call != 0, times);   // maturity_ was set by the call above
+        out3[2] = bp.ComputeUpperBound(paths, r, strike, dt, is_call != 0, num_branches, times);
+#ifdef _OPENMP
+        omp_set_num_threads(saved_threads);
+#endif
         return 0;
     } catch (const std::exception& e) {
         if (err && errlen) {

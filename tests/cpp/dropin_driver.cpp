@@ -14,6 +14,7 @@
 
 #include "core/common.h"
 #include "models/AsymptoticAnalysisPricer.h"
+#include "models/BranchingProcessPricer.h"
 #include "models/LSMPricer.h"
 #include "models/MartingaleOptimizationPricer.h"
 #include "models/RoughVolatility.h"
@@ -37,6 +38,7 @@ int main(int argc, char** argv) {
         LSM lsm;                  // per row, per thread (PredictionGen.cpp:566-570)
         AsymptoticAnalysis aa;
         MartingaleOptimization mo;
+        BranchingProcesses bp;
         RoughVolatility roughVol;
         try {
             const int steps = 10 + 5 * (row % 7);
@@ -51,6 +53,10 @@ int main(int argc, char** argv) {
             const double asym = aa.PredictOptionPrice(paths, r, strike, maturity, dt, false, 0.2, 0.08);   // :788
             if (!(asym >= 0.0) || !(asym < strike)) throw std::runtime_error("asymptotic price out of range");
             const double mart = mo.PredictOptionPrice(paths, r, strike, maturity, dt, false, 2);            // :791
+            std::vector<int> exerciseTimes(steps);                                                          // :780-783
+            for (int i = 0; i < steps; ++i) exerciseTimes[i] = i;
+            const double branch = bp.PredictOptionPrice(paths, r, strike, maturity, dt, false, 10, exerciseTimes);   // :789
+            if (!(branch >= 0.0) || !(branch < strike)) throw std::runtime_error("branching price out of range");
             if (!(mart >= 0.0) || !(mart < strike)) throw std::runtime_error("martingale price out of range");
             double eu = 0.0;
             for (auto& p : paths) eu += PayoffFunction(false, p.back(), strike);

@@ -438,3 +438,37 @@ def test_martingale_class_api_and_errors(orc):
         mo.PredictOptionPrice(np.zeros((0, 0)), 0.04, K, 1.0, DT, False, 2)
     with pytest.raises(mc.McgError, match="MartingaleOptimization: maxIterations must be positive."):
         mo.PredictOptionPrice(paths, 0.04, K, 1.0, DT, False, 2, 0)
+
+
+# ------------------------------------------------------------------------------------------------
+# BranchingProcesses
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("is_call,branches,stride", [(False, 10, 1), (True, 10, 1), (False, 3, 1), (False, 7, 4), (False, 0, 1)])
+def test_branching_matches_oracle_philox_mode(eng, orc, is_call, branches, stride):
+    steps = 40
+    P = eng.gbm(SEED, 100.0, 0.04, 0.2, DT, steps, 5000, path_begin=11)
+    host = P.to_host_step_major()
+    ex = np.arange(0, steps, stride, dtype=np.int32)          # the driver passes 0..steps-1
+    for maturity in (steps * DT, 22.5 * DT):
+        got = eng.price_branching(P, 0.04, 100.0, maturity, DT, is_call, branches, ex, seed=99)
+        want = orc.branching_price(host, 0.04, 100.0, maturity, DT, is_call, branches, ex, 99, mode="philox", path_begin=11)
+        assert np.allclose(got, want, rtol=1e-12, atol=1e-14), (got, want)
+        assert got[1] <= got[2] + 1e-12 and abs(got[0] - 0.5 * (got[1] + got[2])) < 1e-13
+    P.free()
+
+
+def test_branching_class_api_and_errors(orc):
+    hist = synthetic_history(300, seed=1)
+    mc.set_compat_seed(5)
+    paths = mc.RoughVolatility().GenerateStockPricePaths(hist, 40, 250)
+    K = float(hist[-1])
+    ex = list(range(40))                                       # PredictionGen.cpp:780-783
+    bp = mc.BranchingProcesses()
+    got = bp.PredictOptionPrice(paths, 0.04, K, 40 / 365.0, DT, False, 10, ex)      # :789
+    want = orc.branching_price(paths, 0.04, K, 40 / 365.0, DT, False, 10, ex, 5, mode="philox", step_major=False)[0]
+    assert abs(got - want) <= 1e-12 * abs(want)
+    mc.set_compat_seed(None)
+    for bad, msg in [((np.zeros((0, 0)), K, ex), "Empty pricePaths."), ((paths, K, []), "No exercise times."),
+                     ((paths, 0.0, ex), "Strike must be positive.")]:
+        with pytest.raises(mc.McgError, match="BranchingProcesses: " + msg):
+            bp.PredictOptionPrice(bad[0], 0.04, bad[1], 1.0, DT, False, 10, bad[2])

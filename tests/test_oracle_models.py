@@ -101,18 +101,25 @@ def test_volterra_kernel_reproduces_reference_covariance(orc, steps, H, eta):
 
 
 def test_volterra_sample_covariance_vs_reference_transform(orc):
-    """Sampled X from the device algorithm vs X from the reference's own transform on mt noise."""
-    steps, H, eta, n = 64, 0.1, 1.9, 4000
+    """Sampled X from the device algorithm AND X from the reference's own transform on Gaussian noise both
+    reproduce the closed-form covariance (each within 4 standard errors of the estimator)."""
+    steps, H, eta, n = 64, 0.1, 1.9, 6000
     _, X = orc.paths_rbergomi(3, 100.0, 0.04, 0.04, H, eta, -0.9, DT, steps, 0, n, want_X=True)
     phi = orc.phi(orc.lam(steps, H))
     rs = np.random.RandomState(1)
     Xr = np.array([orc.fractional_gaussian(phi, rs.standard_normal(steps) + 1j * rs.standard_normal(steps), H, eta)
                    for _ in range(n)])
+    M = orc.next_pow2(steps)
+    P = np.zeros(M)
+    P[:steps] = np.abs(phi[:steps]) ** 2
+    k = np.arange(M)
+    cov = lambda d: (2 * H * eta ** 2 / M ** 2) * (P * np.cos(2 * np.pi * k * d / M)).sum()  # noqa: E731
     for lag in (0, 1, 5, 31):
-        a = (X[:, 10] * X[:, (10 + lag) % steps]).mean()
-        b = (Xr[:, 10] * Xr[:, (10 + lag) % steps]).mean()
-        tol = 5 * Xr[:, 10].var() / math.sqrt(n)
-        assert abs(a - b) < tol, (lag, a, b)
+        c0, cd = cov(0), cov(lag)
+        se = math.sqrt((c0 * c0 + cd * cd) / n)
+        for sample in (X, Xr):
+            est = (sample[:, 10] * sample[:, (10 + lag) % steps]).mean()
+            assert abs(est - cd) <= 4 * se, (lag, est, cd, se)
 
 
 def test_rbergomi_oracle_martingale(orc):
@@ -262,3 +269,45 @@ def test_martingale_oracle_vs_lapack(orc, is_call, poly, iters):
         orc.martingale_price(np.zeros((0, 0)), 0.04, 100.0, 1.0, DT, False, 2)
     with pytest.raises(RuntimeError, match="MartingaleOptimization: maxIterations must be positive."):
         orc.martingale_price(P, 0.04, 100.0, 1.0, DT, False, 2, 0, step_major=False)
+
+
+# ---- BranchingProcesses ------------------------------------------------------------------------
+def _branching_fixture():
+    import os
+    g = os.path.join(os.path.dirname(__file__), "golden")
+    return np.load(os.path.join(g, "asymptotic.npz"))["paths"], np.load(os.path.join(g, "branching.npz"))
+
+
+def test_branching_lower_bound_matches_compiled_reference(orc):
+    """The deterministic half (BranchingProcessPricer.cpp:41-72) against values captured from the compiled
+    reference (its OpenMP reduction fixes no summation order: 1e-13, not bit-exact)."""
+    paths, d = _branching_fixture()
+    ex_all = d["ex_all"]
+    for is_call, maturity, K, n_ex, want in d["cases"]:
+        ex = ex_all if int(n_ex) == len(ex_all) else ex_all[::5]
+        for mode in ("mt", "philox"):
+            _, lo, up = orc.branching_price(paths, 0.04, K, maturity, 1 / 252.0, bool(is_call), 10, ex, 7, mode=mode,
+                                            step_major=False)
+            assert abs(lo - want) <= 1e-13 * max(want, 1e-300), (mode, lo, want)
+            assert up >= lo - 1e-12
+    for bad, msg in [((np.zeros((0, 0)), 100.0, ex_all), "Empty pricePaths."), ((paths, 100.0, []), "No exercise times."),
+                     ((paths, 0.0, ex_all), "Strike must be positive.")]:
+        with pytest.raises(RuntimeError, match="BranchingProcesses: " + msg):
+            orc.branching_price(bad[0], 0.04, bad[1], 1.0, 1 / 252.0, False, 10, bad[2], 1, step_major=False)
+
+
+@pytest.mark.skipif(not have_ref(), reason="compiled reference not present")
+def test_branching_upper_bound_statistics(orc):
+    """Upper bound: unseeded resampling in the reference, so compare the mean over repeated calls --
+    compiled reference vs oracle "mt" (same algorithm, explicit seed) vs oracle "philox" (device algorithm)."""
+    ref = Reference()
+    paths, d = _branching_fixture()
+    ex = d["ex_all"]
+    args = (0.04, 100.0, 40 / 252.0, 1 / 252.0, False, 10, ex)
+    a = np.array([ref.branching_price(paths, *args)[2] for _ in range(24)])
+    b = np.array([orc.branching_price(paths, *args, s, mode="mt", step_major=False)[2] for s in range(24)])
+    c = np.array([orc.branching_price(paths, *args, s, mode="philox", step_major=False)[2] for s in range(24)])
+    for x in (b, c):
+        se = math.sqrt(a.var(ddof=1) / len(a) + x.var(ddof=1) / len(x))
+        assert abs(a.mean() - x.mean()) <= 4 * se, (a.mean(), x.mean(), se)
+    assert 0.5 < b.std(ddof=1) / c.std(ddof=1) < 2.0
