@@ -219,6 +219,114 @@ __global__ __launch_bounds__(256) void k_lsm_reduce_solve(const double* partials
     if (do_solve && threadIdx.x == 0) lsm_solve_one(do_reduce ? sm : moments, nb, min_count, coef);
 }
 
+// The whole backward sweep in ONE launch for a small path count (n <= 1024: the reference's production
+// calls price 250 paths per option row, src/core/PredictionGen.cpp:719): one 256-thread block, up to four
+// paths per thread with V in registers, per date a block reduction of the regression moments, the solve on
+// thread 0, the coefficients handed over through LDS (PPT = paths per thread: 1 up to 256 paths, else 4).  Same arithmetic as k_lsm_sweep / lsm_solve_one;
+// only the summation order of the moments differs.  out3 = {sum V, sum V^2, n}.
+template <int NB, int PPT>
+__global__ __launch_bounds__(256) void k_lsm_small(const double* data, int64_t ld, int n, int n_cols, double r_unused,
+                                                   double K, double maturity, double dt, double disc, int is_call,
+                                                   double* out3) {
+    constexpr int NM = 3 * NB - 1;
+    __shared__ double red[NM * 4];
+    __shared__ double sm_mom[32];
+    __shared__ double sm_coef[16];
+    const bool call = is_call != 0;
+    const double invK = 1.0 / K;
+    double V[PPT];
+#pragma unroll
+    for (int q = 0; q < PPT; ++q) {
+        const int p = threadIdx.x + 256 * q;
+        V[q] = p < n ? payoff_of(call, data[(int64_t)(n_cols - 1) * ld + p], K) : 0.0;
+    }
+    for (int j = n_cols - 2; j >= 0; --j) {
+        const double this_time = j * dt;
+        if (this_time > maturity) {  // LSMPricer.cpp:43-49 (wave-uniform)
+#pragma unroll
+            for (int q = 0; q < PPT; ++q) V[q] = V[q] * disc;
+            continue;
+        }
+        const double* row = data + (int64_t)j * ld;
+        double s_j[PPT], pay_j[PPT];
+        double m[NM];
+#pragma unroll
+        for (int q = 0; q < NM; ++q) m[q] = 0.0;
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            const int p = threadIdx.x + 256 * q;
+            s_j[q] = p < n ? row[p] : 0.0;
+            pay_j[q] = payoff_of(call, s_j[q], K);
+            if (p < n && pay_j[q] > 1e-14) {
+                const double x = fma(s_j[q], invK, -1.0);
+                const double y = V[q] * disc;
+                double pw = 1.0;
+#pragma unroll
+                for (int t = 0; t < 2 * NB - 1; ++t) {
+                    m[t] += pw;
+                    if (t < NB) m[2 * NB - 1 + t] = fma(pw, y, m[2 * NB - 1 + t]);
+                    pw *= x;
+                }
+            }
+        }
+        block_sum<NM, 4>(m, red);
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int t = 0; t < NM; ++t) sm_mom[t] = m[t];
+            lsm_solve_one(sm_mom, NB, 1.0, sm_coef);  // writes sm_coef[0..9], [9] = ITM count
+        }
+        __syncthreads();
+        double c[NB];
+#pragma unroll
+        for (int t = 0; t < NB; ++t) c[t] = sm_coef[t];
+        const double n_itm = sm_coef[9];
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            const double vn = V[q] * disc;
+            double v;
+            if (pay_j[q] > 1e-14 && n_itm > 0.0) {
+                const double x = fma(s_j[q], invK, -1.0);
+                double cont = c[NB - 1];
+#pragma unroll
+                for (int t = NB - 2; t >= 0; --t) cont = fma(cont, x, c[t]);
+                v = fmax(pay_j[q], cont);
+            } else if (pay_j[q] < 1e-14) {
+                v = vn;
+            } else {
+                v = 0.0;
+            }
+            V[q] = v;
+        }
+        __syncthreads();  // sm_coef / red are rewritten on the next date
+    }
+    double f[2] = {0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < PPT; ++q) {
+        if (threadIdx.x + 256 * q < n) {
+            f[0] += V[q];
+            f[1] += V[q] * V[q];
+        }
+    }
+    __shared__ double red2[2 * 4];
+    block_sum<2, 4>(f, red2);
+    if (threadIdx.x == 0) {
+        out3[0] = f[0];
+        out3[1] = f[1];
+        out3[2] = (double)n;
+    }
+}
+
+template <int NB>
+static void launch_small_nb(mcg_ctx* ctx, const mcg_paths* P, double K, double maturity, double dt, double disc,
+                            int is_call, double* out3) {
+    if (P->n_paths <= 256)  // the production shape (250 paths): one path per thread
+        hipLaunchKernelGGL((k_lsm_small<NB, 1>), dim3(1), dim3(256), 0, ctx->stream, P->data, P->ld, (int)P->n_paths,
+                           P->n_steps + 1, 0.0, K, maturity, dt, disc, is_call, out3);
+    else
+        hipLaunchKernelGGL((k_lsm_small<NB, 4>), dim3(1), dim3(256), 0, ctx->stream, P->data, P->ld, (int)P->n_paths,
+                           P->n_steps + 1, 0.0, K, maturity, dt, disc, is_call, out3);
+}
+
 // sum V, sum V^2 -> partials[grid][2]
 __global__ __launch_bounds__(256) void k_lsm_final(const double* V, int64_t n, double* partials) {
     __shared__ double red[2 * 4];
@@ -289,6 +397,34 @@ int run_lsm(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double maturit
     int grid = (int)std::min<int64_t>((N + 255) / 256, (int64_t)ctx->n_cus * 8);
     if (grid < 1) grid = 1;
 
+    if (N >= 1 && N <= 1024 && !ctx->allreduce) {  // one launch for the whole sweep
+        const double disc_s = std::exp(-r * dt);
+        double* d3 = ctx->scalars + SC_SUMS;
+        {
+            TimedLaunch t(ctx, MCG_K_LSM_SWEEP);
+            switch (nb) {
+                case 1: launch_small_nb<1>(ctx, P, K, maturity, dt, disc_s, is_call, d3); break;
+                case 2: launch_small_nb<2>(ctx, P, K, maturity, dt, disc_s, is_call, d3); break;
+                case 3: launch_small_nb<3>(ctx, P, K, maturity, dt, disc_s, is_call, d3); break;
+                case 4: launch_small_nb<4>(ctx, P, K, maturity, dt, disc_s, is_call, d3); break;
+                case 5: launch_small_nb<5>(ctx, P, K, maturity, dt, disc_s, is_call, d3); break;
+                case 6: launch_small_nb<6>(ctx, P, K, maturity, dt, disc_s, is_call, d3); break;
+                case 7: launch_small_nb<7>(ctx, P, K, maturity, dt, disc_s, is_call, d3); break;
+                case 8: launch_small_nb<8>(ctx, P, K, maturity, dt, disc_s, is_call, d3); break;
+                default: launch_small_nb<9>(ctx, P, K, maturity, dt, disc_s, is_call, d3); break;
+            }
+        }
+        MCG_HIP(hipGetLastError());
+        MCG_HIP(hipMemcpyAsync(ctx->h_scalars + SC_SUMS, d3, 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        MCG_HIP(hipStreamSynchronize(ctx->stream));
+        const double n = ctx->h_scalars[SC_SUMS + 2], m = ctx->h_scalars[SC_SUMS] / n;
+        *mean = m;
+        if (std_err) {
+            const double var = n > 1.0 ? std::max(0.0, (ctx->h_scalars[SC_SUMS + 1] - n * m * m) / (n - 1.0)) : 0.0;
+            *std_err = std::sqrt(var / n);
+        }
+        return MCG_OK;
+    }
     int rc = ensure_cap(ctx, &ctx->lsm_v, &ctx->lsm_v_cap, (size_t)std::max<int64_t>(N, 1));
     if (rc) return rc;
     rc = ensure_cap(ctx, &ctx->partials, &ctx->partials_cap, (size_t)grid * (size_t)std::max(nm, 2));

@@ -9,6 +9,7 @@
 #include <atomic>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <limits>
 #include <random>
 #include <stdexcept>
@@ -24,8 +25,23 @@ namespace {
 // re-entrant.  The holder tears the ctx down when the thread exits.
 struct ThreadCtx {
     mcg_ctx* ctx = nullptr;
+    // The reference's driver hands the SAME host matrix to four pricers in a row (PredictionGen.cpp:788-791).
+    // The last matrix this thread generated or uploaded stays on the device, keyed by shape and a checksum of
+    // every element, so the second to fourth pricer (and the first, right after GenerateStockPricePaths) skip
+    // the upload + transpose.
+    mcg_paths* cached = nullptr;
+    size_t cached_n = 0, cached_m = 0;
+    uint64_t cached_sum = 0;
     ~ThreadCtx() {
+        if (cached) mcg_paths_free(cached);
         if (ctx) mcg_finalize(ctx);
+    }
+    void remember(mcg_paths* p, size_t n, size_t m, uint64_t sum) {
+        if (cached && cached != p) mcg_paths_free(cached);
+        cached = p;
+        cached_n = n;
+        cached_m = m;
+        cached_sum = sum;
     }
     mcg_ctx* get() {
         if (!ctx) {
@@ -48,12 +64,49 @@ uint64_t next_seed() {
     return ((uint64_t)rd() << 32) | rd();
 }
 
+[[noreturn]] void raise_last() { throw std::runtime_error(mcg_last_error()); }
+
 struct PathsGuard {
     mcg_paths* p = nullptr;
     ~PathsGuard() { mcg_paths_free(p); }
+    mcg_paths* release() {
+        mcg_paths* q = p;
+        p = nullptr;
+        return q;
+    }
 };
 
-[[noreturn]] void raise_last() { throw std::runtime_error(mcg_last_error()); }
+// 64-bit mix of every element's bit pattern (order-sensitive), ~10 GB/s on one core
+uint64_t checksum_rows(const std::vector<std::vector<double>>& rows, size_t m) {
+    uint64_t h = 0x9E3779B97F4A7C15ull ^ (rows.size() * 0x100000001B3ull) ^ m;
+    for (const auto& row : rows) {
+        const double* d = row.data();
+        for (size_t j = 0; j < m; ++j) {
+            uint64_t w;
+            std::memcpy(&w, d + j, sizeof w);
+            h = (h ^ w) * 0x100000001B3ull;
+            h ^= h >> 29;
+        }
+    }
+    return h;
+}
+
+// Device copy of a host path matrix: the thread's cached one when shape and checksum match, otherwise a fresh
+// upload (which becomes the cached one).  `what` prefixes the ragged-row error message.
+mcg_paths* device_matrix(const std::vector<std::vector<double>>& pricePaths, const char* ragged_msg) {
+    const size_t N = pricePaths.size(), M = pricePaths[0].size();
+    for (const auto& row : pricePaths)
+        if (row.size() < M) throw std::runtime_error(ragged_msg);
+    const uint64_t sum = checksum_rows(pricePaths, M);
+    mcg_ctx* ctx = t_ctx.get();
+    if (t_ctx.cached && t_ctx.cached_n == N && t_ctx.cached_m == M && t_ctx.cached_sum == sum) return t_ctx.cached;
+    std::vector<double> flat(N * M);
+    for (size_t i = 0; i < N; ++i) std::copy(pricePaths[i].begin(), pricePaths[i].begin() + M, flat.begin() + i * M);
+    PathsGuard g;
+    if (mcg_paths_from_host(ctx, flat.data(), (int64_t)N, (int)M, &g.p) != MCG_OK) raise_last();
+    t_ctx.remember(g.p, N, M, sum);
+    return g.release();
+}
 
 }  // namespace
 
@@ -91,6 +144,7 @@ std::vector<std::vector<double>> RoughVolatility::GenerateStockPricePaths(
     if (mcg_paths_to_host(g.p, flat.data()) != MCG_OK) raise_last();
     const size_t cols = (size_t)forward_steps + 1;
     for (size_t i = 0; i < (size_t)path_num; ++i) paths[i].assign(flat.begin() + i * cols, flat.begin() + (i + 1) * cols);
+    t_ctx.remember(g.release(), (size_t)path_num, cols, checksum_rows(paths, cols));  // the pricers come next
     return paths;
 }
 
@@ -99,17 +153,9 @@ double LSM::PredictOptionPrice(const std::vector<std::vector<double>>& pricePath
     if (pricePaths.empty() || pricePaths[0].empty())
         throw std::runtime_error("LSM::PredictOptionPrice: Empty pricePaths.");
     if (polyOrder < 0 || polyOrder > 8) throw std::invalid_argument("LSM: polyOrder must be in [0, 8]");
-    const size_t N = pricePaths.size(), M = pricePaths[0].size();
-    std::vector<double> flat(N * M);
-    for (size_t i = 0; i < N; ++i) {
-        if (pricePaths[i].size() < M) throw std::runtime_error("LSM: Invalid path index in regression");
-        std::copy(pricePaths[i].begin(), pricePaths[i].begin() + M, flat.begin() + i * M);
-    }
-    mcg_ctx* ctx = t_ctx.get();
-    PathsGuard g;
-    if (mcg_paths_from_host(ctx, flat.data(), (int64_t)N, (int)M, &g.p) != MCG_OK) raise_last();
+    mcg_paths* P = device_matrix(pricePaths, "LSM: Invalid path index in regression");
     double price = 0.0;
-    if (mcg_price_lsm(ctx, g.p, r, strike, maturity, dt, isCall ? 1 : 0, polyOrder, &price, nullptr) != MCG_OK)
+    if (mcg_price_lsm(t_ctx.get(), P, r, strike, maturity, dt, isCall ? 1 : 0, polyOrder, &price, nullptr) != MCG_OK)
         raise_last();
     return price;
 }
@@ -119,17 +165,13 @@ double AsymptoticAnalysis::PredictOptionPrice(const std::vector<std::vector<doub
                                               double dividend) {
     if (pricePaths.empty() || pricePaths[0].empty()) return 0.0;                     // :47-49
     if (sigma <= 0.0) throw std::runtime_error("AsymptoticAnalysis: Volatility must be positive.");  // :50-52
-    const size_t N = pricePaths.size(), M = pricePaths[0].size();
+    const size_t M = pricePaths[0].size();
     for (const auto& row : pricePaths)
         if (row.size() != M) return 0.0;                                               // :57-61
     try {
-        std::vector<double> flat(N * M);
-        for (size_t i = 0; i < N; ++i) std::copy(pricePaths[i].begin(), pricePaths[i].end(), flat.begin() + i * M);
-        mcg_ctx* ctx = t_ctx.get();
-        PathsGuard g;
-        if (mcg_paths_from_host(ctx, flat.data(), (int64_t)N, (int)M, &g.p) != MCG_OK) raise_last();
+        mcg_paths* P = device_matrix(pricePaths, "AsymptoticAnalysis: ragged pricePaths.");
         double price = 0.0;
-        if (mcg_price_asymptotic(ctx, g.p, r, strike, maturity, dt, isCall ? 1 : 0, sigma, dividend, &price) != MCG_OK)
+        if (mcg_price_asymptotic(t_ctx.get(), P, r, strike, maturity, dt, isCall ? 1 : 0, sigma, dividend, &price) != MCG_OK)
             raise_last();
         return price;
     } catch (const std::bad_alloc&) {
@@ -144,17 +186,9 @@ double MartingaleOptimization::PredictOptionPrice(const std::vector<std::vector<
         throw std::runtime_error("MartingaleOptimization: Empty pricePaths.");                      // :31-33
     if (maxIterations <= 0) throw std::runtime_error("MartingaleOptimization: maxIterations must be positive.");  // :34-36
     if (polyOrder < 0 || polyOrder > 8) throw std::invalid_argument("MartingaleOptimization: polyOrder must be in [0, 8]");
-    const size_t N = pricePaths.size(), M = pricePaths[0].size();
-    std::vector<double> flat(N * M);
-    for (size_t i = 0; i < N; ++i) {
-        if (pricePaths[i].size() < M) throw std::runtime_error("MartingaleOptimization: ragged pricePaths.");
-        std::copy(pricePaths[i].begin(), pricePaths[i].begin() + M, flat.begin() + i * M);
-    }
-    mcg_ctx* ctx = t_ctx.get();
-    PathsGuard g;
-    if (mcg_paths_from_host(ctx, flat.data(), (int64_t)N, (int)M, &g.p) != MCG_OK) raise_last();
+    mcg_paths* P = device_matrix(pricePaths, "MartingaleOptimization: ragged pricePaths.");
     double price = 0.0;
-    if (mcg_price_martingale(ctx, g.p, r, strike, maturity, dt, isCall ? 1 : 0, polyOrder, maxIterations, &price, nullptr,
+    if (mcg_price_martingale(t_ctx.get(), P, r, strike, maturity, dt, isCall ? 1 : 0, polyOrder, maxIterations, &price, nullptr,
                              nullptr) != MCG_OK)
         raise_last();
     return price;
@@ -166,17 +200,9 @@ double BranchingProcesses::PredictOptionPrice(const std::vector<std::vector<doub
     if (pricePaths.empty() || pricePaths[0].empty()) throw std::runtime_error("BranchingProcesses: Empty pricePaths.");
     if (exerciseTimes.empty()) throw std::runtime_error("BranchingProcesses: No exercise times.");
     if (strike <= 0.0) throw std::runtime_error("BranchingProcesses: Strike must be positive.");
-    const size_t N = pricePaths.size(), M = pricePaths[0].size();
-    std::vector<double> flat(N * M);
-    for (size_t i = 0; i < N; ++i) {
-        if (pricePaths[i].size() < M) throw std::runtime_error("BranchingProcesses: ragged pricePaths.");
-        std::copy(pricePaths[i].begin(), pricePaths[i].begin() + M, flat.begin() + i * M);
-    }
-    mcg_ctx* ctx = t_ctx.get();
-    PathsGuard g;
-    if (mcg_paths_from_host(ctx, flat.data(), (int64_t)N, (int)M, &g.p) != MCG_OK) raise_last();
+    mcg_paths* P = device_matrix(pricePaths, "BranchingProcesses: ragged pricePaths.");
     double price = 0.0;
-    if (mcg_price_branching(ctx, g.p, r, strike, maturity, dt, isCall ? 1 : 0, numBranches, exerciseTimes.data(),
+    if (mcg_price_branching(t_ctx.get(), P, r, strike, maturity, dt, isCall ? 1 : 0, numBranches, exerciseTimes.data(),
                             (int)exerciseTimes.size(), next_seed(), &price, nullptr, nullptr) != MCG_OK)
         raise_last();
     return price;
