@@ -53,7 +53,8 @@ enum mcg_kernel {
     MCG_K_ASYM = 6,       /* AsymptoticAnalysis boundary scan               */
     MCG_K_MARTINGALE = 7, /* MartingaleOptimization primal/offset/dual scans */
     MCG_K_BRANCHING = 8,  /* BranchingProcesses suffix-max + bounds kernels   */
-    MCG_K_COUNT = 9
+    MCG_K_BATCH = 9,      /* the six kernels of mcg_batch_price_rows (one span) */
+    MCG_K_COUNT = 10
 };
 
 const char* mcg_last_error(void);
@@ -152,6 +153,26 @@ int mcg_price_martingale(mcg_ctx* ctx, const mcg_paths* paths, double r, double 
 int mcg_price_branching(mcg_ctx* ctx, const mcg_paths* paths, double r, double K, double maturity,
                         double dt, int is_call, int num_branches, const int* exercise_times,
                         int n_exercise_times, uint64_t seed, double* price, double* lower, double* upper);
+
+/* ---- batched driver rows ------------------------------------------- */
+/* One option row of the reference's production caller (src/core/PredictionGen.cpp:566-791): path-engine
+ * parameters (mcg_estimate_params of the row's spot history), contract terms and AsymptoticAnalysis inputs. */
+typedef struct mcg_row {
+    double S0, xi, H, eta, rho;                  /* RoughVolatility.cpp:327-331                          */
+    double strike, maturity, sigma, dividend;    /* PredictionGen.cpp:701-709                            */
+    int n_steps;                                 /* floor(maturity*252), :718; <= 1020                   */
+    int is_call;
+} mcg_row;
+
+/* Prices n_rows option rows in six launches: n_paths (<= 256; the driver uses 250) rBergomi paths per row,
+ * then AsymptoticAnalysis, BranchingProcesses(num_branches, exercise dates 0..n_steps-1), LSM(poly_order) and
+ * MartingaleOptimization(poly_order, max_iterations) on them.  out[4*i + {0,1,2,3}] = the four prices of row i
+ * in the driver's column order (asymPrice, branchPrice, lsmPriceVal, martinPrice, :809-814).  Rows the driver
+ * would answer with zeros (no steps, degenerate estimates, sigma <= 0, strike <= 0) get zeros.
+ * Row i uses Philox path ids (i << 32) + p of `seed`: its prices equal the single-contract entry points
+ * called with path_begin = i << 32.  poly_order in [0, 4]. */
+int mcg_batch_price_rows(mcg_ctx* ctx, const mcg_row* rows, int64_t n_rows, int n_paths, double r, double dt,
+                         int num_branches, int poly_order, int max_iterations, uint64_t seed, double* out);
 
 /* ---- host-side pieces of the class-level API (a2/a3 of SURVEY.md section 8) --------------- */
 /* RoughVolatility.cpp:324-331: out5 = {xi, H, eta, rho, S0}. */

@@ -9,11 +9,18 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "lib", "libmcgpu.so")
 
 MCG_OK = 0
-K_GBM, K_RBERGOMI, K_PAYOFF, K_LSM_SWEEP, K_LSM_SOLVE, K_TRANSPOSE, K_ASYM, K_MARTINGALE, K_BRANCHING = range(9)
+K_GBM, K_RBERGOMI, K_PAYOFF, K_LSM_SWEEP, K_LSM_SOLVE, K_TRANSPOSE, K_ASYM, K_MARTINGALE, K_BRANCHING, K_BATCH = range(10)
 KERNEL_NAMES = {K_GBM: "gbm", K_RBERGOMI: "rbergomi", K_PAYOFF: "payoff", K_LSM_SWEEP: "lsm_sweep",
-                K_LSM_SOLVE: "lsm_solve", K_TRANSPOSE: "transpose", K_ASYM: "asymptotic", K_MARTINGALE: "martingale", K_BRANCHING: "branching"}
+                K_LSM_SOLVE: "lsm_solve", K_TRANSPOSE: "transpose", K_ASYM: "asymptotic", K_MARTINGALE: "martingale", K_BRANCHING: "branching", K_BATCH: "batch_rows"}
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p)
+
+
+class Row(C.Structure):
+    """mcg_row (include/mcgpu.h): one option row of the reference's driver."""
+    _fields_ = [("S0", C.c_double), ("xi", C.c_double), ("H", C.c_double), ("eta", C.c_double), ("rho", C.c_double),
+                ("strike", C.c_double), ("maturity", C.c_double), ("sigma", C.c_double), ("dividend", C.c_double),
+                ("n_steps", C.c_int), ("is_call", C.c_int)]
 
 
 class McgError(RuntimeError):
@@ -84,6 +91,8 @@ def load_library():
     ip = C.POINTER(C.c_int)
     L.mcg_price_branching.argtypes = [vp, vp] + [C.c_double] * 4 + [C.c_int, C.c_int, ip, C.c_int, C.c_uint64, dp, dp, dp]
     L.mcg_compat_branching_price.argtypes = [dp, C.c_int64, C.c_int] + [C.c_double] * 4 + [C.c_int, C.c_int, ip, C.c_int, dp]
+    L.mcg_batch_price_rows.argtypes = [vp, C.POINTER(Row), C.c_int64, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int,
+                                       C.c_int, C.c_uint64, dp]
     L.mcg_estimate_params.argtypes = [dp, C.c_size_t, dp]
     L.mcg_rbergomi_weights.argtypes = [C.c_double, C.c_double, C.c_double, C.c_int, dp, dp, C.POINTER(C.c_int)]
     L.mcg_compat_set_seed.argtypes = [C.c_uint64, C.c_int]

@@ -544,6 +544,20 @@ int mcg_price_branching(mcg_ctx* ctx, const mcg_paths* P, double r, double K, do
     return run_branching(ctx, P, r, K, maturity, dt, is_call, num_branches, exercise_times, n_ex, seed, price, lower, upper);
 }
 
+int mcg_batch_price_rows(mcg_ctx* ctx, const mcg_row* rows, int64_t n_rows, int n_paths, double r, double dt,
+                         int num_branches, int poly_order, int max_iterations, uint64_t seed, double* out) {
+    if (!ctx || !out) return fail(MCG_ERR_INVALID, "ctx/out is NULL");
+    if (n_rows < 0 || (n_rows > 0 && !rows)) return fail(MCG_ERR_INVALID, "bad rows");
+    if (n_paths < 1 || n_paths > 256) return fail(MCG_ERR_INVALID, "n_paths must be in [1,256] (got %d)", n_paths);
+    if (poly_order < 0 || poly_order > 4) return fail(MCG_ERR_INVALID, "poly_order must be in [0,4] (got %d)", poly_order);
+    if (max_iterations <= 0) return fail(MCG_ERR_INVALID, "MartingaleOptimization: maxIterations must be positive.");
+    if (!(dt > 0.0)) return fail(MCG_ERR_INVALID, "dt must be > 0");
+    if (n_rows > 4000000) return fail(MCG_ERR_INVALID, "too many rows for one call");
+    if (n_rows == 0) return MCG_OK;
+    MCG_HIP(hipSetDevice(ctx->device));
+    return run_batch_rows(ctx, rows, n_rows, n_paths, r, dt, num_branches, poly_order, max_iterations, seed, out);
+}
+
 // ---- host-only pieces --------------------------------------------------------------------------
 int mcg_estimate_params(const double* hist, size_t n, double out5[5]) {
     if (!out5) return fail(MCG_ERR_INVALID, "out5 is NULL");

@@ -128,6 +128,8 @@ int run_martingale(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double 
 int run_branching(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double maturity, double dt, int is_call,
                   int num_branches, const int* exercise_times, int n_ex, uint64_t seed, double* price, double* lower,
                   double* upper);
+int run_batch_rows(mcg_ctx* ctx, const mcg_row* rows, int64_t n_rows, int n_paths, double r, double dt, int num_branches,
+                   int poly_order, int max_iterations, uint64_t seed, double* out);
 int run_asymptotic(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double maturity, double dt, int is_call,
                    double sigma, double dividend, double* price);
 

@@ -228,6 +228,21 @@ class PathEngine:
                                           C.byref(lo), C.byref(up)))
         return p.value, lo.value, up.value
 
+    def batch_price_rows(self, rows, n_paths: int = 250, r: float = 0.04, dt: float = 1.0 / 252.0,
+                         num_branches: int = 10, poly_order: int = 2, max_iterations: int = 5,
+                         seed: int = 0) -> np.ndarray:
+        """mcg_batch_price_rows: rows = sequence of dicts with the mcg_row fields; returns [n_rows][4]
+        (asymptotic, branching, lsm, martingale) -- the driver's four model columns."""
+        arr = (N.Row * len(rows))()
+        for i, d in enumerate(rows):
+            for k, _ in N.Row._fields_:
+                setattr(arr[i], k, d[k])
+        out = np.zeros((len(rows), 4), dtype=np.float64)
+        check(self._L.mcg_batch_price_rows(self._ctx, arr, len(rows), int(n_paths), r, dt, int(num_branches),
+                                           int(poly_order), int(max_iterations), int(seed),
+                                           out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out
+
     def debug_eval(self, fn: int, x: np.ndarray) -> np.ndarray:
         """Test hook (mcg_debug_eval): one device math routine elementwise; returns [n][4]."""
         x = np.ascontiguousarray(x, dtype=np.float64)

@@ -472,3 +472,53 @@ def test_branching_class_api_and_errors(orc):
                      ((paths, 0.0, ex), "Strike must be positive.")]:
         with pytest.raises(mc.McgError, match="BranchingProcesses: " + msg):
             bp.PredictOptionPrice(bad[0], 0.04, bad[1], 1.0, DT, False, 10, bad[2])
+
+
+# ------------------------------------------------------------------------------------------------
+# batched driver rows
+# ------------------------------------------------------------------------------------------------
+def _driver_rows(n, rs):
+    rows = []
+    for i in range(n):
+        steps = int(rs.choice([5, 16, 21, 40, 63, 64, 100, 130]))
+        S0 = float(rs.uniform(20, 400))
+        rows.append(dict(S0=S0, xi=float(rs.uniform(0.01, 0.3)), H=float(rs.uniform(0.05, 0.6)),
+                         eta=float(rs.uniform(0.0, 2.0)), rho=-0.3, strike=S0 * float(rs.uniform(0.9, 1.1)),
+                         maturity=steps / 252.0 * float(rs.choice([1.0, 1.0, 0.69])), sigma=float(rs.uniform(0.1, 0.6)),
+                         dividend=float(rs.uniform(0.0, 0.1)), n_steps=steps, is_call=int(rs.randint(0, 2))))
+    return rows
+
+
+def test_batch_rows_equal_single_contract_entry_points(eng):
+    """Row i of the batch == the single-contract C ABI calls on paths (i << 32) + p of the same seed.
+    (kappa comes from a device DFT in the batch and from the host FFT otherwise: ~1e-13 apart.)"""
+    rs = np.random.RandomState(4)
+    rows = _driver_rows(24, rs)
+    rows[3]["sigma"] = 0.0          # AsymptoticAnalysis would throw  -> the driver writes zeros for the row
+    rows[7]["n_steps"] = 0          # "No time steps"                 -> zeros
+    rows[11]["rho"] = float("nan")  # two-point history               -> NaN paths -> zeros
+    got = eng.batch_price_rows(rows, n_paths=250, r=0.04, dt=DT, num_branches=10, poly_order=2, max_iterations=5, seed=77)
+    assert got.shape == (24, 4)
+    for i, d in enumerate(rows):
+        if i in (3, 7, 11):
+            assert (got[i] == 0.0).all()
+            continue
+        P = eng.rbergomi(77, d["S0"], 0.04, d["xi"], d["H"], d["eta"], d["rho"], DT, d["n_steps"], 250, path_begin=i << 32)
+        call = bool(d["is_call"])
+        want = [eng.price_asymptotic(P, 0.04, d["strike"], d["maturity"], DT, call, d["sigma"], d["dividend"]),
+                eng.price_branching(P, 0.04, d["strike"], d["maturity"], DT, call, 10, np.arange(d["n_steps"]), 77)[0],
+                eng.price_lsm(P, 0.04, d["strike"], d["maturity"], DT, call, 2)[0],
+                eng.price_martingale(P, 0.04, d["strike"], d["maturity"], DT, call, 2, 5)[0]]
+        P.free()
+        assert np.allclose(got[i], want, rtol=1e-7, atol=1e-9), (i, d, got[i], want)
+
+
+def test_batch_rows_arguments(eng):
+    rows = _driver_rows(2, np.random.RandomState(1))
+    assert eng.batch_price_rows([], n_paths=250).shape == (0, 4)
+    with pytest.raises(mc.McgError, match="n_paths"):
+        eng.batch_price_rows(rows, n_paths=300)
+    with pytest.raises(mc.McgError, match="maxIterations must be positive"):
+        eng.batch_price_rows(rows, max_iterations=0)
+    a = eng.batch_price_rows(rows, seed=5)
+    assert np.array_equal(a, eng.batch_price_rows(rows, seed=5)) and not np.array_equal(a, eng.batch_price_rows(rows, seed=6))
