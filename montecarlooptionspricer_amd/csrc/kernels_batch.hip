@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256) void k_batch_martingale(BatchArgs a) {
     if (threadIdx.x == 0) {
 #pragma unroll
         for (int q = 0; q <= NM; ++q) sm_mom[q] = m[q];
-        lsm_solve_one(sm_mom, NB, (double)NB, sm_coef);
+        lsm_solve_nb<NB>(sm_mom, (double)NB, sm_coef);
     }
     __syncthreads();
     const double primal = sm_mom[NM] / (double)a.n_paths;

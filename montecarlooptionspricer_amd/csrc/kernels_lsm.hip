@@ -29,7 +29,7 @@ struct LsmArgs {
     int is_call;
     int upd;
     const double* coef;   // device: coef[0..NB), coef[9] = number of ITM paths of date j (global)
-    double* partials;     // [gridDim.x][NM]
+    double* partials;     // [NM][gridDim.x] (moment-major: the reduce kernel reads contiguously)
 };
 
 // NB = poly_order + 1 basis functions; NM = (2p+1) power sums + (p+1) cross sums = 3*NB - 1.
@@ -91,12 +91,12 @@ __global__ __launch_bounds__(256) void k_lsm_sweep(LsmArgs a) {
         block_sum<NM, 4>(m, red);
         if (threadIdx.x == 0) {
 #pragma unroll
-            for (int q = 0; q < NM; ++q) a.partials[(int64_t)blockIdx.x * NM + q] = m[q];
+            for (int q = 0; q < NM; ++q) a.partials[(int64_t)q * gridDim.x + blockIdx.x] = m[q];
         }
     }
 }
 
-// One block.  do_reduce: partials[n_blocks][nm] -> moments[nm] in a fixed order (wave w sums moments
+// One block.  do_reduce: partials[nm][n_blocks] -> moments[nm] in a fixed order (wave w sums moments
 // w, w+4, ...: lanes stride over the blocks, then a wavefront butterfly).  do_solve: moments -> coef.
 // Single GPU: both in one launch.  Sharded: reduce, all-reduce of `moments`, then solve.
 __global__ __launch_bounds__(256) void k_lsm_reduce_solve(const double* partials, int n_blocks, int nm, int nb,
@@ -107,7 +107,8 @@ __global__ __launch_bounds__(256) void k_lsm_reduce_solve(const double* partials
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         for (int q = wave; q < nm; q += 4) {
             double s = 0.0;
-            for (int b = lane; b < n_blocks; b += 64) s += partials[(int64_t)b * nm + q];
+#pragma unroll 8
+            for (int b = lane; b < n_blocks; b += 64) s += partials[(int64_t)q * n_blocks + b];  // loads issue ahead of the adds
             s = wave_sum(s);
             if (lane == 0) {
                 moments[q] = s;  // for the all-reduce / the host

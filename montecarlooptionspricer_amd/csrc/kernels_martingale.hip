@@ -29,7 +29,7 @@ struct MoArgs {
     double* partials;
 };
 
-// primal scan + regression moments.  partials[block][NM + 1]: NM moments, then the primal sum.
+// primal scan + regression moments.  partials[NM + 1][grid] (moment-major): NM moments, then the primal sum.
 template <int NB>
 __global__ __launch_bounds__(256) void k_mo_primal(MoArgs a) {
     constexpr int NM = 3 * NB - 1;
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void k_mo_primal(MoArgs a) {
     block_sum<NM + 1, 4>(m, red);
     if (threadIdx.x == 0) {
 #pragma unroll
-        for (int q = 0; q <= NM; ++q) a.partials[(int64_t)blockIdx.x * (NM + 1) + q] = m[q];
+        for (int q = 0; q <= NM; ++q) a.partials[(int64_t)q * gridDim.x + blockIdx.x] = m[q];
     }
 }
 

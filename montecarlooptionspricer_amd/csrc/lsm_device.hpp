@@ -11,8 +11,12 @@ namespace mcg {
 // date: ~1 us).  Otherwise (one ITM path, all paths equal at j = 0, ...): cyclic Jacobi
 // eigen-decomposition and a pseudo-inverse with relative eigenvalue cut 1e-12, which yields the
 // projection the reference's min-norm SVD solve gives at the data points.
-__device__ inline void lsm_solve_one(const double* moments, int nb, double min_count, double* coef) {
-    double G[9][9], Q[9][9], rhs[9], d[9], sol[9];
+// NB is a template parameter so that every loop unrolls and G, Q live in registers: with a run-time size the
+// arrays go to scratch memory and the (serial, one-thread) solve takes ~20 us instead of ~2.
+template <int NB>
+__device__ __forceinline__ void lsm_solve_nb(const double* moments, double min_count, double* coef) {
+    constexpr int nb = NB;
+    double G[NB][NB], Q[NB][NB], rhs[NB], d[NB], sol[NB];
     const double count = moments[0];
     coef[9] = count;
     for (int a = 0; a < 9; ++a) coef[a] = 0.0;
@@ -105,6 +109,21 @@ __device__ inline void lsm_solve_one(const double* moments, int nb, double min_c
     for (int a = 0; a < nb; ++a) coef[a] = sol[a] * d[a];
 }
 
+// run-time order -> the unrolled instance
+__device__ inline void lsm_solve_one(const double* moments, int nb, double min_count, double* coef) {
+    switch (nb) {
+        case 1: lsm_solve_nb<1>(moments, min_count, coef); break;
+        case 2: lsm_solve_nb<2>(moments, min_count, coef); break;
+        case 3: lsm_solve_nb<3>(moments, min_count, coef); break;
+        case 4: lsm_solve_nb<4>(moments, min_count, coef); break;
+        case 5: lsm_solve_nb<5>(moments, min_count, coef); break;
+        case 6: lsm_solve_nb<6>(moments, min_count, coef); break;
+        case 7: lsm_solve_nb<7>(moments, min_count, coef); break;
+        case 8: lsm_solve_nb<8>(moments, min_count, coef); break;
+        default: lsm_solve_nb<9>(moments, min_count, coef); break;
+    }
+}
+
 // The whole backward sweep in ONE launch for a small path count (n <= 1024: the reference's production
 // calls price 250 paths per option row, src/core/PredictionGen.cpp:719): one 256-thread block, up to four
 // paths per thread with V in registers, per date a block reduction of the regression moments, the solve on
@@ -158,7 +177,7 @@ __device__ __forceinline__ void lsm_small_body(const double* data, int64_t ld, i
         if (threadIdx.x == 0) {
 #pragma unroll
             for (int t = 0; t < NM; ++t) sm_mom[t] = m[t];
-            lsm_solve_one(sm_mom, NB, 1.0, sm_coef);  // writes sm_coef[0..9], [9] = ITM count
+            lsm_solve_nb<NB>(sm_mom, 1.0, sm_coef);  // writes sm_coef[0..9], [9] = ITM count
         }
         __syncthreads();
         double c[NB];

@@ -522,3 +522,49 @@ def test_batch_rows_arguments(eng):
         eng.batch_price_rows(rows, max_iterations=0)
     a = eng.batch_price_rows(rows, seed=5)
     assert np.array_equal(a, eng.batch_price_rows(rows, seed=5)) and not np.array_equal(a, eng.batch_price_rows(rows, seed=6))
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE.json's full sizes, through size-independent properties
+# ------------------------------------------------------------------------------------------------
+def test_full_size_c2_properties(eng):
+    """C2 (10M x 252): Black-Scholes within 2 std-errs, forward = S0 e^{rT} by put-call parity on the same
+    paths, and two 5M shards combine to exactly the sums of the 10M run (checksum of checksums)."""
+    n = 10_000_000
+    P = eng.gbm(SEED, 100.0, 0.04, 0.2, DT, 252, n, payoff=(100.0, True))
+    c, cse = eng.price_european(P, 100.0, 0.04, 1.0, True)
+    p, pse = eng.price_european(P, 100.0, 0.04, 1.0, False)
+    P.free()
+    assert abs(c - bs_price(100.0, 100.0, 0.04, 0.2, 1.0)) <= 2.0 * cse
+    fwd = math.exp(0.04) * (c - p) + 100.0
+    assert abs(fwd - 100.0 * math.exp(0.04)) <= 2.5 * math.exp(0.04) * math.hypot(cse, pse)
+    disc = math.exp(-0.04)
+    parts = []
+    for b in (0, n // 2):
+        Q = eng.gbm(SEED, 100.0, 0.04, 0.2, DT, 252, n // 2, path_begin=b, payoff=(100.0, True))
+        m, se = eng.price_european(Q, 100.0, 0.04, 1.0, True)
+        Q.free()
+        k = n // 2
+        mean = m / disc
+        parts.append((mean * k, (se / disc) ** 2 * k * (k - 1) + k * mean * mean, float(k)))
+    from montecarlooptionspricer_amd.sharding import combine_sums, price_from_sums
+    m2, se2 = price_from_sums(combine_sums(parts), disc)
+    assert abs(m2 - c) <= 1e-10 * c and abs(se2 - cse) <= 1e-6 * cse
+
+
+def test_full_size_c3_c4_properties(eng):
+    """C3 (1M x 50 LSM): American put above the European put on the same paths, below the strike.
+    C4 (4M x 512 rBergomi): martingale E[S_T] = S0 e^{rT} via put-call parity; finite price."""
+    P = eng.gbm(SEED, 100.0, 0.04, 0.2, 0.02, 50, 1_000_000)
+    am, ase = eng.price_lsm(P, 0.04, 100.0, 1.0, 0.02, False, 2)
+    eu, ese = eng.price_european(P, 100.0, 0.04, 1.0, False)
+    P.free()
+    assert eu - 3 * ese < am < 100.0 and am > 6.0
+    T = 512 * DT
+    R = eng.rbergomi(SEED, 100.0, 0.04, RB["xi"], RB["H"], RB["eta"], RB["rho"], DT, 512, 4_000_000, payoff=(100.0, True))
+    c, cse = eng.price_european(R, 100.0, 0.04, T, True)
+    p, pse = eng.price_european(R, 100.0, 0.04, T, False)
+    R.free()
+    fwd = math.exp(0.04 * T) * (c - p) + 100.0
+    assert abs(fwd - 100.0 * math.exp(0.04 * T)) <= 2.5 * math.exp(0.04 * T) * math.hypot(cse, pse)
+    assert math.isfinite(c) and c > 0
