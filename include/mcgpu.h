@@ -92,7 +92,8 @@ int mcg_paths_gbm(mcg_ctx* ctx, uint64_t seed, double S0, double r, double sigma
                   int n_steps, uint64_t path_begin, int64_t n_paths, mcg_paths** out);
 
 /* rBergomi as the reference simulates it (RoughVolatility.cpp:342-364) with explicit parameters.
- * rho is accepted for interface parity; it does not change the law. */
+ * rho is accepted for interface parity; it does not change the law.
+ * Paths are generated in pairs: path_begin must be even. */
 int mcg_paths_rbergomi(mcg_ctx* ctx, uint64_t seed, double S0, double r, double xi, double H,
                        double eta, double rho, double dt, int n_steps, uint64_t path_begin,
                        int64_t n_paths, mcg_paths** out);
@@ -177,10 +178,10 @@ int mcg_batch_price_rows(mcg_ctx* ctx, const mcg_row* rows, int64_t n_rows, int 
 /* ---- host-side pieces of the class-level API (a2/a3 of SURVEY.md section 8) --------------- */
 /* RoughVolatility.cpp:324-331: out5 = {xi, H, eta, rho, S0}. */
 int mcg_estimate_params(const double* hist, size_t n, double out5[5]);
-/* Real Volterra weights kappa[0..Mz) and compensator comp[0..n_steps) staged in LDS by the
- * rBergomi kernel; Mz = nextpow2(n_steps). */
-int mcg_rbergomi_weights(double H, double eta, double dt, int n_steps, double* kappa, double* comp,
-                         int* Mz);
+/* Spectral amplitudes amp[0..Mz) and compensator comp[0..n_steps) staged in LDS by the rBergomi kernels
+ * (DESIGN.md); Mz = nextpow2(n_steps). */
+int mcg_rbergomi_spectrum(double H, double eta, double dt, int n_steps, double* amp, double* comp,
+                          int* Mz);
 
 /* The reference's class API through the C ABI (what the C++ shims in include/models call):
  * GenerateStockPricePaths(hist, steps, paths) -> out[paths][steps+1], and

@@ -2,14 +2,14 @@
 // (/root/reference/src/core/PredictionGen.cpp:700-791 -- 250 rBergomi paths, then AsymptoticAnalysis,
 // BranchingProcesses(10 branches, exercise dates 0..steps-1), LSM(polyOrder 2), MartingaleOptimization(2))
 // for MANY option rows in six launches instead of ~15 launches and ~8 host synchronisations per row:
-//   k_batch_weights    one workgroup per row: lambda -> |phi_k|^2 -> Volterra weights kappa and compensator
+//   k_batch_weights    one workgroup per row: lambda -> |phi_k|^2 -> spectral amplitudes a_k and compensator
 //                      (the host/volterra.cpp math, done with a direct DFT against an LDS table of roots of unity)
-//   k_batch_paths      ceil(n_paths/64) workgroups per row: the MFMA generator of kernels_rbergomi.hip
+//   k_batch_paths      a few workgroups per row: the FFT generator of rbergomi_device.hpp
 //   k_batch_asym / _branching / _lsm / _martingale    one workgroup per row (n_paths <= 256: one path per
 //                      thread), all reductions inside the workgroup, regression solves on thread 0
 // Row c uses Philox path ids (c << 32) + p, so its four prices equal those of the single-contract entry
 // points called with path_begin = c << 32 (up to the ~1e-13 difference between the device DFT and the host FFT
-// in kappa).  Matrix layout: step-major, row c owns columns [256 c, 256 c + n_paths).
+// in the amplitudes).  Matrix layout: step-major, row c owns columns [256 c, 256 c + n_paths).
 #include <cmath>
 
 #include "lsm_device.hpp"
@@ -29,7 +29,7 @@ struct BatchArgs {
     int n_paths, max_steps, m_max;
     double r, dt, sqdt, disc;  // disc = exp(-r dt)
     uint32_t k0, k1;
-    double* kappa;  // [n_rows][m_max]
+    double* kappa;  // [n_rows][m_max] spectral amplitudes a_k of each row
     double* comp;   // [n_rows][max_steps]
     double* S;      // [(max_steps+1)][ld]
     double* F;      // same shape (branching suffix maxima)
@@ -78,19 +78,10 @@ __global__ __launch_bounds__(256) void k_batch_weights(BatchArgs a) {
         P[k] = p;
     }
     __syncthreads();
-    double amp_mine[4];  // M <= 1024: at most 4 entries per thread
-    for (int k = threadIdx.x, t = 0; k < M; k += 256, ++t) amp_mine[t] = sqrt(0.5 * (P[k] + P[(M - k) & (M - 1)]));
-    __syncthreads();
-    for (int k = threadIdx.x, t = 0; k < M; k += 256, ++t) P[k] = amp_mine[t];
-    __syncthreads();
-    const double scale = row.eta * sqrt(2.0 * row.H / (double)M) / (double)M;
-    const int stride = Mphi / M;  // cos(2 pi q / M) = ct[q * Mphi/M]
-    double* kap = a.kappa + (int64_t)blockIdx.x * a.m_max;
-    for (int m = threadIdx.x; m < M; m += 256) {
-        double s = 0.0;
-        for (int k = 0; k < M; ++k) s = fma(P[k], ct[((k * m) & (M - 1)) * stride], s);
-        kap[m] = scale * s;
-    }
+    // a_k = eta sqrt(2H)/M * sqrt((P_k + P_{M-k})/2): the symmetric spectral amplitudes of host/volterra.cpp
+    const double scale = row.eta * sqrt(2.0 * row.H) / (double)M;
+    double* amp = a.kappa + (int64_t)blockIdx.x * a.m_max;
+    for (int k = threadIdx.x; k < M; k += 256) amp[k] = scale * sqrt(0.5 * (P[k] + P[(M - k) & (M - 1)]));
     double* cmp = a.comp + (int64_t)blockIdx.x * a.max_steps;
     for (int n = threadIdx.x; n < steps; n += 256) cmp[n] = -0.5 * row.eta * row.eta * pow((double)n * a.dt, 2.0 * row.H);
 }
@@ -100,8 +91,11 @@ __global__ __launch_bounds__(256) void k_batch_paths(BatchArgs a, int blocks_per
     extern __shared__ double smem[];
     __shared__ fm::Tables tabs;
     const int64_t r_idx = blockIdx.x / blocks_per_row;
+    const int sub = (int)(blockIdx.x % blocks_per_row);
     const BatchRow row = a.rows[r_idx];
     if (!row.valid) return;
+    const int n_pairs = (a.n_paths + 1) / 2;
+    if ((int64_t)sub * rb_pairs_per_block(row.M) >= n_pairs) return;  // this row needs fewer workgroups than the widest
     RbArgs g;
     g.out = a.S + r_idx * 256;
     g.ld = a.ld;
@@ -117,14 +111,23 @@ __global__ __launch_bounds__(256) void k_batch_paths(BatchArgs a, int blocks_per
     g.xi = row.xi;
     g.dt = a.dt;
     g.sqdt = a.sqdt;
-    g.kappa = a.kappa + r_idx * a.m_max;
+    g.amp = a.kappa + r_idx * a.m_max;
     g.comp = a.comp + r_idx * a.max_steps;
     g.log_tab = a.log_tab;
     g.K = 0.0;
     g.is_call = 0;
     g.partials = nullptr;
-    bool lead;
-    (void)rb_generate(g, (int64_t)(blockIdx.x % blocks_per_row), smem, &tabs, lead);
+    double la, lb;
+    bool va, vb, lead;
+    switch (row.M) {  // wave-uniform
+        case 32: rb_generate_fft<0>(g, sub, smem, &tabs, la, lb, va, vb, lead); break;
+        case 64: rb_generate_fft<1>(g, sub, smem, &tabs, la, lb, va, vb, lead); break;
+        case 128: rb_generate_fft<2>(g, sub, smem, &tabs, la, lb, va, vb, lead); break;
+        case 256: rb_generate_fft<3>(g, sub, smem, &tabs, la, lb, va, vb, lead); break;
+        case 512: rb_generate_fft<4>(g, sub, smem, &tabs, la, lb, va, vb, lead); break;
+        case 1024: rb_generate_fft<5>(g, sub, smem, &tabs, la, lb, va, vb, lead); break;
+        default: rb_generate_small(g, sub, smem, &tabs, la, lb, va, vb, lead); break;
+    }
 }
 
 // ---- AsymptoticAnalysis (AsymptoticAnalysisPricer.cpp:38-113), one workgroup per row ------------
@@ -443,9 +446,12 @@ int run_batch_rows(mcg_ctx* ctx, const mcg_row* rows, int64_t n_rows, int n_path
     }
     const int mphi_max = 2 * m_max >= 2 ? 2 * m_max : 2;
     const size_t smem_w = ((size_t)2 * mphi_max + (size_t)max_steps + 1 + (size_t)m_max) * sizeof(double);
-    const size_t smem_p = ((size_t)m_max + RB_PAD + (size_t)max_steps) * sizeof(double);
+    const size_t smem_p = ((size_t)m_max + (size_t)max_steps + 2 * (size_t)(m_max / 2 + 1)) * sizeof(double);
     const size_t smem_c = ((size_t)max_steps + 1) * sizeof(double);
-    const int bpr = (n_paths + 63) / 64;
+    // workgroups per row: enough for the row with the fewest pairs per workgroup (the largest Mz)
+    const int n_pairs = (n_paths + 1) / 2;
+    int bpr = 1;
+    for (int m = 32; m <= m_max; m <<= 1) bpr = std::max(bpr, (n_pairs + rb_pairs_per_block(m) - 1) / rb_pairs_per_block(m));
     {
         TimedLaunch t(ctx, MCG_K_BATCH);
         hipLaunchKernelGGL(k_batch_weights, dim3((unsigned)n_rows), dim3(256), smem_w, ctx->stream, a);

@@ -564,12 +564,12 @@ int mcg_estimate_params(const double* hist, size_t n, double out5[5]) {
     return host_estimate_params(hist, n, out5);
 }
 
-int mcg_rbergomi_weights(double H, double eta, double dt, int n_steps, double* kappa, double* comp, int* Mz) {
-    if (n_steps < 1 || !kappa || !comp) return fail(MCG_ERR_INVALID, "bad arguments");
+int mcg_rbergomi_spectrum(double H, double eta, double dt, int n_steps, double* amp, double* comp, int* Mz) {
+    if (n_steps < 1 || !amp || !comp) return fail(MCG_ERR_INVALID, "bad arguments");
     std::vector<double> k, c;
-    int rc = host_rbergomi_weights(H, eta, dt, n_steps, k, c);
+    int rc = host_rbergomi_spectrum(H, eta, dt, n_steps, k, c);
     if (rc) return rc;
-    std::memcpy(kappa, k.data(), k.size() * sizeof(double));
+    std::memcpy(amp, k.data(), k.size() * sizeof(double));
     std::memcpy(comp, c.data(), c.size() * sizeof(double));
     if (Mz) *Mz = (int)k.size();
     return MCG_OK;

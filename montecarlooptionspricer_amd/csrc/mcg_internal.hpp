@@ -137,7 +137,7 @@ int run_asymptotic(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double 
 void host_asymptotic_tables(int n_cols, double r, double K, double maturity, double dt, int is_call, double sigma,
                             double dividend, std::vector<double>& bnd, std::vector<double>& disc);
 int host_estimate_params(const double* hist, size_t n, double out5[5]);
-int host_rbergomi_weights(double H, double eta, double dt, int n_steps, std::vector<double>& kappa,
-                          std::vector<double>& comp);
+int host_rbergomi_spectrum(double H, double eta, double dt, int n_steps, std::vector<double>& amp,
+                           std::vector<double>& comp);
 
 }  // namespace mcg

@@ -1,137 +1,304 @@
-// Device-side body of the rBergomi generator, shared by the single-contract kernel
-// (kernels_rbergomi.hip) and the batched driver-row kernel (kernels_batch.hip).  See
-// kernels_rbergomi.hip for the algorithm.
+// Device-side body of the rBergomi generator, shared by the single-contract kernels
+// (kernels_rbergomi.hip) and the batched driver-row kernel (kernels_batch.hip).
+//
+// Reference behaviour per path (/root/reference/src/models/RoughVolatility.cpp:346-365):
+//   X = sqrt(2H) eta Re(FFT^-(phi (.) Z)/Mz)        (:347-348, :264-292)   a stationary circular Gaussian sequence
+//   v_n = xi exp(X_n - 0.5 eta^2 t_n^{2H})          (:349, :294-309)
+//   S_{n+1} = S_n exp((r - v_n/2) dt + sqrt(max(0,v_n)) dW_n),  dW_n ~ N(0, dt)   (:354-364)
+//
+// Device algorithm: spectral synthesis, one complex transform per PAIR of paths.  With the symmetric
+// amplitudes a_k of host/volterra.cpp and Y_k = a_k (g_k + i h_k),
+//   x_n = sum_{k<Mz} Y_k e^{+2 pi i k n/Mz},   X(path 2q) = Re x,  X(path 2q+1) = Im x
+// (two independent copies of the reference's X).  The transform is an in-register radix-2
+// decimation-in-time FFT of length Mz = 32 G spread over G lanes (32 complex points per lane): the
+// spectrum is drawn directly in bit-reversed order (each lane's 32 inputs are four runs of 8 consecutive k,
+// i.e. 16 Philox blocks with no draw wasted), the 2 lowest and 3 highest index bits are butterflies between
+// registers, the log2(G) middle bits are butterflies between lanes (wavefront shuffles), twiddles come
+// from an LDS table.  O(Mz log Mz) instead of the O(Mz steps) contraction of the Volterra form (which ran at the
+// fp64-FMA roofline on MFMA in an earlier version of this file: 64 cycles per v_mfma_f64_16x16x4_f64 and no
+// overlap with fp64 VALU work on gfx950, tools/ubench_mfma_f64.hip).
+// The natural-order output leaves lane g of a pair with steps n = 4(tG + g) + v (t = 0..7, v = 0..3): four
+// CONSECUTIVE steps per 4G-step tile.  The price then advances in log space: in-lane 4-prefix, wavefront-
+// shuffle scan over the G lanes, S = exp(.), and each lane stores {S(path 2q), S(path 2q+1)} as one 16-byte
+// store (lanes of equal g cover 64/G pairs = a contiguous (64/G)*16-byte run of the step-major row).
 #pragma once
 #include "devmath.hpp"
 #include "fastmath.hpp"
 
 namespace mcg {
 
-typedef double v4d __attribute__((ext_vector_type(4)));
-
-constexpr int RB_NT = 16;   // 16-step tiles accumulated per pass (256 steps)
-constexpr int RB_PAD = 32;  // periodic extension of the weight vector in LDS
-
 struct RbArgs {
     double* out;
     int64_t ld;
     int64_t n_paths;
     int n_steps;
-    int M;  // Mz
-    uint64_t path_begin;
+    int M;  // Mz = nextpow2(n_steps)
+    uint64_t path_begin;  // even
     uint32_t k0, k1;
     double S0, logS0, r, xi, dt, sqdt;
-    const double* kappa;  // [M]
-    const double* comp;   // [n_steps]
+    const double* amp;   // [M] spectral amplitudes a_k
+    const double* comp;  // [n_steps]
     const double2* log_tab;
     double K;
     int is_call;
     double* partials;
 };
 
-// One pass over NT consecutive 16-step tiles starting at step n_base: accumulate X by MFMA, then
-// advance the price through those steps.  Tiles (or single steps) beyond n_steps are computed but
-// neither stored nor added to the running log-price.
-template <int NT>
-__device__ __forceinline__ void rb_pass(const RbArgs& a, const double* kext, const double* comp, const fm::Tables* tab,
-                                        int n_base, int g, int c, int a_off, uint64_t id, bool live, double* col,
-                                        double& logS) {
-    const int M = a.M;
-    v4d acc[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = v4d{0.0, 0.0, 0.0, 0.0};
+// LDS carve-up shared by all variants: amp[M] | comp[n_steps] | twiddle (cos, sin)(2 pi q / M), q < max(M/2, 1)
+__device__ __forceinline__ size_t rb_smem_doubles(int M, int n_steps) { return (size_t)M + n_steps + 2 * (size_t)(M / 2 + 1); }
 
-    const int n_kq = (M + 15) >> 4;
-    for (int kq = 0; kq < n_kq; ++kq) {
-        // this lane's four noise values: j = 16kq + 4g + e, e = 0..3 (one Philox block, number 4kq + g)
-        double eps[4];
-        fm::normal_quad_fast(a.k0, a.k1, id, (uint32_t)(4 * kq + g), STREAM_VOL, tab, eps);
-        const int j0 = 16 * kq + 4 * g;
-        const int base = (n_base - 16 * kq) & (M - 1);
+struct RbLds {
+    const double* amp;
+    const double* comp;
+    const double2* tw;
+};
+
+__device__ __forceinline__ RbLds rb_stage_lds(const RbArgs& a, double* smem, fm::Tables* tabs) {
+    const int M = a.M;
+    double* amp = smem;
+    double* comp = smem + M;
+    double2* tw = reinterpret_cast<double2*>(smem + M + a.n_steps + ((M + a.n_steps) & 1));  // 16-B aligned
+    for (int i = threadIdx.x; i < M; i += blockDim.x) amp[i] = a.amp[i];
+    for (int i = threadIdx.x; i < a.n_steps; i += blockDim.x) comp[i] = a.comp[i];
+    for (int q = threadIdx.x; q < M / 2; q += blockDim.x) {
+        double s, c;
+        sincospi(2.0 * (double)q / (double)M, &s, &c);
+        tw[q] = make_double2(c, s);
+    }
+    fm::load_tables(tabs, a.log_tab);
+    __syncthreads();
+    return RbLds{amp, comp, tw};
+}
+
+// {S_A, S_B} -> out[col_a], out[col_a + 1] (col_a even, rows 16-byte aligned)
+__device__ __forceinline__ void rb_store_pair(double* row_a, double sa, double sb, bool live_a, bool live_b) {
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    if (live_b) {
+        v2d v = {sa, sb};
+        __builtin_nontemporal_store(v, reinterpret_cast<v2d*>(row_a));
+    } else if (live_a) {
+        __builtin_nontemporal_store(sa, row_a);
+    }
+}
+
+__device__ __forceinline__ constexpr int rb_rev3(int t) { return ((t & 1) << 2) | (t & 2) | ((t >> 2) & 1); }
+
+// One workgroup's share: 4 waves x (64 >> LG) path pairs.  Returns through log_a/log_b the final log-prices of
+// this lane's pair; lead = this lane is the one lane (g == 0) that reports the pair's payoff.
+template <int LG>
+__device__ __forceinline__ void rb_generate_fft(const RbArgs& a, int64_t block_index, double* smem, fm::Tables* tabs,
+                                                double& log_a, double& log_b, bool& live_a, bool& live_b, bool& lead) {
+    constexpr int G = 1 << LG;   // lanes per pair
+    constexpr int P = 64 >> LG;  // pairs per wave
+    const RbLds L = rb_stage_lds(a, smem, tabs);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> (6 - LG), c = lane & (P - 1);
+    const int64_t q = block_index * (4 * P) + wave * P + c;  // pair index within the launch
+    const int64_t col_a = 2 * q;
+    live_a = col_a < a.n_paths;
+    live_b = col_a + 1 < a.n_paths;
+    const uint64_t id_a = a.path_begin + (uint64_t)col_a, id_b = id_a + 1;
+    const uint64_t pair_id = id_a >> 1;
+
+    // ---- spectrum, in bit-reversed order: slot (t, v) of lane g holds Y_k, k = rev(4(tG + g) + v) ----
+    double xr[32], xi[32];
+    const int g_rev = LG ? (int)(__brev((unsigned)g) >> (32 - LG)) : 0;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const double ev = (j0 + e < M) ? eps[e] : 0.0;  // only matters when Mz < 16
+    for (int v = 0; v < 4; ++v) {
+        const int v_rev = ((v & 1) << 1) | (v >> 1);
+        const int k_base = (v_rev << (3 + LG)) | (g_rev << 3);  // 8 consecutive k: k_base + rev3(t)
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const double w = kext[((base + 16 * t) & (M - 1)) + a_off - e];
-                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(w, ev, acc[t], 0, 0, 0);
+        for (int bq = 0; bq < 4; ++bq) {
+            double z[4];
+            fm::normal_quad_fast(a.k0, a.k1, pair_id, (uint32_t)((k_base >> 1) + bq), STREAM_VOL, tabs, z);
+            const double a0 = L.amp[k_base + 2 * bq], a1 = L.amp[k_base + 2 * bq + 1];
+            const int t0 = rb_rev3(2 * bq), t1 = rb_rev3(2 * bq + 1);
+            xr[t0 * 4 + v] = a0 * z[0];
+            xi[t0 * 4 + v] = a0 * z[1];
+            xr[t1 * 4 + v] = a1 * z[2];
+            xi[t1 * 4 + v] = a1 * z[3];
+        }
+    }
+
+    // ---- stages 1, 2: index bits 0, 1 (v), twiddles 1 and i ----
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+#pragma unroll
+        for (int v = 0; v < 4; v += 2) {
+            const double ar = xr[t * 4 + v], ai = xi[t * 4 + v], br = xr[t * 4 + v + 1], bi = xi[t * 4 + v + 1];
+            xr[t * 4 + v] = ar + br;
+            xi[t * 4 + v] = ai + bi;
+            xr[t * 4 + v + 1] = ar - br;
+            xi[t * 4 + v + 1] = ai - bi;
+        }
+        {  // (0,2) with w = 1
+            const double ar = xr[t * 4], ai = xi[t * 4], br = xr[t * 4 + 2], bi = xi[t * 4 + 2];
+            xr[t * 4] = ar + br;
+            xi[t * 4] = ai + bi;
+            xr[t * 4 + 2] = ar - br;
+            xi[t * 4 + 2] = ai - bi;
+        }
+        {  // (1,3) with w = e^{2 pi i /4} = i:  w*b = (-bi, br)
+            const double ar = xr[t * 4 + 1], ai = xi[t * 4 + 1], br = xr[t * 4 + 3], bi = xi[t * 4 + 3];
+            xr[t * 4 + 1] = ar - bi;
+            xi[t * 4 + 1] = ai + br;
+            xr[t * 4 + 3] = ar + bi;
+            xi[t * 4 + 3] = ai - br;
+        }
+    }
+
+    // ---- stages 3 .. 2+LG: index bits 2 .. 1+LG (the lane bits): butterflies between lanes ----
+#pragma unroll
+    for (int b = 0; b < LG; ++b) {
+        const bool upper = ((g >> b) & 1) != 0;
+        const int delta = P << b;
+        const int j_hi = (g & ((1 << b) - 1)) << 2;  // twiddle exponent j = j_hi | v, stage s = 3 + b
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const double2 w = L.tw[(j_hi | v) << (2 + LG - b)];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const double mr = xr[t * 4 + v], mi = xi[t * 4 + v];
+                const double pr = __shfl_xor(mr, delta, 64), pi = __shfl_xor(mi, delta, 64);
+                const double ar = upper ? pr : mr, ai = upper ? pi : mi;  // lower element of the butterfly
+                const double br = upper ? mr : pr, bi = upper ? mi : pi;  // upper element
+                const double wr = w.x * br - w.y * bi, wi = w.x * bi + w.y * br;
+                xr[t * 4 + v] = upper ? ar - wr : ar + wr;
+                xi[t * 4 + v] = upper ? ai - wi : ai + wi;
             }
         }
     }
 
-    // price stepping; lane (g, c) owns steps nl .. nl+3 of path c in every tile
+    // ---- stages 3+LG .. 5+LG: index bits 2+LG .. 4+LG (t): butterflies between registers ----
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int nl = n_base + 16 * t + 4 * g;
-        double z[4];  // steps nl..nl+3 are exactly Philox block nl/4 of the price stream
-        fm::normal_quad_fast(a.k0, a.k1, id, (uint32_t)(nl >> 2), STREAM_PRICE, tab, z);
-        double pre[4];
-        double run = 0.0;
+    for (int bt = 0; bt < 3; ++bt) {
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const int n = nl + v;
-            const bool valid = n < a.n_steps;
-            const double var = fm::scaled_exp(a.xi, acc[t][v] + (valid ? comp[n] : 0.0));
-            const double sd = fm::sqrt_pos(fmax(var, 1e-300)) * a.sqdt;
-            const double inc = fma(sd, z[v], (a.r - 0.5 * var) * a.dt);
-            run += valid ? inc : 0.0;
-            pre[v] = run;
+        for (int tl = 0; tl < (1 << bt); ++tl) {  // t bits below bt
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int j = (((tl << LG) | g) << 2) | v;  // i0 mod 2^(s-1), s = 3 + LG + bt
+                const double2 w = L.tw[j << (2 - bt)];
+#pragma unroll
+                for (int th = 0; th < (4 >> bt); ++th) {  // t bits above bt
+                    const int t_lo = (th << (bt + 1)) | tl, t_up = t_lo | (1 << bt);
+                    const double ar = xr[t_lo * 4 + v], ai = xi[t_lo * 4 + v];
+                    const double br = xr[t_up * 4 + v], bi = xi[t_up * 4 + v];
+                    const double wr = w.x * br - w.y * bi, wi = w.x * bi + w.y * br;
+                    xr[t_lo * 4 + v] = ar + wr;
+                    xi[t_lo * 4 + v] = ai + wi;
+                    xr[t_up * 4 + v] = ar - wr;
+                    xi[t_up * 4 + v] = ai - wi;
+                }
+            }
         }
-        // inclusive scan of the group totals over g = 0..3 (lanes c, c+16, c+32, c+48)
-        double incl = run;
-        const double up16 = __shfl_up(incl, 16, 64);
-        if (g >= 1) incl += up16;
-        const double up32 = __shfl_up(incl, 32, 64);
-        if (g >= 2) incl += up32;
-        const double lead = logS + (incl - run);
-        const double tile_total = __shfl(incl, 48 + c, 64);
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const int n = nl + v;
-            const double S = fm::scaled_exp(1.0, lead + pre[v]);
-            if (live && n < a.n_steps) __builtin_nontemporal_store(S, col + (int64_t)(n + 1) * a.ld);
-        }
-        logS += tile_total;
     }
+    // now xr/xi[t*4+v] = Re/Im x_n, n = 4(tG + g) + v
+
+    // ---- price stepping, two paths per lane ----
+    lead = g == 0;
+    double* col = a.out + col_a;
+    if (lead) rb_store_pair(col, a.S0, a.S0, live_a, live_b);
+    double ls_a = a.logS0, ls_b = a.logS0;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        if (((t * G) << 2) < a.n_steps) {  // wave-uniform: the tile has at least one live step
+            const int nl = ((t * G + g) << 2);
+            double za[4], zb[4];  // steps nl..nl+3 are Philox block nl/4 of each path's price stream
+            fm::normal_quad_fast(a.k0, a.k1, id_a, (uint32_t)(nl >> 2), STREAM_PRICE, tabs, za);
+            fm::normal_quad_fast(a.k0, a.k1, id_b, (uint32_t)(nl >> 2), STREAM_PRICE, tabs, zb);
+            double pa[4], pb[4], run_a = 0.0, run_b = 0.0;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int n = nl + v;
+                const bool valid = n < a.n_steps;
+                const double cmp = valid ? L.comp[n] : 0.0;
+                const double var_a = fm::scaled_exp(a.xi, xr[t * 4 + v] + cmp);
+                const double var_b = fm::scaled_exp(a.xi, xi[t * 4 + v] + cmp);
+                const double sd_a = fm::sqrt_pos(fmax(var_a, 1e-300)) * a.sqdt;
+                const double sd_b = fm::sqrt_pos(fmax(var_b, 1e-300)) * a.sqdt;
+                const double inc_a = fma(sd_a, za[v], (a.r - 0.5 * var_a) * a.dt);
+                const double inc_b = fma(sd_b, zb[v], (a.r - 0.5 * var_b) * a.dt);
+                run_a += valid ? inc_a : 0.0;
+                run_b += valid ? inc_b : 0.0;
+                pa[v] = run_a;
+                pb[v] = run_b;
+            }
+            // inclusive scan of the lane totals over g = 0..G-1 (lanes c, c+P, c+2P, ...)
+            double inc_a = run_a, inc_b = run_b;
+#pragma unroll
+            for (int b = 0; b < LG; ++b) {
+                const double ua = __shfl_up(inc_a, P << b, 64), ub = __shfl_up(inc_b, P << b, 64);
+                if (g >= (1 << b)) {
+                    inc_a += ua;
+                    inc_b += ub;
+                }
+            }
+            const double lead_a = ls_a + (inc_a - run_a), lead_b = ls_b + (inc_b - run_b);
+            const double tot_a = __shfl(inc_a, (G - 1) * P + c, 64), tot_b = __shfl(inc_b, (G - 1) * P + c, 64);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int n = nl + v;
+                const double sa = fm::scaled_exp(1.0, lead_a + pa[v]);
+                const double sb = fm::scaled_exp(1.0, lead_b + pb[v]);
+                if (n < a.n_steps) rb_store_pair(col + (int64_t)(n + 1) * a.ld, sa, sb, live_a, live_b);
+            }
+            ls_a += tot_a;
+            ls_b += tot_b;
+        }
+    }
+    log_a = ls_a;
+    log_b = ls_b;
 }
 
-// One workgroup's share of the job: 64 paths (4 waves x 16), block `block_index` of the launch.
-// smem: (M + RB_PAD + n_steps) doubles of LDS; tabs: the math tables, loaded here.
-// Returns the final log-price of this lane's path; `live_lead` tells whether this lane is the one lane
-// of its path (lane group 0) that should contribute a payoff.
-__device__ __forceinline__ double rb_generate(const RbArgs& a, int64_t block_index, double* smem, fm::Tables* tabs,
-                                              bool& live_lead) {
-    const int M = a.M;
-    double* kext = smem;               // [M + RB_PAD], kext[i] = kappa[(i - 16) mod M]
-    double* comp = smem + M + RB_PAD;  // [n_steps]
-    for (int i = threadIdx.x; i < M + RB_PAD; i += 256) kext[i] = a.kappa[(i - 16 + 16 * M) & (M - 1)];
-    for (int i = threadIdx.x; i < a.n_steps; i += 256) comp[i] = a.comp[i];
-    fm::load_tables(tabs, a.log_tab);
-    __syncthreads();
-
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int g = lane >> 4, c = lane & 15;
-    const int64_t p = block_index * 64 + wave * 16 + c;
-    const bool live = p < a.n_paths;
-    const uint64_t id = a.path_begin + (uint64_t)p;
-    // A operand: this lane supplies row i = c, i.e. local step 4(c%4) + c/4, for k-slot g
-    // (noise index j = 16kq + 4g + e): weight index = step - j, shifted by the 16-entry extension
-    const int a_off = 4 * (c & 3) + (c >> 2) - 4 * g + 16;
-
-    double* col = a.out + p;
-    if (live && g == 0) __builtin_nontemporal_store(a.S0, col);
-    double logS = a.logS0;
-
-    int n_base = 0;
-    for (; n_base + RB_NT * 16 <= a.n_steps; n_base += RB_NT * 16)
-        rb_pass<RB_NT>(a, kext, comp, tabs, n_base, g, c, a_off, id, live, col, logS);
-    const int tiles_left = (a.n_steps - n_base + 15) >> 4;  // 0..RB_NT-1, wave-uniform
-    if (tiles_left > 8) rb_pass<16>(a, kext, comp, tabs, n_base, g, c, a_off, id, live, col, logS);
-    else if (tiles_left > 4) rb_pass<8>(a, kext, comp, tabs, n_base, g, c, a_off, id, live, col, logS);
-    else if (tiles_left > 2) rb_pass<4>(a, kext, comp, tabs, n_base, g, c, a_off, id, live, col, logS);
-    else if (tiles_left > 0) rb_pass<2>(a, kext, comp, tabs, n_base, g, c, a_off, id, live, col, logS);
-    live_lead = live && g == 0;
-    return logS;
+// Mz < 32 (at most 16 steps): one pair per lane, the transform evaluated directly.
+__device__ __forceinline__ void rb_generate_small(const RbArgs& a, int64_t block_index, double* smem, fm::Tables* tabs,
+                                                  double& log_a, double& log_b, bool& live_a, bool& live_b, bool& lead) {
+    const RbLds L = rb_stage_lds(a, smem, tabs);
+    const int M = a.M;  // 1, 2, 4, 8 or 16
+    const int64_t q = block_index * (int64_t)blockDim.x + threadIdx.x;
+    const int64_t col_a = 2 * q;
+    live_a = col_a < a.n_paths;
+    live_b = col_a + 1 < a.n_paths;
+    lead = true;
+    const uint64_t id_a = a.path_begin + (uint64_t)col_a, id_b = id_a + 1;
+    double yr[16], yi[16];
+#pragma unroll
+    for (int k = 0; k < 16; k += 2) {
+        double z[4] = {0.0, 0.0, 0.0, 0.0};
+        if (k < M) fm::normal_quad_fast(a.k0, a.k1, id_a >> 1, (uint32_t)(k >> 1), STREAM_VOL, tabs, z);
+        const double a0 = k < M ? L.amp[k] : 0.0, a1 = k + 1 < M ? L.amp[k + 1] : 0.0;
+        yr[k] = a0 * z[0];
+        yi[k] = a0 * z[1];
+        yr[k + 1] = a1 * z[2];
+        yi[k + 1] = a1 * z[3];
+    }
+    double* col = a.out + col_a;
+    rb_store_pair(col, a.S0, a.S0, live_a, live_b);
+    double ls_a = a.logS0, ls_b = a.logS0;
+    double za[4], zb[4];
+    for (int n = 0; n < a.n_steps; ++n) {
+        double re = 0.0, im = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            double s, c;
+            sincospi(2.0 * (double)((k * n) & (M - 1)) / (double)M, &s, &c);
+            re += yr[k] * c - yi[k] * s;
+            im += yr[k] * s + yi[k] * c;
+        }
+        if ((n & 3) == 0) {
+            fm::normal_quad_fast(a.k0, a.k1, id_a, (uint32_t)(n >> 2), STREAM_PRICE, tabs, za);
+            fm::normal_quad_fast(a.k0, a.k1, id_b, (uint32_t)(n >> 2), STREAM_PRICE, tabs, zb);
+        }
+        const double var_a = fm::scaled_exp(a.xi, re + L.comp[n]), var_b = fm::scaled_exp(a.xi, im + L.comp[n]);
+        ls_a += fma(fm::sqrt_pos(fmax(var_a, 1e-300)) * a.sqdt, za[n & 3], (a.r - 0.5 * var_a) * a.dt);
+        ls_b += fma(fm::sqrt_pos(fmax(var_b, 1e-300)) * a.sqdt, zb[n & 3], (a.r - 0.5 * var_b) * a.dt);
+        rb_store_pair(col + (int64_t)(n + 1) * a.ld, fm::scaled_exp(1.0, ls_a), fm::scaled_exp(1.0, ls_b), live_a, live_b);
+    }
+    log_a = ls_a;
+    log_b = ls_b;
 }
+
+// pairs handled by one 256-thread workgroup of the variant chosen for Mz
+__host__ __device__ inline int rb_pairs_per_block(int M) { return M < 32 ? 256 : 4 * (64 / (M / 32)); }
 
 }  // namespace mcg

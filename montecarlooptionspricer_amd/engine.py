@@ -274,14 +274,14 @@ def estimate_params(hist) -> dict:
     return dict(xi=out[0], H=out[1], eta=out[2], rho=out[3], S0=out[4])
 
 
-def rbergomi_weights(H: float, eta: float, dt: float, n_steps: int):
-    """(kappa[Mz], comp[n_steps]) -- the LDS-staged Volterra weights and compensator."""
+def rbergomi_spectrum(H: float, eta: float, dt: float, n_steps: int):
+    """(amp[Mz], comp[n_steps]) -- the LDS-staged spectral amplitudes and compensator."""
     L = N.load_library()
     M = 1
     while M < n_steps:
         M *= 2
-    kappa, comp, mz = np.empty(M), np.empty(n_steps), C.c_int()
-    check(L.mcg_rbergomi_weights(H, eta, dt, n_steps, kappa.ctypes.data_as(C.POINTER(C.c_double)),
-                                 comp.ctypes.data_as(C.POINTER(C.c_double)), C.byref(mz)))
+    amp, comp, mz = np.empty(M), np.empty(n_steps), C.c_int()
+    check(L.mcg_rbergomi_spectrum(H, eta, dt, n_steps, amp.ctypes.data_as(C.POINTER(C.c_double)),
+                                  comp.ctypes.data_as(C.POINTER(C.c_double)), C.byref(mz)))
     assert mz.value == M
-    return kappa, comp
+    return amp, comp

@@ -1,5 +1,5 @@
-// Host precompute of the Volterra weights the rBergomi kernel stages in LDS (row a3 of SURVEY.md
-// section 8: rbergomiLambda / rbergomiPhi / fft / nextPowerOfTwo, once per call, O(M^2) at M <= 4096).
+// Host precompute for the rBergomi kernels (row a3 of SURVEY.md section 8: rbergomiLambda / rbergomiPhi /
+// fft / nextPowerOfTwo, once per call): the spectral amplitudes a_k and the compensator table.
 //
 // What the reference does per path (/root/reference/src/models/RoughVolatility.cpp:264-292):
 //   A_k = phi_k * Z_k (k < steps, Z complex standard normal), zero-pad to Mz = nextpow2(steps),
@@ -7,13 +7,12 @@
 //   lambda_i = 0.5 * (i*dt)^(2H)                                             (:212-236, :337-343).
 // X is therefore a zero-mean stationary *circular* Gaussian sequence of period Mz with
 //   Cov(X_n, X_{n+d}) = (2H eta^2 / Mz^2) * sum_{k<steps} |phi_k|^2 cos(2 pi k d / Mz).
-// A Gaussian vector is fixed by its covariance, so any linear map of white noise with the same
-// covariance has the same law.  We use the real symmetric circular kernel
-//   kappa_m = (eta*sqrt(2H/Mz)/Mz) * sum_{k<Mz} sqrt((P_k + P_{Mz-k})/2) cos(2 pi k m / Mz),
-//   P_k = |phi_k|^2 (k < steps), 0 otherwise,
-// so that X_n = sum_j kappa_{(n-j) mod Mz} eps_j, eps ~ iid N(0,1) of length Mz per path: a
-// time-domain (Volterra) contraction against weights every lane shares.  The M_phi != M_z quirk
-// at power-of-two step counts (:217 vs :270) is inherited through phi.
+// A Gaussian vector is fixed by its covariance.  With P_k = |phi_k|^2 (k < steps, else 0) and the SYMMETRIC
+// amplitudes a_k = eta*sqrt(2H)/Mz * sqrt((P_k + P_{Mz-k})/2), the complex sequence
+//   x_n = sum_{k<Mz} a_k (g_k + i h_k) e^{+2 pi i k n/Mz},  g, h ~ iid N(0,1),
+// has Re x and Im x each with exactly that covariance and, by the symmetry of a_k, zero cross-covariance at
+// every lag: one transform yields two independent copies of the reference's X (rbergomi_device.hpp).
+// The M_phi != M_z quirk at power-of-two step counts (:217 vs :270) is inherited through phi.
 #include <cmath>
 #include <complex>
 #include <cstddef>
@@ -64,8 +63,8 @@ void dit_fft(std::vector<cd>& a, int sign) {
 
 namespace mcg {
 
-int host_rbergomi_weights(double H, double eta, double dt, int n_steps, std::vector<double>& kappa,
-                          std::vector<double>& comp) {
+int host_rbergomi_spectrum(double H, double eta, double dt, int n_steps, std::vector<double>& amp,
+                           std::vector<double>& comp) {
     if (n_steps < 1) return fail(MCG_ERR_INVALID, "n_steps must be >= 1");
     const size_t steps = (size_t)n_steps;
     // lambda on the grid t_i = i*dt, i = 0..steps, then phi (M_phi = nextpow2(steps+1))
@@ -74,20 +73,11 @@ int host_rbergomi_weights(double H, double eta, double dt, int n_steps, std::vec
     dit_fft(phi, +1);
 
     const size_t M = pow2_at_least(steps);  // M_z
-    std::vector<double> P(M, 0.0), amp(M);
+    std::vector<double> P(M, 0.0);
     for (size_t k = 0; k < steps && k < M; ++k) P[k] = std::norm(phi[k]);
-    for (size_t k = 0; k < M; ++k) amp[k] = std::sqrt(0.5 * (P[k] + P[(M - k) % M]));
-
-    // kappa = real inverse DFT of the (real, symmetric) amplitude spectrum
-    const double scale = eta * std::sqrt(2.0 * H / (double)M) / (double)M;
-    std::vector<double> ctab(M);
-    for (size_t q = 0; q < M; ++q) ctab[q] = std::cos(2.0 * kPi * (double)q / (double)M);
-    kappa.assign(M, 0.0);
-    for (size_t m = 0; m < M; ++m) {
-        double s = 0.0;
-        for (size_t k = 0; k < M; ++k) s += amp[k] * ctab[(k * m) & (M - 1)];
-        kappa[m] = scale * s;
-    }
+    const double scale = eta * std::sqrt(2.0 * H) / (double)M;
+    amp.resize(M);
+    for (size_t k = 0; k < M; ++k) amp[k] = scale * std::sqrt(0.5 * (P[k] + P[(M - k) % M]));
     // compensator of RoughVolatility.cpp:305 on t_n = n*dt
     comp.resize(steps);
     for (size_t n = 0; n < steps; ++n) comp[n] = -0.5 * eta * eta * std::pow(n * dt, 2 * H);

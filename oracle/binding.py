@@ -77,6 +77,8 @@ class Oracle:
         L.orc_paths_gbm.restype = C.c_int
         L.orc_rbergomi_weights.argtypes = [C.c_double, C.c_double, C.c_double, C.c_int, _dp, _dp]
         L.orc_rbergomi_weights.restype = C.c_size_t
+        L.orc_rbergomi_spectrum.argtypes = [C.c_double, C.c_double, C.c_double, C.c_int, _dp, _dp]
+        L.orc_rbergomi_spectrum.restype = C.c_size_t
         L.orc_paths_rbergomi.argtypes = [C.c_uint64] + [C.c_double] * 7 + [C.c_int, C.c_uint64, C.c_long,
                                                                           _dp, C.c_size_t, _dp]
         L.orc_paths_rbergomi.restype = C.c_int
@@ -210,6 +212,14 @@ class Oracle:
         comp = np.empty(steps)
         self.L.orc_rbergomi_weights(H, eta, dt, steps, _p(kappa), _p(comp))
         return kappa, comp
+
+    def rbergomi_spectrum(self, H, eta, dt, steps):
+        """(amp[Mz], comp[steps]): spectral amplitudes a_k and the compensator."""
+        M = self.next_pow2(steps)
+        amp = np.empty(M)
+        comp = np.empty(steps)
+        self.L.orc_rbergomi_spectrum(H, eta, dt, steps, _p(amp), _p(comp))
+        return amp, comp
 
     def paths_rbergomi(self, seed, S0, r, xi, H, eta, rho, dt, steps, path_begin, n_paths, want_X=False):
         out = np.empty((steps + 1, n_paths))

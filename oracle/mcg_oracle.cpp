@@ -540,33 +540,87 @@ size_t orc_rbergomi_weights(double H, double eta, double dt, int steps, double* 
     return M;
 }
 
+// Spectral amplitudes of the reference's X (RoughVolatility.cpp:264-292).  With P_k = |phi_k|^2 for k < steps
+// (0 for steps <= k < Mz), a_k = eta*sqrt(2H)/Mz * sqrt((P_k + P_{(Mz-k) mod Mz}) / 2) and
+// Y_k = a_k (g_k + i h_k), g, h ~ iid N(0,1),
+//   x_n = sum_{k<Mz} Y_k e^{+2 pi i k n / Mz}
+// is a complex stationary circular Gaussian sequence with
+//   Cov(Re x_n, Re x_{n+d}) = Cov(Im x_n, Im x_{n+d}) = sum_k a_k^2 cos(2 pi k d / Mz)
+//                           = (2H eta^2/Mz^2) sum_{k<steps} |phi_k|^2 cos(2 pi k d/Mz),
+// exactly the covariance of the reference's X, and -- because a_k is symmetric in
+// k <-> Mz-k -- Cov(Re x_n, Im x_{n+d}) = sum_k a_k^2 sin(2 pi k d/Mz) = 0 for every lag: the real and imaginary
+// parts are two INDEPENDENT copies of X.  One transform therefore serves a PAIR of paths:
+// Re x -> path 2q, Im x -> path 2q + 1.  amp gets Mz entries; comp_n = -0.5 eta^2 (n dt)^(2H) (:305).  Returns Mz.
+size_t orc_rbergomi_spectrum(double H, double eta, double dt, int steps, double* amp, double* comp) {
+    std::vector<double> lam(steps + 1);
+    orc_lambda(steps, H, dt, lam.data());
+    std::vector<double> phi(2 * next_pow2((size_t)steps + 1));
+    orc_phi(lam.data(), (size_t)steps + 1, phi.data());
+    const size_t M = next_pow2((size_t)steps);
+    std::vector<double> P(M, 0.0);
+    for (size_t k = 0; k < (size_t)steps && k < M; ++k) P[k] = phi[2 * k] * phi[2 * k] + phi[2 * k + 1] * phi[2 * k + 1];
+    const double scale = eta * std::sqrt(2.0 * H) / (double)M;
+    for (size_t k = 0; k < M; ++k) amp[k] = scale * std::sqrt(0.5 * (P[k] + P[(M - k) % M]));
+    for (int n = 0; n < steps; ++n) comp[n] = -0.5 * eta * eta * std::pow(n * dt, 2 * H);
+    return M;
+}
+
 // rBergomi paths, device algorithm (DESIGN.md "rBergomi kernel").  Step-major output as above.
-// If X_out != nullptr it receives X[p*steps + n] (for covariance tests).
+// Volatility driver of the pair q = (path id) >> 1: Philox stream 1 with the PAIR id in the path field;
+// block b holds (g_{2b}, h_{2b}, g_{2b+1}, h_{2b+1}).  Price driver per path: stream 0 as in GBM.
+// If X_out != nullptr it receives X[p*steps + n] (for covariance tests).  path_begin must be even.
 int orc_paths_rbergomi(uint64_t seed, double S0, double r, double xi, double H, double eta, double rho,
                        double dt, int steps, uint64_t path_begin, long n_paths, double* out, size_t ld,
                        double* X_out) {
     (void)rho;  // inert in the reference (W1, W2 independent of Z); kept for interface parity
-    if (steps < 1 || n_paths < 0) return 1;
+    if (steps < 1 || n_paths < 0 || (path_begin & 1)) return 1;
     const size_t M = next_pow2((size_t)steps);
-    std::vector<double> kappa(M), comp(steps), eps(M + 4);
-    orc_rbergomi_weights(H, eta, dt, steps, kappa.data(), comp.data());
+    std::vector<double> amp(M), comp(steps), yr(M + 2), yi(M + 2), ct(M), st(M);
+    orc_rbergomi_spectrum(H, eta, dt, steps, amp.data(), comp.data());
+    for (size_t q = 0; q < M; ++q) {
+        ct[q] = std::cos(2.0 * M_PI * (double)q / (double)M);
+        st[q] = std::sin(2.0 * M_PI * (double)q / (double)M);
+    }
     const double sqdt = std::sqrt(dt);
-    for (long p = 0; p < n_paths; ++p) {
-        const uint64_t id = path_begin + p;
-        for (size_t j = 0; j < M; j += 4) normal_quad(seed, id, (uint32_t)(j >> 2), STREAM_VOL, &eps[j]);
-        double S = S0;
-        out[p] = S;
-        double z[4] = {0, 0, 0, 0};
+    std::vector<double> XA(steps), XB(steps);
+    for (long p0 = 0; p0 < n_paths; p0 += 2) {
+        const uint64_t pair = (path_begin + (uint64_t)p0) >> 1;
+        for (size_t k = 0; k < M; k += 2) {
+            double z[4];
+            normal_quad(seed, pair, (uint32_t)(k >> 1), STREAM_VOL, z);
+            yr[k] = amp[k] * z[0];
+            yi[k] = amp[k] * z[1];
+            if (k + 1 < M) {
+                yr[k + 1] = amp[k + 1] * z[2];
+                yi[k + 1] = amp[k + 1] * z[3];
+            }
+        }
         for (int n = 0; n < steps; ++n) {
-            double X = 0.0;
-            for (size_t j = 0; j < M; ++j) X = std::fma(kappa[((size_t)n - j) & (M - 1)], eps[j], X);
-            if (X_out) X_out[(size_t)p * steps + n] = X;
-            const double v = xi * std::exp(X + comp[n]);
-            if ((n & 3) == 0) normal_quad(seed, id, (uint32_t)(n >> 2), STREAM_PRICE, z);
-            const double drift = (r - 0.5 * v) * dt;
-            const double sd = std::sqrt(std::max(0.0, v)) * sqdt;
-            S = S * std::exp(std::fma(sd, z[n & 3], drift));
-            out[(size_t)(n + 1) * ld + p] = S;
+            double re = 0.0, im = 0.0;
+            for (size_t k = 0; k < M; ++k) {
+                const size_t qi = (k * (size_t)n) & (M - 1);
+                re += yr[k] * ct[qi] - yi[k] * st[qi];
+                im += yr[k] * st[qi] + yi[k] * ct[qi];
+            }
+            XA[n] = re;
+            XB[n] = im;
+        }
+        for (int h = 0; h < 2 && p0 + h < n_paths; ++h) {
+            const long p = p0 + h;
+            const uint64_t id = path_begin + (uint64_t)p;
+            const std::vector<double>& X = h ? XB : XA;
+            double S = S0;
+            out[p] = S;
+            double z[4] = {0, 0, 0, 0};
+            for (int n = 0; n < steps; ++n) {
+                if (X_out) X_out[(size_t)p * steps + n] = X[n];
+                const double v = xi * std::exp(X[n] + comp[n]);
+                if ((n & 3) == 0) normal_quad(seed, id, (uint32_t)(n >> 2), STREAM_PRICE, z);
+                const double drift = (r - 0.5 * v) * dt;
+                const double sd = std::sqrt(std::max(0.0, v)) * sqdt;
+                S = S * std::exp(std::fma(sd, z[n & 3], drift));
+                out[(size_t)(n + 1) * ld + p] = S;
+            }
         }
     }
     return 0;
