@@ -28,7 +28,7 @@ __device__ __forceinline__ void rb_finish(const RbArgs& a, double log_a, double 
 }
 
 template <int LG, bool PAYOFF>
-__global__ __launch_bounds__(256) void k_rbergomi_fft(RbArgs a) {
+__global__ __launch_bounds__(256, 2) void k_rbergomi_fft(RbArgs a) {  // 2 waves/SIMD: at most 256 VGPRs
     extern __shared__ double smem[];
     __shared__ fm::Tables tabs;
     double la, lb;
