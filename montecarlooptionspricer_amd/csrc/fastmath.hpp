@@ -77,6 +77,26 @@ __device__ __forceinline__ double scaled_exp(double S, double a) {
     return v;
 }
 
+// e^a with the range reduction always on (no wave-uniform test): for arguments that are rarely all small,
+// e.g. the log-variance and log-price of the rBergomi kernels.
+__device__ __forceinline__ double exp_full(double a) {
+    const double kd = __builtin_rint(a * 0x1.71547652b82fep+0);
+    double r = __builtin_fma(kd, -0x1.62e42fee00000p-1, a);
+    r = __builtin_fma(kd, -0x1.a39ef35793c76p-33, r);
+    double q = 0x1.af38a9b0ec855p-26;
+    q = fma_sc(q, r, 0x1.289185613a3d6p-22);
+    q = fma_sc(q, r, 0x1.71de0dae63bb3p-19);
+    q = fma_sc(q, r, 0x1.a019b90d2ae7ap-16);
+    q = fma_sc(q, r, 0x1.a01a01a7c41d5p-13);
+    q = fma_sc(q, r, 0x1.6c16c1788bd90p-10);
+    q = fma_sc(q, r, 0x1.11111111109b3p-7);
+    q = fma_sc(q, r, 0x1.5555555553d63p-5);
+    q = fma_sc(q, r, 0x1.5555555555556p-3);
+    q = fma_sc(q, r, 0x1.0000000000001p-1);
+    const double em1 = __builtin_fma(r * r, q, r);
+    return __builtin_ldexp(1.0 + em1, (int)kd);
+}
+
 // S * e^a for |a| <= 0.125, guaranteed by the caller from the step's parameters (a GBM step has
 // |a| <= |drift| + vol * 7.55: the 40-bit radius uniform caps |z| at sqrt(2*41*ln2) = 7.54).  No range
 // reduction, no branch; e^a = 1 + a + a^2 q(a) with q of degree 7 (max rel err 2^-58.7 on the interval).

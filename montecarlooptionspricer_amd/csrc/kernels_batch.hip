@@ -120,12 +120,12 @@ __global__ __launch_bounds__(256) void k_batch_paths(BatchArgs a, int blocks_per
     double la, lb;
     bool va, vb, lead;
     switch (row.M) {  // wave-uniform
-        case 32: rb_generate_fft<0>(g, sub, smem, &tabs, la, lb, va, vb, lead); break;
-        case 64: rb_generate_fft<1>(g, sub, smem, &tabs, la, lb, va, vb, lead); break;
-        case 128: rb_generate_fft<2>(g, sub, smem, &tabs, la, lb, va, vb, lead); break;
-        case 256: rb_generate_fft<3>(g, sub, smem, &tabs, la, lb, va, vb, lead); break;
-        case 512: rb_generate_fft<4>(g, sub, smem, &tabs, la, lb, va, vb, lead); break;
-        case 1024: rb_generate_fft<5>(g, sub, smem, &tabs, la, lb, va, vb, lead); break;
+        case 32: rb_generate_fft<0 + 3 - RB_LT_DEFAULT, RB_LT_DEFAULT>(g, sub, smem, &tabs, la, lb, va, vb, lead); break;
+        case 64: rb_generate_fft<1 + 3 - RB_LT_DEFAULT, RB_LT_DEFAULT>(g, sub, smem, &tabs, la, lb, va, vb, lead); break;
+        case 128: rb_generate_fft<2 + 3 - RB_LT_DEFAULT, RB_LT_DEFAULT>(g, sub, smem, &tabs, la, lb, va, vb, lead); break;
+        case 256: rb_generate_fft<3 + 3 - RB_LT_DEFAULT, RB_LT_DEFAULT>(g, sub, smem, &tabs, la, lb, va, vb, lead); break;
+        case 512: rb_generate_fft<4 + 3 - RB_LT_DEFAULT, RB_LT_DEFAULT>(g, sub, smem, &tabs, la, lb, va, vb, lead); break;
+        case 1024: rb_generate_fft<5 + 3 - RB_LT_DEFAULT, RB_LT_DEFAULT>(g, sub, smem, &tabs, la, lb, va, vb, lead); break;
         default: rb_generate_small(g, sub, smem, &tabs, la, lb, va, vb, lead); break;
     }
 }
@@ -446,7 +446,8 @@ int run_batch_rows(mcg_ctx* ctx, const mcg_row* rows, int64_t n_rows, int n_path
     }
     const int mphi_max = 2 * m_max >= 2 ? 2 * m_max : 2;
     const size_t smem_w = ((size_t)2 * mphi_max + (size_t)max_steps + 1 + (size_t)m_max) * sizeof(double);
-    const size_t smem_p = ((size_t)m_max + (size_t)max_steps + 2 * (size_t)(m_max / 2 + 1)) * sizeof(double);
+    size_t smem_p = 0;  // largest over the transform sizes present (the staging part does not grow with Mz)
+    for (int m = 1; m <= m_max; m <<= 1) smem_p = std::max(smem_p, rb_smem_bytes(m, std::min(m, max_steps)));
     const size_t smem_c = ((size_t)max_steps + 1) * sizeof(double);
     // workgroups per row: enough for the row with the fewest pairs per workgroup (the largest Mz)
     const int n_pairs = (n_paths + 1) / 2;
@@ -455,6 +456,8 @@ int run_batch_rows(mcg_ctx* ctx, const mcg_row* rows, int64_t n_rows, int n_path
     {
         TimedLaunch t(ctx, MCG_K_BATCH);
         hipLaunchKernelGGL(k_batch_weights, dim3((unsigned)n_rows), dim3(256), smem_w, ctx->stream, a);
+        if (smem_p > 48 * 1024)
+            (void)hipFuncSetAttribute((const void*)k_batch_paths, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_p);
         hipLaunchKernelGGL(k_batch_paths, dim3((unsigned)(n_rows * bpr)), dim3(256), smem_p, ctx->stream, a, bpr);
         hipLaunchKernelGGL(k_batch_asym, dim3((unsigned)n_rows), dim3(256), 2 * smem_c, ctx->stream, a);
         hipLaunchKernelGGL(k_batch_branching, dim3((unsigned)n_rows), dim3(256), smem_c, ctx->stream, a);

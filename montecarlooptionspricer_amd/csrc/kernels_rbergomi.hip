@@ -27,13 +27,16 @@ __device__ __forceinline__ void rb_finish(const RbArgs& a, double log_a, double 
     }
 }
 
-template <int LG, bool PAYOFF>
-__global__ __launch_bounds__(256, 2) void k_rbergomi_fft(RbArgs a) {  // 2 waves/SIMD: at most 256 VGPRs
+#ifndef RB_WAVES
+#define RB_WAVES 2
+#endif
+template <int LG, int LT, bool PAYOFF>
+__global__ __launch_bounds__(256, RB_WAVES) void k_rbergomi_fft(RbArgs a) {
     extern __shared__ double smem[];
     __shared__ fm::Tables tabs;
     double la, lb;
     bool va, vb, lead;
-    rb_generate_fft<LG>(a, (int64_t)blockIdx.x, smem, &tabs, la, lb, va, vb, lead);
+    rb_generate_fft<LG, LT>(a, (int64_t)blockIdx.x, smem, &tabs, la, lb, va, vb, lead);
     rb_finish<PAYOFF>(a, la, lb, va, vb, lead);
 }
 
@@ -47,18 +50,38 @@ __global__ __launch_bounds__(256) void k_rbergomi_small(RbArgs a) {
     rb_finish<PAYOFF>(a, la, lb, va, vb, lead);
 }
 
+// gfx950 allows a workgroup up to 160 KB of LDS, but beyond 64 KB of dynamic LDS the kernel has to opt in
+#define MCG_RB_LAUNCH(LG)                                                                                      \
+    do {                                                                                                       \
+        if (smem > 48 * 1024)                                                                                  \
+            (void)hipFuncSetAttribute((const void*)k_rbergomi_fft<LG, LT, PAYOFF>,                             \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                  \
+        hipLaunchKernelGGL((k_rbergomi_fft<LG, LT, PAYOFF>), g, b, smem, ctx->stream, a);                      \
+    } while (0)
+
+template <int LT, bool PAYOFF>
+static void launch_fft(mcg_ctx* ctx, const RbArgs& a, dim3 g, dim3 b, size_t smem) {
+    switch (a.M >> (2 + LT)) {  // lanes per pair
+        case 1: MCG_RB_LAUNCH(0); break;
+        case 2: MCG_RB_LAUNCH(1); break;
+        case 4: MCG_RB_LAUNCH(2); break;
+        case 8: MCG_RB_LAUNCH(3); break;
+        case 16: MCG_RB_LAUNCH(4); break;
+        case 32: MCG_RB_LAUNCH(5); break;
+        default: MCG_RB_LAUNCH(6); break;
+    }
+}
+#undef MCG_RB_LAUNCH
+
 template <bool PAYOFF>
 static void launch_variant(mcg_ctx* ctx, const RbArgs& a, unsigned grid, size_t smem) {
     const dim3 g(grid), b(256);
-    switch (a.M) {
-        case 32: hipLaunchKernelGGL((k_rbergomi_fft<0, PAYOFF>), g, b, smem, ctx->stream, a); break;
-        case 64: hipLaunchKernelGGL((k_rbergomi_fft<1, PAYOFF>), g, b, smem, ctx->stream, a); break;
-        case 128: hipLaunchKernelGGL((k_rbergomi_fft<2, PAYOFF>), g, b, smem, ctx->stream, a); break;
-        case 256: hipLaunchKernelGGL((k_rbergomi_fft<3, PAYOFF>), g, b, smem, ctx->stream, a); break;
-        case 512: hipLaunchKernelGGL((k_rbergomi_fft<4, PAYOFF>), g, b, smem, ctx->stream, a); break;
-        case 1024: hipLaunchKernelGGL((k_rbergomi_fft<5, PAYOFF>), g, b, smem, ctx->stream, a); break;
-        case 2048: hipLaunchKernelGGL((k_rbergomi_fft<6, PAYOFF>), g, b, smem, ctx->stream, a); break;
-        default: hipLaunchKernelGGL(k_rbergomi_small<PAYOFF>, g, b, smem, ctx->stream, a); break;  // Mz < 32
+    if (a.M < 32) hipLaunchKernelGGL(k_rbergomi_small<PAYOFF>, g, b, smem, ctx->stream, a);
+    else if (rb_log_tiles(a.M) == 2) launch_fft<2, PAYOFF>(ctx, a, g, b, smem);
+    else {  // Mz = 2048: 64 lanes x 32 points
+        if (smem > 48 * 1024)
+            (void)hipFuncSetAttribute((const void*)k_rbergomi_fft<6, 3, PAYOFF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipLaunchKernelGGL((k_rbergomi_fft<6, 3, PAYOFF>), g, b, smem, ctx->stream, a);
     }
 }
 
@@ -108,7 +131,7 @@ int launch_rbergomi(mcg_ctx* ctx, mcg_paths* P, uint64_t seed, double S0, double
     a.K = K;
     a.is_call = is_call;
     a.partials = ctx->partials;
-    const size_t smem = ((size_t)M + (size_t)P->n_steps + 2 * (size_t)(M / 2 + 1)) * sizeof(double);
+    const size_t smem = rb_smem_bytes(M, P->n_steps);
     {
         TimedLaunch t(ctx, MCG_K_RBERGOMI);
         if (want_payoff) launch_variant<true>(ctx, a, (unsigned)n_blocks, smem);

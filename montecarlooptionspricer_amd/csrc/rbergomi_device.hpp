@@ -44,13 +44,34 @@ struct RbArgs {
     double* partials;
 };
 
-// LDS carve-up shared by all variants: amp[M] | comp[n_steps] | twiddle (cos, sin)(2 pi q / M), q < max(M/2, 1)
-__device__ __forceinline__ size_t rb_smem_doubles(int M, int n_steps) { return (size_t)M + n_steps + 2 * (size_t)(M / 2 + 1); }
+// Transform points per lane = 4 * 2^LT.  16 points (64 data VGPRs) keep the kernel at 2 waves/SIMD with no
+// spills; 32 points only where 64 lanes x 16 points do not cover the transform (Mz = 2048).
+#ifndef RB_LT_DEFAULT
+#define RB_LT_DEFAULT 2
+#endif
+__host__ __device__ inline int rb_log_tiles(int M) { return M > (64 * 4 << RB_LT_DEFAULT) ? 3 : RB_LT_DEFAULT; }
+// pairs handled by one 256-thread workgroup of the variant chosen for Mz
+__host__ __device__ inline int rb_pairs_per_block(int M) { return M < 32 ? 256 : 4 * (64 / (M >> (2 + rb_log_tiles(M)))); }
+
+// Output staging (FFT variants): one 4G-step tile of the workgroup's pairs, [4G rows][pairs + 1 pad] double2,
+// double-buffered while LDS allows (LT = 2), so that the step-major rows leave as (pairs * 16)-byte runs
+// instead of one 16-byte piece per lane.
+__host__ __device__ inline int rb_stage_bufs(int M) { return rb_log_tiles(M) == 2 ? 2 : 1; }
+__host__ __device__ inline size_t rb_stage_units(int M) {  // double2 units per buffer
+    return M < 32 ? 0 : (size_t)(M >> rb_log_tiles(M)) * (size_t)(rb_pairs_per_block(M) + 1);
+}
+
+// LDS carve-up shared by all variants: amp[M] | comp[n_steps] | twiddle (cos, sin)(2 pi q / M), q < max(M/2, 1) | staging
+__host__ __device__ inline size_t rb_smem_bytes(int M, int n_steps) {
+    const size_t head = (size_t)M + n_steps + ((M + n_steps) & 1);
+    return (head + 2 * (size_t)(M / 2 + 1) + 2 * rb_stage_bufs(M) * rb_stage_units(M)) * sizeof(double);
+}
 
 struct RbLds {
     const double* amp;
     const double* comp;
     const double2* tw;
+    double2* stage;
 };
 
 __device__ __forceinline__ RbLds rb_stage_lds(const RbArgs& a, double* smem, fm::Tables* tabs) {
@@ -67,12 +88,15 @@ __device__ __forceinline__ RbLds rb_stage_lds(const RbArgs& a, double* smem, fm:
     }
     fm::load_tables(tabs, a.log_tab);
     __syncthreads();
-    return RbLds{amp, comp, tw};
+    return RbLds{amp, comp, tw, tw + (M / 2 + 1)};
 }
 
 // {S_A, S_B} -> out[col_a], out[col_a + 1] (col_a even, rows 16-byte aligned)
 __device__ __forceinline__ void rb_store_pair(double* row_a, double sa, double sb, bool live_a, bool live_b) {
     typedef double v2d __attribute__((ext_vector_type(2)));
+#ifdef RB_NO_STORE
+    if (sa != 12345.678) return;
+#endif
     if (live_b) {
         v2d v = {sa, sb};
         __builtin_nontemporal_store(v, reinterpret_cast<v2d*>(row_a));
@@ -81,15 +105,24 @@ __device__ __forceinline__ void rb_store_pair(double* row_a, double sa, double s
     }
 }
 
-__device__ __forceinline__ constexpr int rb_rev3(int t) { return ((t & 1) << 2) | (t & 2) | ((t >> 2) & 1); }
+// bit reversal of the low LT bits of t (LT = 2 or 3)
+template <int LT>
+__device__ __forceinline__ constexpr int rb_rev(int t) {
+    return LT == 3 ? (((t & 1) << 2) | (t & 2) | ((t >> 2) & 1)) : (((t & 1) << 1) | ((t >> 1) & 1));
+}
 
-// One workgroup's share: 4 waves x (64 >> LG) path pairs.  Returns through log_a/log_b the final log-prices of
-// this lane's pair; lead = this lane is the one lane (g == 0) that reports the pair's payoff.
-template <int LG>
+// One workgroup's share: 4 waves x (64 >> LG) path pairs, 4 * 2^LT transform points per lane
+// (Mz = 2^(2 + LG + LT)).  Returns through log_a/log_b the final log-prices of this lane's pair;
+// lead = this lane is the one lane (g == 0) that reports the pair's payoff.
+template <int LG, int LT>
 __device__ __forceinline__ void rb_generate_fft(const RbArgs& a, int64_t block_index, double* smem, fm::Tables* tabs,
                                                 double& log_a, double& log_b, bool& live_a, bool& live_b, bool& lead) {
     constexpr int G = 1 << LG;   // lanes per pair
     constexpr int P = 64 >> LG;  // pairs per wave
+    constexpr int NT = 1 << LT;  // 4-step tiles per lane
+    constexpr int PW = 4 * P;    // pairs per workgroup
+    constexpr int RS = PW + 1;   // staging row stride in 16-byte units (one unit of padding)
+    constexpr int NBUF = LT == 2 ? 2 : 1;
     const RbLds L = rb_stage_lds(a, smem, tabs);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> (6 - LG), c = lane & (P - 1);
@@ -101,18 +134,18 @@ __device__ __forceinline__ void rb_generate_fft(const RbArgs& a, int64_t block_i
     const uint64_t pair_id = id_a >> 1;
 
     // ---- spectrum, in bit-reversed order: slot (t, v) of lane g holds Y_k, k = rev(4(tG + g) + v) ----
-    double xr[32], xi[32];
+    double xr[4 * NT], xi[4 * NT];
     const int g_rev = LG ? (int)(__brev((unsigned)g) >> (32 - LG)) : 0;
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
         const int v_rev = ((v & 1) << 1) | (v >> 1);
-        const int k_base = (v_rev << (3 + LG)) | (g_rev << 3);  // 8 consecutive k: k_base + rev3(t)
+        const int k_base = (v_rev << (LT + LG)) | (g_rev << LT);  // NT consecutive k: k_base + rev(t)
 #pragma unroll
-        for (int bq = 0; bq < 4; ++bq) {
+        for (int bq = 0; bq < NT / 2; ++bq) {
             double z[4];
             fm::normal_quad_fast(a.k0, a.k1, pair_id, (uint32_t)((k_base >> 1) + bq), STREAM_VOL, tabs, z);
             const double a0 = L.amp[k_base + 2 * bq], a1 = L.amp[k_base + 2 * bq + 1];
-            const int t0 = rb_rev3(2 * bq), t1 = rb_rev3(2 * bq + 1);
+            const int t0 = rb_rev<LT>(2 * bq), t1 = rb_rev<LT>(2 * bq + 1);
             xr[t0 * 4 + v] = a0 * z[0];
             xi[t0 * 4 + v] = a0 * z[1];
             xr[t1 * 4 + v] = a1 * z[2];
@@ -122,7 +155,7 @@ __device__ __forceinline__ void rb_generate_fft(const RbArgs& a, int64_t block_i
 
     // ---- stages 1, 2: index bits 0, 1 (v), twiddles 1 and i ----
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
+    for (int t = 0; t < NT; ++t) {
 #pragma unroll
         for (int v = 0; v < 4; v += 2) {
             const double ar = xr[t * 4 + v], ai = xi[t * 4 + v], br = xr[t * 4 + v + 1], bi = xi[t * 4 + v + 1];
@@ -148,38 +181,41 @@ __device__ __forceinline__ void rb_generate_fft(const RbArgs& a, int64_t block_i
     }
 
     // ---- stages 3 .. 2+LG: index bits 2 .. 1+LG (the lane bits): butterflies between lanes ----
+    // A butterfly (lo, up) -> (lo + w up, lo - w up) has its two ends in lanes g and g ^ 2^b.  Each lane first
+    // multiplies its own value by w_eff (w in the upper lane, 1 in the lower), the lanes swap, and the result is
+    // partner + sgn * own (sgn = +1 lower, -1 upper): no per-element selects.
 #pragma unroll
     for (int b = 0; b < LG; ++b) {
         const bool upper = ((g >> b) & 1) != 0;
+        const double sgn = upper ? -1.0 : 1.0;
         const int delta = P << b;
         const int j_hi = (g & ((1 << b) - 1)) << 2;  // twiddle exponent j = j_hi | v, stage s = 3 + b
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-            const double2 w = L.tw[(j_hi | v) << (2 + LG - b)];
+            const double2 w = L.tw[(j_hi | v) << (LG + LT - 1 - b)];
+            const double wx = upper ? w.x : 1.0, wy = upper ? w.y : 0.0;
 #pragma unroll
-            for (int t = 0; t < 8; ++t) {
+            for (int t = 0; t < NT; ++t) {
                 const double mr = xr[t * 4 + v], mi = xi[t * 4 + v];
-                const double pr = __shfl_xor(mr, delta, 64), pi = __shfl_xor(mi, delta, 64);
-                const double ar = upper ? pr : mr, ai = upper ? pi : mi;  // lower element of the butterfly
-                const double br = upper ? mr : pr, bi = upper ? mi : pi;  // upper element
-                const double wr = w.x * br - w.y * bi, wi = w.x * bi + w.y * br;
-                xr[t * 4 + v] = upper ? ar - wr : ar + wr;
-                xi[t * 4 + v] = upper ? ai - wi : ai + wi;
+                const double tr = wx * mr - wy * mi, ti = wx * mi + wy * mr;
+                const double pr = __shfl_xor(tr, delta, 64), pi = __shfl_xor(ti, delta, 64);
+                xr[t * 4 + v] = fma(sgn, tr, pr);
+                xi[t * 4 + v] = fma(sgn, ti, pi);
             }
         }
     }
 
-    // ---- stages 3+LG .. 5+LG: index bits 2+LG .. 4+LG (t): butterflies between registers ----
+    // ---- stages 3+LG .. 2+LG+LT: index bits 2+LG .. (t): butterflies between registers ----
 #pragma unroll
-    for (int bt = 0; bt < 3; ++bt) {
+    for (int bt = 0; bt < LT; ++bt) {
 #pragma unroll
         for (int tl = 0; tl < (1 << bt); ++tl) {  // t bits below bt
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 const int j = (((tl << LG) | g) << 2) | v;  // i0 mod 2^(s-1), s = 3 + LG + bt
-                const double2 w = L.tw[j << (2 - bt)];
+                const double2 w = L.tw[j << (LT - 1 - bt)];
 #pragma unroll
-                for (int th = 0; th < (4 >> bt); ++th) {  // t bits above bt
+                for (int th = 0; th < (NT / 2 >> bt); ++th) {  // t bits above bt
                     const int t_lo = (th << (bt + 1)) | tl, t_up = t_lo | (1 << bt);
                     const double ar = xr[t_lo * 4 + v], ai = xi[t_lo * 4 + v];
                     const double br = xr[t_up * 4 + v], bi = xi[t_up * 4 + v];
@@ -199,10 +235,12 @@ __device__ __forceinline__ void rb_generate_fft(const RbArgs& a, int64_t block_i
     double* col = a.out + col_a;
     if (lead) rb_store_pair(col, a.S0, a.S0, live_a, live_b);
     double ls_a = a.logS0, ls_b = a.logS0;
+    const double sq_xi_dt = sqrt(a.xi) * a.sqdt;  // sqrt(xi dt)
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
+    for (int t = 0; t < NT; ++t) {
         if (((t * G) << 2) < a.n_steps) {  // wave-uniform: the tile has at least one live step
             const int nl = ((t * G + g) << 2);
+            double2* stage = L.stage + (NBUF == 2 ? (t & 1) * (4 * G * RS) : 0);
             double za[4], zb[4];  // steps nl..nl+3 are Philox block nl/4 of each path's price stream
             fm::normal_quad_fast(a.k0, a.k1, id_a, (uint32_t)(nl >> 2), STREAM_PRICE, tabs, za);
             fm::normal_quad_fast(a.k0, a.k1, id_b, (uint32_t)(nl >> 2), STREAM_PRICE, tabs, zb);
@@ -212,12 +250,11 @@ __device__ __forceinline__ void rb_generate_fft(const RbArgs& a, int64_t block_i
                 const int n = nl + v;
                 const bool valid = n < a.n_steps;
                 const double cmp = valid ? L.comp[n] : 0.0;
-                const double var_a = fm::scaled_exp(a.xi, xr[t * 4 + v] + cmp);
-                const double var_b = fm::scaled_exp(a.xi, xi[t * 4 + v] + cmp);
-                const double sd_a = fm::sqrt_pos(fmax(var_a, 1e-300)) * a.sqdt;
-                const double sd_b = fm::sqrt_pos(fmax(var_b, 1e-300)) * a.sqdt;
-                const double inc_a = fma(sd_a, za[v], (a.r - 0.5 * var_a) * a.dt);
-                const double inc_b = fma(sd_b, zb[v], (a.r - 0.5 * var_b) * a.dt);
+                // sqrt(v) = sqrt(xi) e^{(X + comp)/2}: one exponential gives both v and sqrt(v dt)
+                const double ea = fm::exp_full(0.5 * (xr[t * 4 + v] + cmp)), eb = fm::exp_full(0.5 * (xi[t * 4 + v] + cmp));
+                const double var_a = a.xi * (ea * ea), var_b = a.xi * (eb * eb);
+                const double inc_a = fma(sq_xi_dt * ea, za[v], (a.r - 0.5 * var_a) * a.dt);
+                const double inc_b = fma(sq_xi_dt * eb, zb[v], (a.r - 0.5 * var_b) * a.dt);
                 run_a += valid ? inc_a : 0.0;
                 run_b += valid ? inc_b : 0.0;
                 pa[v] = run_a;
@@ -237,13 +274,26 @@ __device__ __forceinline__ void rb_generate_fft(const RbArgs& a, int64_t block_i
             const double tot_a = __shfl(inc_a, (G - 1) * P + c, 64), tot_b = __shfl(inc_b, (G - 1) * P + c, 64);
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
-                const int n = nl + v;
-                const double sa = fm::scaled_exp(1.0, lead_a + pa[v]);
-                const double sb = fm::scaled_exp(1.0, lead_b + pb[v]);
-                if (n < a.n_steps) rb_store_pair(col + (int64_t)(n + 1) * a.ld, sa, sb, live_a, live_b);
+                const double sa = fm::exp_full(lead_a + pa[v]);
+                const double sb = fm::exp_full(lead_b + pb[v]);
+                stage[(4 * g + v) * RS + wave * P + c] = make_double2(sa, sb);
             }
             ls_a += tot_a;
             ls_b += tot_b;
+            __syncthreads();
+            // write-out: the tile is 4G rows x PW pairs = 1024 16-byte units, four per thread; a wavefront store
+            // covers 64 / PW complete rows of PW * 16 contiguous bytes
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int u = i * 256 + (int)threadIdx.x;
+                const int row = u / PW, pc = u % PW;
+                const int n = ((t * G) << 2) + row;
+                const int64_t colp = 2 * (block_index * PW + pc);
+                const double2 sv = stage[row * RS + pc];
+                if (n < a.n_steps)
+                    rb_store_pair(a.out + colp + (int64_t)(n + 1) * a.ld, sv.x, sv.y, colp < a.n_paths, colp + 1 < a.n_paths);
+            }
+            if (NBUF == 1) __syncthreads();
         }
     }
     log_a = ls_a;
@@ -297,8 +347,5 @@ __device__ __forceinline__ void rb_generate_small(const RbArgs& a, int64_t block
     log_a = ls_a;
     log_b = ls_b;
 }
-
-// pairs handled by one 256-thread workgroup of the variant chosen for Mz
-__host__ __device__ inline int rb_pairs_per_block(int M) { return M < 32 ? 256 : 4 * (64 / (M / 32)); }
 
 }  // namespace mcg

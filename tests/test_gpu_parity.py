@@ -140,7 +140,8 @@ def test_gbm_martingale_property_large(eng):
 RB = dict(S0=100.0, r=0.04, xi=0.04, H=0.1, eta=1.9, rho=-0.9)
 
 
-@pytest.mark.parametrize("n_paths,n_steps", [(192, 64), (100, 252), (70, 7), (65, 1), (64, 512)])
+@pytest.mark.parametrize("n_paths,n_steps", [(192, 64), (100, 252), (70, 7), (65, 1), (64, 512), (41, 17), (21, 33), (33, 100),
+                                             (7, 1000), (5, 2048), (600, 16)])
 def test_rbergomi_paths_match_oracle(eng, orc, n_paths, n_steps):
     P = eng.rbergomi(SEED, RB["S0"], RB["r"], RB["xi"], RB["H"], RB["eta"], RB["rho"], DT, n_steps, n_paths,
                      path_begin=998)
