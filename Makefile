@@ -7,9 +7,8 @@ PKG     := montecarlooptionspricer_amd
 OBJDIR  := build/obj
 LIB     := $(PKG)/lib/libmcgpu.so
 
-# -amdgpu-mfma-vgpr-form: keep MFMA accumulators in VGPRs (gfx950 has a unified file); without it hipcc
-# parks the fp64 accumulators in AGPRs and copies all of them to VGPRs and back on every loop trip
-HIPFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Iinclude -Wall -Wno-unused-function -mllvm -amdgpu-mfma-vgpr-form $(HIPFLAGS_EXTRA)
+# HIPFLAGS_EXTRA: experiment switches (e.g. -DRB_NO_STORE, -DRB_WAVES=3), empty for the product build
+HIPFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Iinclude -Wall -Wno-unused-function $(HIPFLAGS_EXTRA)
 # host-only TUs: no FMA contraction so the estimators match the reference bit for bit
 HOSTFLAGS := -O2 -std=c++17 -fPIC -ffp-contract=off -Iinclude -Wall -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include
 

@@ -29,7 +29,7 @@ struct BatchArgs {
     int n_paths, max_steps, m_max;
     double r, dt, sqdt, disc;  // disc = exp(-r dt)
     uint32_t k0, k1;
-    double* kappa;  // [n_rows][m_max] spectral amplitudes a_k of each row
+    double* amp;  // [n_rows][m_max] spectral amplitudes a_k of each row
     double* comp;   // [n_rows][max_steps]
     double* S;      // [(max_steps+1)][ld]
     double* F;      // same shape (branching suffix maxima)
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void k_batch_weights(BatchArgs a) {
     __syncthreads();
     // a_k = eta sqrt(2H)/M * sqrt((P_k + P_{M-k})/2): the symmetric spectral amplitudes of host/volterra.cpp
     const double scale = row.eta * sqrt(2.0 * row.H) / (double)M;
-    double* amp = a.kappa + (int64_t)blockIdx.x * a.m_max;
+    double* amp = a.amp + (int64_t)blockIdx.x * a.m_max;
     for (int k = threadIdx.x; k < M; k += 256) amp[k] = scale * sqrt(0.5 * (P[k] + P[(M - k) & (M - 1)]));
     double* cmp = a.comp + (int64_t)blockIdx.x * a.max_steps;
     for (int n = threadIdx.x; n < steps; n += 256) cmp[n] = -0.5 * row.eta * row.eta * pow((double)n * a.dt, 2.0 * row.H);
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void k_batch_paths(BatchArgs a, int blocks_per
     g.xi = row.xi;
     g.dt = a.dt;
     g.sqdt = a.sqdt;
-    g.amp = a.kappa + r_idx * a.m_max;
+    g.amp = a.amp + r_idx * a.m_max;
     g.comp = a.comp + r_idx * a.max_steps;
     g.log_tab = a.log_tab;
     g.K = 0.0;
@@ -418,8 +418,8 @@ int run_batch_rows(mcg_ctx* ctx, const mcg_row* rows, int64_t n_rows, int n_path
     BatchArgs a;
     double* sd = (double*)small;
     a.out = sd;
-    a.kappa = sd + 4 * n_rows;
-    a.comp = a.kappa + (size_t)n_rows * m_max;
+    a.amp = sd + 4 * n_rows;
+    a.comp = a.amp + (size_t)n_rows * m_max;
     a.rows = reinterpret_cast<const BatchRow*>(a.comp + (size_t)n_rows * max_steps);
     a.n_rows = n_rows;
     a.n_paths = n_paths;

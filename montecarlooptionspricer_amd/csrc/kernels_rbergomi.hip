@@ -2,9 +2,9 @@
 // in-register FFT spread over the lanes of a wavefront, log-space price stepping, 16-byte pair stores)
 // is documented in rbergomi_device.hpp.
 //
-// Roofline: with the O(Mz log Mz) transform the kernel is no longer bound by the Volterra contraction;
-// like the GBM kernel it is issue-bound on fp64 VALU work (per path and step: one volatility normal, one
-// price normal, two exponentials, one square root) while writing 8 (n_steps+1) bytes per path.
+// Roofline: like the GBM kernel it is issue-bound on fp64 VALU work (per path and step: one volatility
+// normal, one price normal, two exponentials, log2(Mz) half-butterflies) while writing 8 (n_steps+1)
+// bytes per path; DESIGN.md section 5 has the instruction budget and the measurements.
 #include "mcg_internal.hpp"
 #include "rbergomi_device.hpp"
 

@@ -50,7 +50,7 @@ struct mcg_ctx {
     size_t partials_cap = 0;     // in doubles
     double* scalars = nullptr;   // device: sums, moments, coefficients
     double* h_scalars = nullptr; // pinned host mirror
-    double* weights = nullptr;   // Volterra weights + compensator
+    double* weights = nullptr;   // rBergomi spectral amplitudes + compensator
     size_t weights_cap = 0;
     double* lsm_v = nullptr;     // LSM value vector
     size_t lsm_v_cap = 0;

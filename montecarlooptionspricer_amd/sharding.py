@@ -12,17 +12,23 @@ import math
 from typing import Sequence, Tuple
 
 
-def shard_range(n_paths: int, rank: int, world: int) -> Tuple[int, int]:
-    """[begin, count) of global path ids owned by `rank`.  Contiguous, balanced to within one path,
-    covers [0, n_paths) exactly once over all ranks; count may be 0 when n_paths < world."""
+def shard_range(n_paths: int, rank: int, world: int, align: int = 1) -> Tuple[int, int]:
+    """[begin, count) of global path ids owned by `rank`.  Contiguous, balanced to within one unit of
+    `align` paths, covers [0, n_paths) exactly once over all ranks; count may be 0 when there are fewer
+    units than ranks.  Every begin is a multiple of `align`: the rBergomi generator makes paths in pairs
+    (one complex transform serves ids 2q and 2q+1), so its shards use align=2."""
     if world < 1 or not (0 <= rank < world):
         raise ValueError(f"bad rank {rank} of {world}")
     if n_paths < 0:
         raise ValueError("n_paths must be >= 0")
-    base, rem = divmod(n_paths, world)
-    begin = rank * base + min(rank, rem)
-    count = base + (1 if rank < rem else 0)
-    return begin, count
+    if align < 1:
+        raise ValueError("align must be >= 1")
+    units = -(-n_paths // align)  # the last unit may be partial
+    base, rem = divmod(units, world)
+    u0 = rank * base + min(rank, rem)
+    u1 = u0 + base + (1 if rank < rem else 0)
+    begin = min(u0 * align, n_paths)
+    return begin, min(u1 * align, n_paths) - begin
 
 
 def combine_sums(parts: Sequence[Sequence[float]]) -> Tuple[float, float, float]:

@@ -75,8 +75,6 @@ class Oracle:
         L.orc_paths_gbm.argtypes = [C.c_uint64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int,
                                     C.c_uint64, C.c_long, _dp, C.c_size_t]
         L.orc_paths_gbm.restype = C.c_int
-        L.orc_rbergomi_weights.argtypes = [C.c_double, C.c_double, C.c_double, C.c_int, _dp, _dp]
-        L.orc_rbergomi_weights.restype = C.c_size_t
         L.orc_rbergomi_spectrum.argtypes = [C.c_double, C.c_double, C.c_double, C.c_int, _dp, _dp]
         L.orc_rbergomi_spectrum.restype = C.c_size_t
         L.orc_paths_rbergomi.argtypes = [C.c_uint64] + [C.c_double] * 7 + [C.c_int, C.c_uint64, C.c_long,
@@ -205,13 +203,6 @@ class Oracle:
         if rc:
             raise RuntimeError("orc_paths_gbm failed")
         return out
-
-    def rbergomi_weights(self, H, eta, dt, steps):
-        M = self.next_pow2(steps)
-        kappa = np.empty(M)
-        comp = np.empty(steps)
-        self.L.orc_rbergomi_weights(H, eta, dt, steps, _p(kappa), _p(comp))
-        return kappa, comp
 
     def rbergomi_spectrum(self, H, eta, dt, steps):
         """(amp[Mz], comp[steps]): spectral amplitudes a_k and the compensator."""

@@ -512,34 +512,6 @@ int orc_paths_gbm(uint64_t seed, double S0, double r, double sigma, double dt, i
     return 0;
 }
 
-// Real Volterra weights for the time-domain form of RoughVolatility.cpp:264-309.
-// The reference's X (:277-291) is a stationary circular Gaussian sequence with
-//   Cov(X_n, X_{n+d}) = (2H eta^2 / Mz^2) * sum_{k<steps} |phi_k|^2 cos(2 pi k d / Mz)
-// (SURVEY.md section 3.2).  With eps ~ iid N(0,1) of length Mz and the real symmetric kernel
-//   kappa_m = (eta*sqrt(2H/Mz)/Mz) * sum_k sqrt((P_k + P_{Mz-k})/2) cos(2 pi k m / Mz),
-//   P_k = |phi_k|^2 for k < steps, else 0,
-// X_n = sum_j kappa_{(n-j) mod Mz} eps_j has exactly that covariance, hence the same law.
-// comp_n = -0.5 eta^2 (n dt)^(2H) is the compensator of :305.  Returns Mz.
-size_t orc_rbergomi_weights(double H, double eta, double dt, int steps, double* kappa, double* comp) {
-    std::vector<double> lam(steps + 1);
-    orc_lambda(steps, H, dt, lam.data());
-    std::vector<double> phi(2 * next_pow2((size_t)steps + 1));
-    orc_phi(lam.data(), (size_t)steps + 1, phi.data());
-    const size_t M = next_pow2((size_t)steps);
-    std::vector<double> P(M, 0.0), amp(M);
-    for (size_t k = 0; k < (size_t)steps && k < M; ++k)
-        P[k] = phi[2 * k] * phi[2 * k] + phi[2 * k + 1] * phi[2 * k + 1];
-    for (size_t k = 0; k < M; ++k) amp[k] = std::sqrt(0.5 * (P[k] + P[(M - k) % M]));
-    const double scale = eta * std::sqrt(2.0 * H / (double)M) / (double)M;
-    for (size_t m = 0; m < M; ++m) {
-        double s = 0.0;
-        for (size_t k = 0; k < M; ++k) s += amp[k] * std::cos(2.0 * M_PI * (double)((k * m) % M) / (double)M);
-        kappa[m] = scale * s;
-    }
-    for (int n = 0; n < steps; ++n) comp[n] = -0.5 * eta * eta * std::pow(n * dt, 2 * H);
-    return M;
-}
-
 // Spectral amplitudes of the reference's X (RoughVolatility.cpp:264-292).  With P_k = |phi_k|^2 for k < steps
 // (0 for steps <= k < Mz), a_k = eta*sqrt(2H)/Mz * sqrt((P_k + P_{(Mz-k) mod Mz}) / 2) and
 // Y_k = a_k (g_k + i h_k), g, h ~ iid N(0,1),

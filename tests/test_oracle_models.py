@@ -77,11 +77,14 @@ def test_gbm_oracle_z_scores_over_many_seeds(orc):
         assert abs(a.mean()) < 0.6 and 0.5 < (a ** 2).mean() < 1.7, (a.mean(), (a ** 2).mean())
 
 
-# ---- rBergomi: the Volterra form has the reference's law ---------------------------------------
+# ---- rBergomi: the spectral-pair synthesis has the reference's law ------------------------------
 @pytest.mark.parametrize("steps,H,eta", [(252, 0.1, 1.9), (512, 0.1, 1.9), (7, 0.57, 0.03), (50, 0.3, 1.0), (1, 0.2, 0.5)])
-def test_volterra_kernel_reproduces_reference_covariance(orc, steps, H, eta):
-    """Cov(X_n, X_{n+d}) of the reference == (kappa * kappa)(d) for all lags.
-    Both are zero-mean Gaussian vectors, so equal covariance <=> equal law."""
+def test_spectral_pairs_reproduce_reference_covariance(orc, steps, H, eta):
+    """With Y_k = a_k (g_k + i h_k) and x_n = sum_k Y_k e^{2 pi i k n/M}:
+    Cov(Re x_n, Re x_{n+d}) = Cov(Im x_n, Im x_{n+d}) = sum_k a_k^2 cos(2 pi k d/M) must equal the covariance of the
+    reference's X at every lag, and Cov(Re x_n, Im x_{n+d}) = sum_k a_k^2 sin(2 pi k d/M)
+    must vanish at every lag (the two paths of a pair are independent).  Zero-mean Gaussian vectors: equal
+    covariance <=> equal law."""
     lam = orc.lam(steps, H)
     phi = orc.phi(lam)                       # pinned bit-exact to the compiled reference
     M = orc.next_pow2(steps)
@@ -89,10 +92,14 @@ def test_volterra_kernel_reproduces_reference_covariance(orc, steps, H, eta):
     P[:min(steps, M)] = np.abs(phi[:min(steps, M)]) ** 2
     d = np.arange(M)
     k = np.arange(M)
-    cov_ref = (2 * H * eta ** 2 / M ** 2) * (P[None, :] * np.cos(2 * np.pi * np.outer(d, k) / M)).sum(axis=1)
-    kappa, comp = orc.rbergomi_weights(H, eta, DT, steps)
-    cov_ours = np.array([np.dot(kappa, np.roll(kappa, -int(s))) for s in d])
-    assert np.allclose(cov_ours, cov_ref, rtol=1e-10, atol=1e-13 * max(1.0, abs(cov_ref[0])))
+    ang = 2 * np.pi * np.outer(d, k) / M
+    cov_ref = (2 * H * eta ** 2 / M ** 2) * (P[None, :] * np.cos(ang)).sum(axis=1)
+    amp, comp = orc.rbergomi_spectrum(H, eta, DT, steps)
+    cov_ours = ((amp ** 2)[None, :] * np.cos(ang)).sum(axis=1)
+    cross = ((amp ** 2)[None, :] * np.sin(ang)).sum(axis=1)
+    scale = max(1e-300, abs(cov_ref[0]))
+    assert np.allclose(cov_ours, cov_ref, rtol=1e-10, atol=1e-13 * scale)
+    assert np.all(np.abs(cross) <= 1e-12 * scale)
     assert np.allclose(comp, -0.5 * eta ** 2 * (np.arange(steps) * DT) ** (2 * H), rtol=1e-14)
     if steps == 252:
         assert abs(cov_ref[0] - 0.12552) < 5e-5      # SURVEY-verified Var(X_n)
@@ -100,7 +107,7 @@ def test_volterra_kernel_reproduces_reference_covariance(orc, steps, H, eta):
         assert abs(cov_ref[0] - 0.25480) < 5e-5      # the M_phi=1024 / M_z=512 quirk
 
 
-def test_volterra_sample_covariance_vs_reference_transform(orc):
+def test_spectral_sample_covariance_vs_reference_transform(orc):
     """Sampled X from the device algorithm AND X from the reference's own transform on Gaussian noise both
     reproduce the closed-form covariance (each within 4 standard errors of the estimator)."""
     steps, H, eta, n = 64, 0.1, 1.9, 6000
@@ -120,6 +127,9 @@ def test_volterra_sample_covariance_vs_reference_transform(orc):
         for sample in (X, Xr):
             est = (sample[:, 10] * sample[:, (10 + lag) % steps]).mean()
             assert abs(est - cd) <= 4 * se, (lag, est, cd, se)
+        # the two paths of a pair (Re / Im of one transform) are uncorrelated at every lag
+        cross = (X[0::2, 10] * X[1::2, (10 + lag) % steps]).mean()
+        assert abs(cross) <= 4 * c0 / math.sqrt(n / 2), (lag, cross)
 
 
 def test_rbergomi_oracle_martingale(orc):

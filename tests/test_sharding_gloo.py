@@ -34,6 +34,18 @@ def test_shard_range_partitions_exactly():
         shard_range(10, 2, 2)
 
 
+def test_shard_range_aligned_for_pair_generators():
+    """rBergomi shards start on even path ids (paths are generated in pairs)."""
+    for n in (0, 1, 2, 7, 1001, 64_000_001):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(n, r, world, align=2) for r in range(world)]
+            assert spans[0][0] == 0 and sum(c for _, c in spans) == n
+            for (b0, c0), (b1, _) in zip(spans, spans[1:]):
+                assert b0 + c0 == b1
+            assert all(b % 2 == 0 for b, c in spans if c > 0)
+            assert max(c for _, c in spans) - min(c for _, c in spans) <= 3  # one unit + the partial last unit
+
+
 def test_combine_and_price_from_sums():
     x = np.random.RandomState(0).rand(1000)
     parts = [(x[:300].sum(), (x[:300] ** 2).sum(), 300.0), (x[300:].sum(), (x[300:] ** 2).sum(), 700.0)]
