@@ -48,10 +48,14 @@ def cpu_baseline(n_steps: int, budget_s: float = 15.0) -> dict:
     from oracle.binding import Oracle, Reference, have_ref, synthetic_history
     hist = synthetic_history(1001, seed=42)
     chunk = 250
+    strike = float(hist[-1])  # at the money: the reference takes S0 = last history price (:331)
     if have_ref():
         ref = Reference()
         kind = "reference"
-        run = lambda n: ref.generate_paths_omp(hist, n_steps, n, chunk)  # noqa: E731
+
+        def run(n):
+            th, o = ref.generate_paths_omp_payoff(hist, n_steps, n, chunk, strike, True)
+            return th, o
     else:
         orc = Oracle()
         p = orc.estimate_params(hist)
@@ -64,11 +68,37 @@ def cpu_baseline(n_steps: int, budget_s: float = 15.0) -> dict:
     rate = 8000 / max(pilot, 1e-6)
     n = int(min(max(rate * budget_s, 20_000), 5_000_000)) // chunk * chunk
     t0 = time.perf_counter()
-    cores, sum_st = run(n)
+    cores, sums = run(n)
     dt = time.perf_counter() - t0
-    return {"value": n / dt / 1e6, "unit": "Mpaths/s", "cores": int(cores), "kind": kind,
-            "sample": f"{n} paths x {n_steps} steps via RoughVolatility::GenerateStockPricePaths "
-                      f"(rBergomi, 1001-point synthetic history), omp dynamic, {chunk} paths/call, {dt:.1f} s"}
+    out = {"value": n / dt / 1e6, "unit": "Mpaths/s", "cores": int(cores), "kind": kind,
+           "sample": f"{n} paths x {n_steps} steps via RoughVolatility::GenerateStockPricePaths "
+                     f"(rBergomi, 1001-point synthetic history), omp dynamic, {chunk} paths/call, {dt:.1f} s"}
+    if kind == "reference":
+        # the reference's own sample, priced: undiscounted mean call payoff +- std-err at K = S0
+        m = sums[1] / sums[3]
+        var = max(0.0, (sums[2] - sums[3] * m * m) / (sums[3] - 1))
+        out["_ref_price"] = {"history": hist, "strike": strike, "mean_payoff": m, "std_err": math.sqrt(var / sums[3]),
+                             "paths": int(sums[3])}
+    return out
+
+
+def reference_parity(eng, mc, ref_price: dict, n_steps: int, seed: int) -> dict:
+    """|price - ref| / MC-std-err against the compiled reference itself: the engine prices the same contract
+    (rBergomi with the parameters the reference estimates from the same history, same step count, K = S0) and is
+    set beside the mean payoff of the reference's own sample from the cpu_baseline leg."""
+    p = mc.estimate_params(ref_price["history"])
+    n = 4_000_000
+    K = ref_price["strike"]
+    P = eng.rbergomi(seed, p["S0"], 0.04, p["xi"], p["H"], p["eta"], p["rho"], 1.0 / 252.0, n_steps, n, payoff=(K, True))
+    price, se = eng.price_european(P, K, 0.0, 0.0, True)  # r = 0: undiscounted mean payoff
+    P.free()
+    comb = math.hypot(se, ref_price["std_err"])
+    return {"contract": f"rBergomi European call, K = S0 = {K:.4f}, {n_steps} steps, parameters estimated from the "
+                        "1001-point synthetic history (xi=%.5f H=%.4f eta=%.4f)" % (p["xi"], p["H"], p["eta"]),
+            "gpu_mean_payoff": price, "gpu_std_err": se, "gpu_paths": n,
+            "reference_mean_payoff": ref_price["mean_payoff"], "reference_std_err": ref_price["std_err"],
+            "reference_paths": ref_price["paths"],
+            "abs_diff_over_combined_std_err": abs(price - ref_price["mean_payoff"]) / comb if comb > 0 else None}
 
 
 def main() -> None:
@@ -191,7 +221,11 @@ def main() -> None:
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(n_steps)
+                cb = cpu_baseline(n_steps)
+                ref_price = cb.pop("_ref_price", None)
+                out["cpu_baseline"] = cb
+                if ref_price is not None:
+                    out["parity"]["vs_reference"] = reference_parity(eng, mc, ref_price, n_steps, seed)
             except Exception as e:  # the baseline is reported, never required for the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "Mpaths/s", "cores": 0, "kind": "port",
                                        "sample": f"failed: {e}"}

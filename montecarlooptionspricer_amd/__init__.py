@@ -8,10 +8,10 @@ McgError when the library or a GPU is missing.
     from montecarlooptionspricer_amd import PathEngine, RoughVolatility, LSM
 """
 from ._native import McgError, lib_path, load_library  # noqa: F401
-from .engine import PathEngine, PathMatrix  # noqa: F401
+from .engine import PathEngine, PathMatrix, estimate_params, rbergomi_spectrum  # noqa: F401
 from .compat import LSM, AsymptoticAnalysis, BranchingProcesses, MartingaleOptimization, PayoffFunction, RoughVolatility, set_compat_seed  # noqa: F401
 from .sharding import combine_sums, price_from_sums, shard_range  # noqa: F401
 
 __all__ = ["McgError", "PathEngine", "PathMatrix", "RoughVolatility", "LSM", "AsymptoticAnalysis", "MartingaleOptimization", "BranchingProcesses",
-           "PayoffFunction",
+           "PayoffFunction", "estimate_params", "rbergomi_spectrum",
            "set_compat_seed", "shard_range", "combine_sums", "price_from_sums", "load_library", "lib_path"]

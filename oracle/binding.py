@@ -347,6 +347,9 @@ class Reference:
         L.ref_generate_paths.restype = C.c_int
         L.ref_generate_paths_omp.argtypes = [_dp, C.c_size_t, C.c_int, C.c_long, C.c_int, _dp]
         L.ref_generate_paths_omp.restype = C.c_int
+        if hasattr(L, "ref_generate_paths_omp_payoff"):
+            L.ref_generate_paths_omp_payoff.argtypes = [_dp, C.c_size_t, C.c_int, C.c_long, C.c_int, C.c_double, C.c_int, _dp]
+            L.ref_generate_paths_omp_payoff.restype = C.c_int
         if hasattr(L, "ref_branching_price"):
             L.ref_branching_price.argtypes = [_dp, C.c_long, C.c_int] + [C.c_double] * 4 + [C.c_int, C.c_int, C.POINTER(C.c_int),
                                                                                    C.c_int, _dp, C.c_char_p, C.c_size_t]
@@ -442,6 +445,14 @@ class Reference:
         s = C.c_double(0.0)
         th = self.L.ref_generate_paths_omp(_p(h), len(h), steps, total_paths, chunk, C.byref(s))
         return th, s.value
+
+
+    def generate_paths_omp_payoff(self, hist, steps, total_paths, chunk, strike, is_call):
+        """(threads, {sum S_T, sum payoff, sum payoff^2, n}) over the reference's own sample."""
+        h = np.ascontiguousarray(hist, dtype=np.float64)
+        out = np.zeros(4)
+        th = self.L.ref_generate_paths_omp_payoff(_p(h), len(h), steps, total_paths, chunk, strike, int(is_call), _p(out))
+        return th, out
 
 
 def synthetic_history(n: int, seed: int = 42, s0: float = 100.0, mu: float = 0.05,

@@ -157,6 +157,38 @@ int ref_generate_paths_omp(const double* hist, size_t n, int steps, long total_p
     return threads;
 }
 
+// Same run, additionally pricing a European option on the reference's own sample: out4 = {sum S_T,
+// sum payoff, sum payoff^2, paths}, payoff = PayoffFunction(is_call, S_T, strike) (include/core/common.h:8-14),
+// undiscounted.  bench.py sets the engine's price on the same (S0, xi, H, eta, steps) beside it.
+int ref_generate_paths_omp_payoff(const double* hist, size_t n, int steps, long total_paths, int chunk, double strike,
+                                  int is_call, double* out4) {
+    std::vector<double> h(hist, hist + n);
+    long n_chunks = (total_paths + chunk - 1) / chunk;
+    double acc = 0.0, pay = 0.0, pay2 = 0.0;
+    int threads = 1;
+#ifdef _OPENMP
+    threads = omp_get_max_threads();
+#endif
+#pragma omp parallel for schedule(dynamic) reduction(+ : acc, pay, pay2)
+    for (long c = 0; c < n_chunks; ++c) {
+        long lo = c * (long)chunk;
+        int cnt = (int)std::min<long>(chunk, total_paths - lo);
+        RoughVolatility rv;
+        auto m = rv.GenerateStockPricePaths(h, steps, cnt);
+        for (auto& p : m) {
+            const double f = PayoffFunction(is_call != 0, p.back(), strike);
+            acc += p.back();
+            pay += f;
+            pay2 += f * f;
+        }
+    }
+    out4[0] = acc;
+    out4[1] = pay;
+    out4[2] = pay2;
+    out4[3] = (double)total_paths;
+    return threads;
+}
+
 // AsymptoticAnalysis::PredictOptionPrice (src/models/AsymptoticAnalysisPricer.cpp:38-113) on a
 // row-major [n][m] matrix.  Returns 0, or 1 when the reference throws (message in err).
 int ref_asymptotic_price(const double* row_major, long n, int m, double r, double strike, double maturity,
