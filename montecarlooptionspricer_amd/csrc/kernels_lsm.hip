@@ -30,6 +30,7 @@ struct LsmArgs {
     int upd;
     const double* coef;   // device: coef[0..NB), coef[9] = number of ITM paths of date j (global)
     double* partials;     // [NM][gridDim.x] (moment-major: the reduce kernel reads contiguously)
+    int rev;              // walk the grid-stride chunks from the last to the first (see run_lsm)
 };
 
 // NB = poly_order + 1 basis functions; NM = (2p+1) power sums + (p+1) cross sums = 3*NB - 1.
@@ -49,7 +50,11 @@ __global__ __launch_bounds__(256) void k_lsm_sweep(LsmArgs a) {
 #pragma unroll
     for (int q = 0; q < NM; ++q) m[q] = 0.0;
 
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * 256) {
+    const int64_t chunk = (int64_t)gridDim.x * 256;
+    const int64_t n_chunks = (a.n + chunk - 1) / chunk;
+    for (int64_t k = 0; k < n_chunks; ++k) {
+        const int64_t i = (a.rev ? n_chunks - 1 - k : k) * chunk + (int64_t)blockIdx.x * 256 + threadIdx.x;
+        if (i >= a.n) continue;
         double v;
         if (a.upd == UPD_INIT) {
             v = payoff_of(call, a.S_upd[i], a.K);  // LSMPricer.cpp:37-40
@@ -259,6 +264,10 @@ int run_lsm(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double maturit
     a.is_call = is_call;
     a.coef = coef;
     a.partials = ctx->partials;
+    // Consecutive sweeps walk the paths in opposite directions: what sweep j touched last (the tail of V and of
+    // row j-1, which sweep j-1 reads again) is what sweep j-1 touches first, while it is still in the 256 MB
+    // memory-side cache.
+    a.rev = 0;
 
     // terminal payoff, fused with the moments of date M-2
     a.upd = UPD_INIT;
@@ -276,6 +285,7 @@ int run_lsm(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double maturit
         a.upd = reg ? UPD_REGRESS : UPD_DISCOUNT;
         a.S_upd = row(j);
         a.S_mom = (j >= 1 && regress_at(j - 1)) ? row(j - 1) : nullptr;
+        a.rev ^= 1;
         launch_sweep(ctx, nb, grid, a);
     }
     MCG_HIP(hipGetLastError());
