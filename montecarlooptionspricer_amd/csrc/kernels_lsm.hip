@@ -13,6 +13,8 @@
 //     The moments are the only cross-GPU exchange: 3p+2 doubles per date through ctx->allreduce.
 // HBM-bound streaming; no MFMA (the "GEMM" A^T A is a (p+1)^2 moment accumulation, done in
 // registers with wavefront-shuffle reductions).
+#include <cstdlib>
+
 #include "lsm_device.hpp"
 #include "mcg_internal.hpp"
 
@@ -160,6 +162,337 @@ __global__ __launch_bounds__(256) void k_lsm_final(const double* V, int64_t n, d
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The whole sweep in ONE cooperative launch (single GPU, poly_order <= 4).  Every thread keeps the values V of
+// its PPT paths in registers for the entire sweep, so the value vector never touches HBM, and -- when they fit
+// (KEEP) -- also the date's prices between the regression pass and the update pass, so that the path matrix is read
+// exactly once: 8 B per path and date instead of the 32 B of the per-date kernels (16 B without KEEP).
+//
+// Per regression date the workgroups exchange 3p+2 moments one way and p+2 coefficients the other way.  On MI355X
+// (8 XCDs, one L2 each) the textbook device-wide barrier -- an atomic counter between two agent-scope fences -- costs
+// 14 us at 256 workgroups and 63 us at 1024, because every fence writes back and invalidates the XCD's L2 and those
+// operations serialise inside the XCD (tools/ubench_gridsync.hip: 1.5-2.4 us without the fences).  The exchange here
+// uses no fence, no read-modify-write and no flag: every exchanged double is written and read with agent-scope (sc1)
+// stores and loads, which go through to the device coherence point one by one, and every slot announces itself --
+// it holds a reserved NaN pattern until its value arrives:
+//   every workgroup : partial moments -> partials[parity][t][b]
+//   workgroup 0     : each lane polls its own slots (all loads of a round in flight together) until none is the
+//                     sentinel; fixed-order reduction; solve; coefficients -> coef[parity][0..9]
+//   every workgroup : lanes 0..9 poll one coefficient each
+// Two one-way trips per date.  Slots are recycled two dates later: workgroup 0 puts the sentinel back into the
+// partials right after reading them and into coef[parity] once the NEXT date's partials have all arrived (every
+// workgroup has then used those coefficients); it waits for the acknowledgement of these stores (s_waitcnt) before
+// it publishes anything newer.  The path matrix is read-only and V never leaves the registers, so nothing else
+// needs coherence.  The grid is sized by the occupancy query and launched with hipLaunchCooperativeKernel (all
+// workgroups co-resident); every spin is bounded and raises a flag instead of hanging.
+// Sharded runs keep the per-date kernels: their all-reduce is issued from the host between two launches.
+constexpr unsigned LSM_SENTINEL32 = 0xFFF85EA7u;  // both halves of the reserved NaN (hipMemsetD32 fills the buffers)
+constexpr int LSM_COOP_MAX_GRID = 1024;           // 16 slots per lane and moment in workgroup 0
+
+struct LsmCoopArgs {
+    const double* data;
+    int64_t ld, n;
+    int n_cols;
+    double K, invK, maturity, dt, disc;
+    int is_call;
+    double* partials;  // [2][NM][gridDim.x], sentinel-filled
+    double* coef;      // [2][16], sentinel-filled: coefficients, [9] = ITM count
+    unsigned* timeout; // set when a spin gives up
+    double* out;       // [2 * gridDim.x]: per-block {sum V, sum V^2}
+};
+
+__device__ __forceinline__ bool lsm_is_sentinel(double v) {
+    return (unsigned long long)__double_as_longlong(v) == (((unsigned long long)LSM_SENTINEL32 << 32) | LSM_SENTINEL32);
+}
+__device__ __forceinline__ double lsm_sentinel() {
+    return __longlong_as_double((long long)((((unsigned long long)LSM_SENTINEL32) << 32) | LSM_SENTINEL32));
+}
+__device__ __forceinline__ void lsm_st_shared(double* p, double v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double lsm_ld_shared(const double* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+constexpr unsigned LSM_SPIN_LIMIT = 1u << 22;  // rounds of ~1 us; a co-resident grid needs a handful
+
+// Second launch bound = workgroups per CU the register budget must allow.
+template <int NB, int PPT, bool KEEP>
+__global__ __launch_bounds__(256, (PPT >= 16 ? 2 : 3)) void k_lsm_coop(LsmCoopArgs a) {
+    constexpr int NM = 3 * NB - 1;
+    __shared__ double red[NM * 4];
+    __shared__ double sm_mom[32];
+    __shared__ double sm_coef[16];
+    const bool call = a.is_call != 0;
+    const unsigned G = gridDim.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // Path q of this thread is column first + q * stride.  `first` is the only per-lane part of an address: rows and
+    // the q * stride offsets are wave-uniform and stay in scalar registers (a per-lane 64-bit address per path would
+    // cost as many VGPRs as V itself).
+    const unsigned first = blockIdx.x * 256u + threadIdx.x;
+    int64_t stride = (int64_t)G * 256;
+    // columns first + q * stride exist for q < n_live (one per-lane integer instead of PPT lane masks)
+    const int n_live = (int64_t)first < a.n ? (int)std::min<int64_t>(PPT, (a.n - 1 - first) / stride + 1) : 0;
+    int parity = 0;
+    double V[PPT];
+    {
+        const double* last = a.data + (int64_t)(a.n_cols - 1) * a.ld;
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            const double* rq = last + (int64_t)q * stride;
+            V[q] = q < n_live ? payoff_of(call, rq[first], a.K) : 0.0;  // LSMPricer.cpp:37-40
+        }
+    }
+    // While the moments travel to workgroup 0 and the coefficients back (~10 us), the next date's row is already
+    // on its way from HBM into s_nxt -- when the registers allow a second row (PPT <= 16).
+    constexpr bool PREFETCH = PPT <= 16;
+    static_assert(KEEP, "the date's prices stay in registers between the regression pass and the update");
+    auto load_row = [&](int j, double (&dst)[PPT]) {
+        const double* row = a.data + (int64_t)j * a.ld;
+        // The PPT offsets q * stride are recomputed on the scalar unit for every row: as loop invariants hipcc
+        // hoists all of them, and 2 x PPT scalar registers do not exist.
+        asm volatile("" : "+s"(stride));
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            const double* rq = row + (int64_t)q * stride;
+            dst[q] = q < n_live ? rq[first] : 0.0;
+        }
+    };
+    int j = a.n_cols - 2;
+    for (; j >= 0 && j * a.dt > a.maturity; --j) {  // LSMPricer.cpp:43-49, uniform over the grid
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) V[q] *= a.disc;
+    }
+    double s_j[PPT], s_nxt[PREFETCH ? PPT : 1];
+    if (j >= 0) load_row(j, s_j);
+    for (; j >= 0; --j) {  // every remaining date regresses (this_time <= maturity from here on)
+        double m[NM];
+#pragma unroll
+        for (int q = 0; q < NM; ++q) m[q] = 0.0;
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {  // regression inputs, :51-74
+            const double s = s_j[q];
+            if (q < n_live && payoff_of(call, s, a.K) > 1e-14) {
+                const double x = fma(s, a.invK, -1.0);
+                const double y = V[q] * a.disc;
+                double pw = 1.0;
+#pragma unroll
+                for (int t = 0; t < 2 * NB - 1; ++t) {
+                    m[t] += pw;
+                    if (t < NB) m[2 * NB - 1 + t] = fma(pw, y, m[2 * NB - 1 + t]);
+                    pw *= x;
+                }
+            }
+        }
+        block_sum<NM, 4>(m, red);
+        double* part = a.partials + (int64_t)parity * NM * G;
+        double* coef_now = a.coef + 16 * parity;
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int t = 0; t < NM; ++t) lsm_st_shared(part + (int64_t)t * G + blockIdx.x, m[t]);
+        }
+        if constexpr (PREFETCH) {
+            if (j >= 1) load_row(j - 1, s_nxt);
+        }
+        if (blockIdx.x == 0) {
+            // the same fixed-order reduction as k_lsm_reduce_solve: wave w sums moments w, w+4, ...; lane l the
+            // workgroups l, l+64, ...
+            for (int t = wave; t < NM; t += 4) {
+                double* slot = part + (int64_t)t * G;
+                double v[LSM_COOP_MAX_GRID / 64];
+                unsigned spins = 0;
+                bool missing = true;
+                while (missing) {
+#pragma unroll
+                    for (int k = 0; k < LSM_COOP_MAX_GRID / 64; ++k) {
+                        const unsigned b = lane + 64u * k;
+                        v[k] = b < G ? lsm_ld_shared(slot + b) : 0.0;
+                    }
+                    missing = false;
+#pragma unroll
+                    for (int k = 0; k < LSM_COOP_MAX_GRID / 64; ++k) missing |= lsm_is_sentinel(v[k]);
+                    if (missing) {
+                        __builtin_amdgcn_s_sleep(1);
+                        if (++spins > LSM_SPIN_LIMIT) {
+                            __hip_atomic_store(a.timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            break;
+                        }
+                    }
+                }
+                double sum = 0.0;
+#pragma unroll
+                for (int k = 0; k < LSM_COOP_MAX_GRID / 64; ++k) {
+                    const unsigned b = lane + 64u * k;
+                    if (b < G) {
+                        sum += v[k];
+                        lsm_st_shared(slot + b, lsm_sentinel());  // recycled two dates from now
+                    }
+                }
+                sum = wave_sum(sum);
+                if (lane == 0) sm_mom[t] = sum;
+            }
+            // all partials of this date are in: every workgroup is past the previous date's coefficients
+            if (threadIdx.x < 10) lsm_st_shared(a.coef + 16 * (parity ^ 1) + threadIdx.x, lsm_sentinel());
+            __syncthreads();
+#ifdef LSM_EXP_NOSOLVE
+            if (threadIdx.x < 10) sm_coef[threadIdx.x] = threadIdx.x == 9 ? sm_mom[0] : 0.01 * sm_mom[1] / (sm_mom[0] + 1.0);
+#else
+            if (threadIdx.x == 0) lsm_solve_nb<NB>(sm_mom, 1.0, sm_coef);
+#endif
+            __builtin_amdgcn_s_waitcnt(0);  // the recycling stores are acknowledged before anything newer goes out
+            __syncthreads();
+            if (threadIdx.x < 10) lsm_st_shared(coef_now + threadIdx.x, sm_coef[threadIdx.x]);
+        } else {
+            if (threadIdx.x < 10) {
+                double cv = lsm_ld_shared(coef_now + threadIdx.x);
+                unsigned spins = 0;
+                while (lsm_is_sentinel(cv)) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > LSM_SPIN_LIMIT) {
+                        __hip_atomic_store(a.timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                    cv = lsm_ld_shared(coef_now + threadIdx.x);
+                }
+                sm_coef[threadIdx.x] = cv;
+            }
+            __syncthreads();
+        }
+        double c[NB];
+#pragma unroll
+        for (int t = 0; t < NB; ++t) c[t] = sm_coef[t];
+        const double n_itm = sm_coef[9];
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {  // :78-94
+            const double s = s_j[q];
+            const double pay = payoff_of(call, s, a.K);
+            const double vn = V[q] * a.disc;
+            double v;
+            if (pay > 1e-14 && n_itm > 0.0) {
+                const double x = fma(s, a.invK, -1.0);
+                double cont = c[NB - 1];
+#pragma unroll
+                for (int t = NB - 2; t >= 0; --t) cont = fma(cont, x, c[t]);
+                v = fmax(pay, cont);
+            } else if (pay < 1e-14) {
+                v = vn;
+            } else {
+                v = 0.0;
+            }
+            V[q] = q < n_live ? v : 0.0;
+        }
+        if (j >= 1) {
+            if constexpr (PREFETCH) {
+#pragma unroll
+                for (int q = 0; q < PPT; ++q) s_j[q] = s_nxt[q];
+            } else {
+                load_row(j - 1, s_j);
+            }
+        }
+        parity ^= 1;
+    }
+    double f[2] = {0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < PPT; ++q) {
+        if (q < n_live) {
+            f[0] += V[q];
+            f[1] += V[q] * V[q];
+        }
+    }
+    __syncthreads();
+    block_sum<2, 4>(f, red);
+    if (threadIdx.x == 0) {
+        a.out[2 * (int64_t)blockIdx.x] = f[0];
+        a.out[2 * (int64_t)blockIdx.x + 1] = f[1];
+    }
+}
+
+namespace {
+
+struct CoopVariant {
+    const void* fn;
+    int ppt;
+};
+
+template <int NB>
+const CoopVariant* coop_variants() {
+    static const CoopVariant v[2] = {{(const void*)k_lsm_coop<NB, 4, true>, 4}, {(const void*)k_lsm_coop<NB, 16, true>, 16}};
+    return v;
+}
+
+const CoopVariant* coop_variants_for(int nb) {
+    switch (nb) {
+        case 1: return coop_variants<1>();
+        case 2: return coop_variants<2>();
+        case 3: return coop_variants<3>();
+        case 4: return coop_variants<4>();
+        case 5: return coop_variants<5>();
+        default: return nullptr;
+    }
+}
+
+}  // namespace
+
+// Returns MCG_OK with *done = true when the cooperative sweep ran; *done = false when this shape has to take the
+// per-date kernels (too many paths for the register file, order too high, no cooperative launch).
+static int run_lsm_coop(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double maturity, double dt, int is_call,
+                        int nb, double* sums3, bool* done) {
+    *done = false;
+    const CoopVariant* vars = coop_variants_for(nb);
+    if (!vars || !ctx->coop_launch) return MCG_OK;
+    const int64_t N = P->n_paths;
+    const int nm = 3 * nb - 1;
+    // Few paths per thread keep each workgroup's serial work per date short, a small grid keeps the reduction in
+    // workgroup 0 short: take the fewest paths per thread that need at most two workgroups per CU, else the most.
+    const CoopVariant* use = nullptr;
+    int grid = 0;
+    static const int min_ppt = std::getenv("MCG_LSM_COOP_MIN_PPT") ? std::atoi(std::getenv("MCG_LSM_COOP_MIN_PPT")) : 0;  // experiments
+    for (int k = 0; k < 2; ++k) {
+        int occ = 0;
+        if (vars[k].ppt < min_ppt) continue;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, vars[k].fn, 256, 0) != hipSuccess || occ < 1) continue;
+        const int64_t g_max = std::min<int64_t>((int64_t)occ * ctx->n_cus, LSM_COOP_MAX_GRID);
+        const int64_t per_block = 256 * (int64_t)vars[k].ppt;
+        if (g_max * per_block < N) continue;
+        use = &vars[k];
+        grid = (int)((N + per_block - 1) / per_block);
+        if (grid <= 2 * ctx->n_cus) break;
+    }
+    if (!use) return MCG_OK;
+    // buffer: {sum, sum^2} per block | [2][nm][grid] moment slots | [2][16] coefficient slots
+    const size_t n_slots = 2 * (size_t)nm * grid + 32;
+    int rc = ensure_cap(ctx, &ctx->partials, &ctx->partials_cap, 2 * (size_t)grid + n_slots);
+    if (rc) return rc;
+    LsmCoopArgs a;
+    a.data = P->data;
+    a.ld = P->ld;
+    a.n = N;
+    a.n_cols = P->n_steps + 1;
+    a.K = K;
+    a.invK = 1.0 / K;
+    a.maturity = maturity;
+    a.dt = dt;
+    a.disc = std::exp(-r * dt);  // LSMPricer.cpp:46,:69,:92
+    a.is_call = is_call;
+    a.out = ctx->partials;  // finish_sums reads {sum, sum^2} pairs from the head of the buffer
+    a.partials = ctx->partials + 2 * (size_t)grid;
+    a.coef = a.partials + 2 * (size_t)nm * grid;
+    a.timeout = reinterpret_cast<unsigned*>(ctx->scalars + SC_BARRIER);
+    MCG_HIP(hipMemsetD32Async((hipDeviceptr_t)a.partials, (int)LSM_SENTINEL32, 2 * n_slots, ctx->stream));
+    MCG_HIP(hipMemsetAsync(a.timeout, 0, sizeof(unsigned), ctx->stream));
+    void* params[] = {&a};
+    {
+        TimedLaunch t(ctx, MCG_K_LSM_SWEEP);
+        MCG_HIP(hipLaunchCooperativeKernel(use->fn, dim3((unsigned)grid), dim3(256), params, 0, ctx->stream));
+    }
+    MCG_HIP(hipMemcpyAsync(ctx->h_scalars + SC_BARRIER, a.timeout, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+    rc = finish_sums(ctx, grid, N, sums3);  // synchronises the stream
+    if (rc) return rc;
+    if (reinterpret_cast<const unsigned*>(ctx->h_scalars + SC_BARRIER)[0] != 0)
+        return fail(MCG_ERR_HIP, "LSM cooperative sweep: workgroup hand-shake timed out");
+    *done = true;
+    return MCG_OK;
+}
+
 // partials[grid][nm] -> moments (fixed order) -> optional all-reduce -> coefficients in ctx->scalars.
 // Shared by the LSM sweep and the MartingaleOptimization refit.
 int lsm_reduce_allreduce_solve(mcg_ctx* ctx, int grid, int nm, int nb, double min_count) {
@@ -242,7 +575,23 @@ int run_lsm(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double maturit
         }
         return MCG_OK;
     }
-    int rc = ensure_cap(ctx, &ctx->lsm_v, &ctx->lsm_v_cap, (size_t)std::max<int64_t>(N, 1));
+    int rc;
+    if (N > 1024 && !ctx->allreduce) {
+        bool done = false;
+        double s3[3];
+        rc = run_lsm_coop(ctx, P, r, K, maturity, dt, is_call, nb, s3, &done);
+        if (rc) return rc;
+        if (done) {
+            const double n = s3[2], m = s3[0] / n;
+            *mean = m;
+            if (std_err) {
+                const double var = n > 1.0 ? std::max(0.0, (s3[1] - n * m * m) / (n - 1.0)) : 0.0;
+                *std_err = std::sqrt(var / n);
+            }
+            return MCG_OK;
+        }
+    }
+    rc = ensure_cap(ctx, &ctx->lsm_v, &ctx->lsm_v_cap, (size_t)std::max<int64_t>(N, 1));
     if (rc) return rc;
     rc = ensure_cap(ctx, &ctx->partials, &ctx->partials_cap, (size_t)grid * (size_t)std::max(nm, 2));
     if (rc) return rc;

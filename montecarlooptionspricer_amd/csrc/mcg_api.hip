@@ -223,6 +223,10 @@ static int init_impl(mcg_ctx** out, int device, bool adopt, void* external_strea
     if (!ctx) return fail(MCG_ERR_OOM, "host allocation failed");
     ctx->device = device;
     ctx->n_cus = prop.multiProcessorCount;
+    {
+        int coop = 0;
+        if (hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, device) == hipSuccess) ctx->coop_launch = coop != 0;
+    }
     if (adopt) {
         ctx->stream = (hipStream_t)external_stream;
         ctx->owns_stream = false;
@@ -273,7 +277,6 @@ int mcg_finalize(mcg_ctx* ctx) {
     if (ctx->h_scalars) (void)hipHostFree(ctx->h_scalars);
     if (ctx->weights) (void)hipFree(ctx->weights);
     if (ctx->lsm_v) (void)hipFree(ctx->lsm_v);
-    if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->log_tab) (void)hipFree(ctx->log_tab);
     if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;

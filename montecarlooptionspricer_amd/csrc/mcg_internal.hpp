@@ -42,6 +42,7 @@ struct mcg_ctx {
     hipStream_t stream = nullptr;
     bool owns_stream = false;
     int n_cus = 256;
+    bool coop_launch = false;    // hipDeviceAttributeCooperativeLaunch
 
     // cached device buffers (path matrices are tens of GB: never hipMalloc per call in steady state)
     std::vector<mcg::PoolBuf> pool;
@@ -54,9 +55,7 @@ struct mcg_ctx {
     size_t weights_cap = 0;
     double* lsm_v = nullptr;     // LSM value vector
     size_t lsm_v_cap = 0;
-    double* scratch = nullptr;   // rBergomi per-lane noise scratch
     double* log_tab = nullptr;   // device copy of fm::LOG_TAB_HOST + fm::SINCOS_TAB_HOST (10 KiB), staged to LDS
-    size_t scratch_cap = 0;
 
     // collective
     mcg_allreduce_fn allreduce = nullptr;
@@ -95,6 +94,7 @@ constexpr int SC_SUMS = 0;     // [0..3)  sum, sumsq, n
 constexpr int SC_MOMENTS = 8;  // [8..8+26) LSM moments (<= 3*8+2)
 constexpr int SC_COEF = 40;    // [40..40+9) LSM coefficients, [49] = regress flag
 constexpr int SC_FINAL = 64;   // [64..67) LSM final sums
+constexpr int SC_BARRIER = 72; // [72] 32-bit timeout flag of k_lsm_coop's hand-shake
 
 int pool_alloc(mcg_ctx* ctx, size_t bytes, void** out);
 void pool_release(mcg_ctx* ctx, void* ptr, size_t bytes);

@@ -204,6 +204,30 @@ def test_lsm_matches_oracle_on_same_paths(eng, orc, is_call, poly):
     P.free()
 
 
+@pytest.mark.parametrize("n,steps,poly", [(300_000, 20, 2), (1_200_000, 12, 3), (3_000_000, 6, 2), (70_000, 30, 4),
+                                          (5_000, 9, 0)])
+def test_lsm_single_launch_sweep_equals_per_date_kernels(eng, n, steps, poly):
+    """Single GPU runs the whole sweep as one cooperative launch (V in registers, workgroups exchanging moments and
+    coefficients through sentinel slots); a context with a collective installed takes the per-date kernels.  Same
+    arithmetic, different summation order of the moments: prices agree to rounding.  The sizes hit both
+    paths-per-thread variants (4, 16) and, at 3M paths, the fall-back to the per-date kernels."""
+    import montecarlooptionspricer_amd as mc
+    dt = 1.0 / steps
+    P = eng.gbm(SEED + 1, 100.0, 0.04, 0.25, dt, steps, n)
+    got, se = eng.price_lsm(P, 0.04, 100.0, 1.0, dt, False, poly)
+    other = mc.PathEngine(0)
+    try:
+        other.set_allreduce(lambda ptr, count, stream: None)  # world of one: the sum over ranks is the local value
+        Q = other.gbm(SEED + 1, 100.0, 0.04, 0.25, dt, steps, n)
+        want, se2 = other.price_lsm(Q, 0.04, 100.0, 1.0, dt, False, poly)
+        Q.free()
+    finally:
+        other.close()
+    P.free()
+    assert abs(got - want) <= 1e-9 * abs(want), (got, want)
+    assert abs(se - se2) <= 1e-9 * abs(se2)
+
+
 def test_lsm_american_put_bounds(eng):
     """Sanity (not parity): American put >= European put (BS 6.0040 at these parameters)."""
     n, steps, dt = 200_000, 50, 0.02
@@ -363,12 +387,15 @@ def test_torch_distributed_and_builtin_rccl_world_size_one():
         want_e = base.price_european(Q, 100.0, 0.04, 1.0, False)
         want_l = base.price_lsm(Q, 0.04, 100.0, 1.0, 0.02, False, 2)
         e.use_torch_distributed()
-        assert e.price_lsm(P, 0.04, 100.0, 1.0, 0.02, False, 2) == want_l
+        # (the collective path runs the per-date kernels, the single-GPU base the one-launch sweep: same arithmetic,
+        # the moments are summed in a different order)
+        got_l = e.price_lsm(P, 0.04, 100.0, 1.0, 0.02, False, 2)
+        assert got_l == pytest.approx(want_l, rel=1e-11)
         R = e.gbm(SEED, 100.0, 0.04, 0.2, 0.02, 50, 20_000, payoff=(100.0, False))
         assert e.price_european(R, 100.0, 0.04, 1.0, False) == want_e
         e.set_allreduce(None)
         e.init_rccl(0, 1, lambda uid: uid)                   # built-in RCCL communicator, 1 rank
-        assert e.price_lsm(P, 0.04, 100.0, 1.0, 0.02, False, 2) == want_l
+        assert e.price_lsm(P, 0.04, 100.0, 1.0, 0.02, False, 2) == got_l   # both collectives: identical kernels
         for x in (P, Q, R):
             x.free()
         e.close()
