@@ -13,6 +13,7 @@
 //     The moments are the only cross-GPU exchange: 3p+2 doubles per date through ctx->allreduce.
 // HBM-bound streaming; no MFMA (the "GEMM" A^T A is a (p+1)^2 moment accumulation, done in
 // registers with wavefront-shuffle reductions).
+#include <cstdio>
 #include <cstdlib>
 
 #include "lsm_device.hpp"
@@ -487,8 +488,13 @@ static int run_lsm_coop(mcg_ctx* ctx, const mcg_paths* P, double r, double K, do
     MCG_HIP(hipMemcpyAsync(ctx->h_scalars + SC_BARRIER, a.timeout, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
     rc = finish_sums(ctx, grid, N, sums3);  // synchronises the stream
     if (rc) return rc;
-    if (reinterpret_cast<const unsigned*>(ctx->h_scalars + SC_BARRIER)[0] != 0)
-        return fail(MCG_ERR_HIP, "LSM cooperative sweep: workgroup hand-shake timed out");
+    if (reinterpret_cast<const unsigned*>(ctx->h_scalars + SC_BARRIER)[0] != 0) {
+        // A spin gave up: the grid was not co-resident after all.  The result is discarded, this context stops using
+        // the cooperative sweep, and the caller runs the per-date kernels.
+        ctx->coop_launch = false;
+        std::fprintf(stderr, "mcgpu: LSM cooperative sweep timed out; using the per-date kernels from now on\n");
+        return MCG_OK;
+    }
     *done = true;
     return MCG_OK;
 }

@@ -228,6 +228,39 @@ def test_lsm_single_launch_sweep_equals_per_date_kernels(eng, n, steps, poly):
     assert abs(se - se2) <= 1e-9 * abs(se2)
 
 
+def test_lsm_single_launch_sweep_from_concurrent_host_threads():
+    """The reference's driver prices rows from an OpenMP region, one pricer object per thread: cooperative sweeps
+    issued at the same time from several contexts must neither dead-lock nor disturb each other."""
+    import threading
+    import montecarlooptionspricer_amd as mc
+    n, steps, dt = 60_000, 25, 0.04
+    ref_eng = mc.PathEngine(0)
+    P = ref_eng.gbm(SEED, 100.0, 0.04, 0.3, dt, steps, n)
+    want = ref_eng.price_lsm(P, 0.04, 100.0, 1.0, dt, False, 2)
+    P.free()
+    ref_eng.close()
+    out, errs = [None] * 4, []
+
+    def work(i):
+        try:
+            e = mc.PathEngine(0)
+            for _ in range(5):
+                Q = e.gbm(SEED, 100.0, 0.04, 0.3, dt, steps, n)
+                out[i] = e.price_lsm(Q, 0.04, 100.0, 1.0, dt, False, 2)
+                Q.free()
+            e.close()
+        except Exception as ex:  # pragma: no cover
+            errs.append(ex)
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=120)
+    assert not errs, errs
+    assert all(o == want for o in out), (out, want)
+
+
 def test_lsm_american_put_bounds(eng):
     """Sanity (not parity): American put >= European put (BS 6.0040 at these parameters)."""
     n, steps, dt = 200_000, 50, 0.02
