@@ -249,14 +249,16 @@ __global__ __launch_bounds__(256) void k_batch_branching(BatchArgs a) {
 }
 
 // ---- LSM (LSMPricer.cpp:19-102) ------------------------------------------------------------------
+// One wavefront per row, four rows per workgroup (lsm_wave_body).
 template <int NB>
 __global__ __launch_bounds__(256) void k_batch_lsm(BatchArgs a) {
-    __shared__ double out3[3];
-    const BatchRow row = a.rows[blockIdx.x];
+    const int64_t r_idx = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r_idx >= a.n_rows) return;
+    const BatchRow row = a.rows[r_idx];
     if (!row.valid) return;
-    lsm_small_body<NB, 1>(a.S + (int64_t)blockIdx.x * 256, a.ld, a.n_paths, row.n_steps + 1, row.strike, row.maturity, a.dt,
-                          a.disc, row.is_call, out3);
-    if (threadIdx.x == 0) a.out[4 * (int64_t)blockIdx.x + 2] = out3[0] / out3[2];
+    const double mean = lsm_wave_body<NB>(a.S + r_idx * 256, a.ld, a.n_paths, row.n_steps + 1, row.strike, row.maturity, a.dt,
+                                          a.disc, row.is_call);
+    if ((threadIdx.x & 63) == 0) a.out[4 * r_idx + 2] = mean;
 }
 
 // ---- MartingaleOptimization (MartingaleOptimizationPricer.cpp:21-189) ----------------------------
@@ -359,7 +361,7 @@ __global__ __launch_bounds__(256) void k_batch_martingale(BatchArgs a) {
 
 template <int NB>
 static void launch_row_regressions(mcg_ctx* ctx, const BatchArgs& a, size_t smem_cols) {
-    hipLaunchKernelGGL(k_batch_lsm<NB>, dim3((unsigned)a.n_rows), dim3(256), 0, ctx->stream, a);
+    hipLaunchKernelGGL(k_batch_lsm<NB>, dim3((unsigned)((a.n_rows + 3) / 4)), dim3(256), 0, ctx->stream, a);
     hipLaunchKernelGGL(k_batch_martingale<NB>, dim3((unsigned)a.n_rows), dim3(256), smem_cols, ctx->stream, a);
 }
 

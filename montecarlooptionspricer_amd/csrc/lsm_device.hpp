@@ -220,4 +220,79 @@ __device__ __forceinline__ void lsm_small_body(const double* data, int64_t ld, i
     }
 }
 
+// The same sweep for one row of at most 256 paths on ONE wavefront (four paths per lane): the moments are reduced
+// with an xor butterfly, which leaves the totals in every lane, so every lane runs the identical solve and no hand-over
+// through LDS and no workgroup barrier is needed.  A 256-thread workgroup prices four rows at once; the per-date
+// critical path (reduce -> solve -> update) is latency-bound, so four independent rows per workgroup give close to
+// four times the throughput of lsm_small_body on the batched driver rows.  Returns the mean of V.
+template <int NB>
+__device__ __forceinline__ double lsm_wave_body(const double* data, int64_t ld, int n, int n_cols, double K, double maturity,
+                                                double dt, double disc, int is_call) {
+    constexpr int NM = 3 * NB - 1;
+    const int lane = threadIdx.x & 63;
+    const bool call = is_call != 0;
+    const double invK = 1.0 / K;
+    double V[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int p = lane + 64 * q;
+        V[q] = p < n ? payoff_of(call, data[(int64_t)(n_cols - 1) * ld + p], K) : 0.0;
+    }
+    for (int j = n_cols - 2; j >= 0; --j) {
+        const double this_time = j * dt;
+        if (this_time > maturity) {  // LSMPricer.cpp:43-49 (wave-uniform)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) V[q] *= disc;
+            continue;
+        }
+        const double* row = data + (int64_t)j * ld;
+        double s_j[4], m[NM];
+#pragma unroll
+        for (int t = 0; t < NM; ++t) m[t] = 0.0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int p = lane + 64 * q;
+            s_j[q] = p < n ? row[p] : 0.0;
+            if (p < n && payoff_of(call, s_j[q], K) > 1e-14) {
+                const double x = fma(s_j[q], invK, -1.0);
+                const double y = V[q] * disc;
+                double pw = 1.0;
+#pragma unroll
+                for (int t = 0; t < 2 * NB - 1; ++t) {
+                    m[t] += pw;
+                    if (t < NB) m[2 * NB - 1 + t] = fma(pw, y, m[2 * NB - 1 + t]);
+                    pw *= x;
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NM; ++t) m[t] = wave_sum(m[t]);
+        double coef[10];
+        lsm_solve_nb<NB>(m, 1.0, coef);  // identical in every lane
+        const double n_itm = coef[9];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const double pay = payoff_of(call, s_j[q], K);
+            const double vn = V[q] * disc;
+            double v;
+            if (pay > 1e-14 && n_itm > 0.0) {
+                const double x = fma(s_j[q], invK, -1.0);
+                double cont = coef[NB - 1];
+#pragma unroll
+                for (int t = NB - 2; t >= 0; --t) cont = fma(cont, x, coef[t]);
+                v = fmax(pay, cont);
+            } else if (pay < 1e-14) {
+                v = vn;
+            } else {
+                v = 0.0;
+            }
+            V[q] = lane + 64 * q < n ? v : 0.0;
+        }
+    }
+    double f = 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) f += V[q];
+    return wave_sum(f) / (double)n;
+}
+
 }  // namespace mcg

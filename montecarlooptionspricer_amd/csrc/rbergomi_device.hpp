@@ -330,10 +330,17 @@ __device__ __forceinline__ void rb_generate_small(const RbArgs& a, int64_t block
         double re = 0.0, im = 0.0;
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
-            double s, c;
-            sincospi(2.0 * (double)((k * n) & (M - 1)) / (double)M, &s, &c);
-            re += yr[k] * c - yi[k] * s;
-            im += yr[k] * s + yi[k] * c;
+            // e^{2 pi i (k n mod M)/M} from the LDS twiddle table (q < M/2; the other half is its negative)
+            const int qn = (k * n) & (M - 1);
+            double c = 1.0, sn = 0.0;
+            if (M > 1 && k < M) {
+                const double2 w = L.tw[qn & (M / 2 - 1)];
+                const double sg = (qn >= M / 2) ? -1.0 : 1.0;
+                c = sg * w.x;
+                sn = sg * w.y;
+            }
+            re += yr[k] * c - yi[k] * sn;
+            im += yr[k] * sn + yi[k] * c;
         }
         if ((n & 3) == 0) {
             fm::normal_quad_fast(a.k0, a.k1, id_a, (uint32_t)(n >> 2), STREAM_PRICE, tabs, za);
