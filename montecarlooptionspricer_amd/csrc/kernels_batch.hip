@@ -256,9 +256,10 @@ __global__ __launch_bounds__(256) void k_batch_lsm(BatchArgs a) {
     if (r_idx >= a.n_rows) return;
     const BatchRow row = a.rows[r_idx];
     if (!row.valid) return;
-    const double mean = lsm_wave_body<NB>(a.S + r_idx * 256, a.ld, a.n_paths, row.n_steps + 1, row.strike, row.maturity, a.dt,
-                                          a.disc, row.is_call);
-    if ((threadIdx.x & 63) == 0) a.out[4 * r_idx + 2] = mean;
+    double sum_v, sum_v2;
+    lsm_wave_body<NB>(a.S + r_idx * 256, a.ld, a.n_paths, row.n_steps + 1, row.strike, row.maturity, a.dt, a.disc, row.is_call,
+                      sum_v, sum_v2);
+    if ((threadIdx.x & 63) == 0) a.out[4 * r_idx + 2] = sum_v / (double)a.n_paths;
 }
 
 // ---- MartingaleOptimization (MartingaleOptimizationPricer.cpp:21-189) ----------------------------

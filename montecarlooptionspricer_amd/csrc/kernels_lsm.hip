@@ -136,12 +136,25 @@ __global__ __launch_bounds__(256) void k_lsm_small(const double* data, int64_t l
     lsm_small_body<NB, PPT>(data, ld, n, n_cols, K, maturity, dt, disc, is_call, out3);
 }
 
+// At most 256 paths (the production shape is 250): a single wavefront, no workgroup barrier on the per-date path.
+template <int NB>
+__global__ __launch_bounds__(64) void k_lsm_small_wave(const double* data, int64_t ld, int n, int n_cols, double K,
+                                                       double maturity, double dt, double disc, int is_call, double* out3) {
+    double sum_v, sum_v2;
+    lsm_wave_body<NB>(data, ld, n, n_cols, K, maturity, dt, disc, is_call, sum_v, sum_v2);
+    if (threadIdx.x == 0) {
+        out3[0] = sum_v;
+        out3[1] = sum_v2;
+        out3[2] = (double)n;
+    }
+}
+
 template <int NB>
 static void launch_small_nb(mcg_ctx* ctx, const mcg_paths* P, double K, double maturity, double dt, double disc,
                             int is_call, double* out3) {
-    if (P->n_paths <= 256)  // the production shape (250 paths): one path per thread
-        hipLaunchKernelGGL((k_lsm_small<NB, 1>), dim3(1), dim3(256), 0, ctx->stream, P->data, P->ld, (int)P->n_paths,
-                           P->n_steps + 1, 0.0, K, maturity, dt, disc, is_call, out3);
+    if (P->n_paths <= 256)
+        hipLaunchKernelGGL(k_lsm_small_wave<NB>, dim3(1), dim3(64), 0, ctx->stream, P->data, P->ld, (int)P->n_paths,
+                           P->n_steps + 1, K, maturity, dt, disc, is_call, out3);
     else
         hipLaunchKernelGGL((k_lsm_small<NB, 4>), dim3(1), dim3(256), 0, ctx->stream, P->data, P->ld, (int)P->n_paths,
                            P->n_steps + 1, 0.0, K, maturity, dt, disc, is_call, out3);

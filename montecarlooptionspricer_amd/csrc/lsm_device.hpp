@@ -224,10 +224,10 @@ __device__ __forceinline__ void lsm_small_body(const double* data, int64_t ld, i
 // with an xor butterfly, which leaves the totals in every lane, so every lane runs the identical solve and no hand-over
 // through LDS and no workgroup barrier is needed.  A 256-thread workgroup prices four rows at once; the per-date
 // critical path (reduce -> solve -> update) is latency-bound, so four independent rows per workgroup give close to
-// four times the throughput of lsm_small_body on the batched driver rows.  Returns the mean of V.
+// four times the throughput of lsm_small_body on the batched driver rows.  sum_v, sum_v2: sums of V and V^2 (all lanes).
 template <int NB>
-__device__ __forceinline__ double lsm_wave_body(const double* data, int64_t ld, int n, int n_cols, double K, double maturity,
-                                                double dt, double disc, int is_call) {
+__device__ __forceinline__ void lsm_wave_body(const double* data, int64_t ld, int n, int n_cols, double K, double maturity,
+                                              double dt, double disc, int is_call, double& sum_v, double& sum_v2) {
     constexpr int NM = 3 * NB - 1;
     const int lane = threadIdx.x & 63;
     const bool call = is_call != 0;
@@ -289,10 +289,14 @@ __device__ __forceinline__ double lsm_wave_body(const double* data, int64_t ld, 
             V[q] = lane + 64 * q < n ? v : 0.0;
         }
     }
-    double f = 0.0;
+    double f = 0.0, f2 = 0.0;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) f += V[q];
-    return wave_sum(f) / (double)n;
+    for (int q = 0; q < 4; ++q) {
+        f += V[q];
+        f2 = fma(V[q], V[q], f2);
+    }
+    sum_v = wave_sum(f);
+    sum_v2 = wave_sum(f2);
 }
 
 }  // namespace mcg
