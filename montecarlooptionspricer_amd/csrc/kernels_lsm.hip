@@ -227,7 +227,7 @@ __device__ __forceinline__ void lsm_st_shared(double* p, double v) {
 __device__ __forceinline__ double lsm_ld_shared(const double* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-constexpr unsigned LSM_SPIN_LIMIT = 1u << 22;  // rounds of ~1 us; a co-resident grid needs a handful
+constexpr unsigned LSM_SPIN_LIMIT = 1u << 20;  // rounds of ~1.5 us; a co-resident grid needs a handful
 
 // Second launch bound = workgroups per CU the register budget must allow.
 template <int NB, int PPT, bool KEEP>
@@ -247,6 +247,7 @@ __global__ __launch_bounds__(256, (PPT >= 16 ? 2 : 3)) void k_lsm_coop(LsmCoopAr
     // columns first + q * stride exist for q < n_live (one per-lane integer instead of PPT lane masks)
     const int n_live = (int64_t)first < a.n ? (int)std::min<int64_t>(PPT, (a.n - 1 - first) / stride + 1) : 0;
     int parity = 0;
+    bool gave_up = false;  // this thread has hit the spin limit once
     double V[PPT];
     {
         const double* last = a.data + (int64_t)(a.n_cols - 1) * a.ld;
@@ -314,7 +315,7 @@ __global__ __launch_bounds__(256, (PPT >= 16 ? 2 : 3)) void k_lsm_coop(LsmCoopAr
                 double* slot = part + (int64_t)t * G;
                 double v[LSM_COOP_MAX_GRID / 64];
                 unsigned spins = 0;
-                bool missing = true;
+                bool missing = !gave_up;  // after one timeout nothing is waited for any more: the run is void
                 while (missing) {
 #pragma unroll
                     for (int k = 0; k < LSM_COOP_MAX_GRID / 64; ++k) {
@@ -328,6 +329,7 @@ __global__ __launch_bounds__(256, (PPT >= 16 ? 2 : 3)) void k_lsm_coop(LsmCoopAr
                         __builtin_amdgcn_s_sleep(1);
                         if (++spins > LSM_SPIN_LIMIT) {
                             __hip_atomic_store(a.timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            gave_up = true;
                             break;
                         }
                     }
@@ -359,10 +361,11 @@ __global__ __launch_bounds__(256, (PPT >= 16 ? 2 : 3)) void k_lsm_coop(LsmCoopAr
             if (threadIdx.x < 10) {
                 double cv = lsm_ld_shared(coef_now + threadIdx.x);
                 unsigned spins = 0;
-                while (lsm_is_sentinel(cv)) {
+                while (lsm_is_sentinel(cv) && !gave_up) {
                     __builtin_amdgcn_s_sleep(1);
                     if (++spins > LSM_SPIN_LIMIT) {
                         __hip_atomic_store(a.timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        gave_up = true;
                         break;
                     }
                     cv = lsm_ld_shared(coef_now + threadIdx.x);
@@ -464,7 +467,9 @@ static int run_lsm_coop(mcg_ctx* ctx, const mcg_paths* P, double r, double K, do
         int occ = 0;
         if (vars[k].ppt < min_ppt) continue;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, vars[k].fn, 256, 0) != hipSuccess || occ < 1) continue;
-        const int64_t g_max = std::min<int64_t>((int64_t)occ * ctx->n_cus, LSM_COOP_MAX_GRID);
+        // The occupancy query can read one workgroup per CU high for kernels with ~100 SGPRs (MI355X_MICROARCH.md,
+        // "Correctness boundaries"), and a cooperative launch accepts the over-sized grid: stay an eighth below it.
+        const int64_t g_max = std::min<int64_t>((int64_t)std::min(occ, 4) * ctx->n_cus * 7 / 8, LSM_COOP_MAX_GRID);
         const int64_t per_block = 256 * (int64_t)vars[k].ppt;
         if (g_max * per_block < N) continue;
         use = &vars[k];
