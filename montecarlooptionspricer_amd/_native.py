@@ -6,7 +6,7 @@ import os
 import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.path.join(_HERE, "lib", "libmcgpu.so")
+_LIB = os.environ.get("MCG_LIB") or os.path.join(_HERE, "lib", "libmcgpu.so")  # MCG_LIB: A/B experiments with another build
 
 MCG_OK = 0
 K_GBM, K_RBERGOMI, K_PAYOFF, K_LSM_SWEEP, K_LSM_SOLVE, K_TRANSPOSE, K_ASYM, K_MARTINGALE, K_BRANCHING, K_BATCH = range(10)

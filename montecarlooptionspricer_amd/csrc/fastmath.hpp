@@ -6,7 +6,7 @@
 // checked against mpmath in tests (mcg_debug_eval).
 //
 //   scaled_exp(S, a)        S * e^a           any finite a (overflow -> inf, underflow -> 0)
-//   neg2log(u, tab)         -2 ln u           u in (0, 1]; 128-entry {1/c, -2 ln c} table in LDS
+//   neg2log(u, tab)         -2 ln u           u in (0, 1); 128-entry {1/c, -2 ln c} table in LDS
 //   sqrt_pos(x)             sqrt(x)           x in [1e-300, 1e300], no denormal/negative handling
 //   sincos_table(wb, tab)   cos/sin(2 pi f)   f = ((wb >> 8) + 1/2) 2^-24, from the raw Philox word; 512-entry table
 //   normal_quad_fast(...)   the four normals of one Philox block (philox.hpp's contract)
@@ -115,19 +115,28 @@ __device__ __forceinline__ double scaled_exp_small(double S, double a) {
     return __builtin_fma(S, em1, S);
 }
 
-// -2 ln u for u in (0,1].  u = z * 2^k with z in [0.6875, 1.375) (so u near 1 has k = 0 and no
-// cancellation); i = interval of z, r = z/c_i - 1 via one FMA with the tabulated 1/c_i;
-// ln z = ln c_i + log1p(r), log1p(r) = r - r^2/2 + r^3 p(r), p of degree 4 on |r| <= 0.0045
-// (max rel err 2^-61).  The interval containing 1 has c = 1 exactly.
+// -2 ln u for u in (0,1).  u = z * 2^k with z = frexp mantissa in [0.5, 1) (v_frexp_exp_i32_f64, v_frexp_mant_f64); i = top seven mantissa bits = interval of z, r = z/c_i - 1 via one FMA with the tabulated 1/c_i;
+// ln z = ln c_i + log1p(r), log1p(r) = r - r^2/2 + r^3 p(r), p of degree 4 on |r| <= 0.0045 (max rel err 2^-61).
+// The last interval [1 - 2^-8, 1) has c = 1 exactly, so u -> 1 keeps full relative accuracy (no cancellation).
 // tab: LDS, entry i = {1/c_i, -2 ln c_i}.
+struct LogSplit {
+    double z;      // mantissa in [0.5, 1)
+    int k;         // exponent: u = z 2^k
+    uint32_t idx;  // table interval
+};
+__device__ __forceinline__ LogSplit log_split(double u) {
+    const uint32_t hi = (uint32_t)__double2hiint(u);
+    LogSplit s;
+    s.k = __builtin_amdgcn_frexp_exp(u);
+    s.idx = (hi >> 13) & 127u;
+    s.z = __builtin_amdgcn_frexp_mant(u);  // (a v_and_or on the high word costs two register copies on top)
+    return s;
+}
+
 __device__ __forceinline__ double neg2log(double u, const double2* tab) {
-    const uint32_t hi = (uint32_t)__double2hiint(u), lo = (uint32_t)__double2loint(u);
-    const uint32_t t = hi - 0x3FE60000u;                  // offset so the mantissa window starts at 0.6875
-    const int k = (int)t >> 20;                            // exponent of the window (arithmetic shift)
-    const uint32_t i = (t >> 13) & 127u;                   // top 7 bits inside the window
-    const double z = from_words(hi - (t & 0xFFF00000u), lo);
-    const double2 e = tab[i];
-    const double r = __builtin_fma(z, e.x, -1.0);
+    const LogSplit sp = log_split(u);
+    const double2 e = tab[sp.idx];
+    const double r = __builtin_fma(sp.z, e.x, -1.0);
     const double r2 = r * r;
     double p = 0x1.2493c2a2efcc3p-3;
     p = fma_sc(p, r, -0x1.5556fe0374498p-3);
@@ -136,8 +145,26 @@ __device__ __forceinline__ double neg2log(double u, const double2* tab) {
     p = fma_sc(p, r, 0x1.5555555555555p-2);
     const double l1p = __builtin_fma(r2 * r, p, __builtin_fma(r2, -0.5, r));  // log1p(r)
     // -2 ln u = -2 k ln2 + (-2 ln c) - 2 log1p(r)
-    const double base = __builtin_fma((double)k, -0x1.62e42fefa39efp+0, e.y);
+    const double base = __builtin_fma((double)sp.k, -0x1.62e42fefa39efp+0, e.y);
     return __builtin_fma(-2.0, l1p, base);
+}
+
+// vol^2 * (-2 ln u): the same evaluation with the scale folded into its constants -- the table's second column is
+// pre-multiplied when it is staged (load_tables_scaled), c_k = -2 ln2 * vol^2, c_l = -2 vol^2 -- so that the
+// square root yields vol * sqrt(-2 ln u) directly and the GBM step saves a multiply.
+__device__ __forceinline__ double neg2log_scaled(double u, const double2* tab, double c_k, double c_l) {
+    const LogSplit sp = log_split(u);
+    const double2 e = tab[sp.idx];
+    const double r = __builtin_fma(sp.z, e.x, -1.0);
+    const double r2 = r * r;
+    double p = 0x1.2493c2a2efcc3p-3;
+    p = fma_sc(p, r, -0x1.5556fe0374498p-3);
+    p = fma_sc(p, r, 0x1.999999991c5b3p-3);
+    p = fma_sc(p, r, -0x1.ffffffff7319dp-3);
+    p = fma_sc(p, r, 0x1.5555555555555p-2);
+    const double l1p = __builtin_fma(r2 * r, p, __builtin_fma(r2, -0.5, r));
+    const double base = __builtin_fma((double)sp.k, c_k, e.y);
+    return __builtin_fma(c_l, l1p, base);
 }
 
 // sqrt for positive normal x in five instructions (measured <= 0.75 ulp): with y = rsq(x) accurate to
@@ -190,6 +217,16 @@ __device__ __forceinline__ void box_muller_pair_affine(uint32_t wa, uint32_t wb,
     a1 = __builtin_fma(rad, s, shift);
 }
 
+// The affine pair with vol folded into the logarithm (tables staged by load_tables_scaled(vol^2)); vol > 0.
+__device__ __forceinline__ void box_muller_pair_affine_scaled(uint32_t wa, uint32_t wb, const Tables* tab, double c_k,
+                                                              double c_l, double shift, double& a0, double& a1) {
+    const double rad = sqrt_pos(neg2log_scaled(radius_u01(wa, wb), tab->log, c_k, c_l));  // = vol * sqrt(-2 ln u)
+    double c, s;
+    sincos_table(wb, tab->sincos, c, s);
+    a0 = __builtin_fma(rad, c, shift);
+    a1 = __builtin_fma(rad, s, shift);
+}
+
 // One Philox block -> four N(0,1) deviates.
 __device__ __forceinline__ void normal_quad_fast(uint32_t k0, uint32_t k1, uint64_t path, uint32_t block,
                                                  uint32_t stream, const Tables* tab, double (&z)[4]) {
@@ -203,6 +240,16 @@ __device__ __forceinline__ void normal_quad_fast(uint32_t k0, uint32_t k1, uint6
 __device__ __forceinline__ void load_tables(Tables* lds, const double2* __restrict__ gtab) {
     double2* dst = reinterpret_cast<double2*>(lds);
     for (int i = threadIdx.x; i < LOG_TAB_ENTRIES + SINCOS_TAB_ENTRIES; i += blockDim.x) dst[i] = gtab[i];
+}
+
+// The same copy with the logarithm table's second column multiplied by `scale` (neg2log_scaled).
+__device__ __forceinline__ void load_tables_scaled(Tables* lds, const double2* __restrict__ gtab, double scale) {
+    double2* dst = reinterpret_cast<double2*>(lds);
+    for (int i = threadIdx.x; i < LOG_TAB_ENTRIES + SINCOS_TAB_ENTRIES; i += blockDim.x) {
+        double2 e = gtab[i];
+        if (i < LOG_TAB_ENTRIES) e.y *= scale;
+        dst[i] = e;
+    }
 }
 
 }  // namespace fm

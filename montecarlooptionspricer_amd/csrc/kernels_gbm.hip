@@ -21,36 +21,49 @@ struct GbmArgs {
     uint64_t path_begin;
     uint32_t k0, k1;   // Philox key = seed
     double S0, drift, vol;
+    double c_k, c_l;   // MODE 2: -2 ln2 vol^2, -2 vol^2
     double K;
     int is_call;
     double* partials;  // [gridDim.x][2]
     const double2* log_tab;  // fm::LOG_TAB_HOST on the device
 };
 
-// SMALL: the host has checked |drift| + vol * 7.55 <= 0.125, so every step's exponent fits
-// fm::scaled_exp_small (no range reduction, two fewer polynomial terms).
-template <bool PAYOFF, bool SMALL>
+// MODE 0: any parameters.  MODE 1 (SMALL): the host has checked |drift| + vol * 7.55 <= 0.125, so every step's exponent
+// fits fm::scaled_exp_small (no range reduction, two fewer polynomial terms).  MODE 2: SMALL and vol > 0 folded into
+// the logarithm (fm::neg2log_scaled): one multiply less per pair.
+template <bool PAYOFF, int MODE>
 __global__ __launch_bounds__(256) void k_gbm_paths(GbmArgs a) {
+    constexpr bool SMALL = MODE >= 1;
     __shared__ fm::Tables tabs;
     const fm::Tables* tab = &tabs;
-    fm::load_tables(&tabs, a.log_tab);
+    if (MODE == 2) fm::load_tables_scaled(&tabs, a.log_tab, a.vol * a.vol);
+    else fm::load_tables(&tabs, a.log_tab);
     __syncthreads();
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const bool live = i < a.n_paths;
     const uint64_t id = a.path_begin + (uint64_t)i;
-    double* col = a.out + i;
+    // The address of a store is (wave-uniform row pointer) + (lane offset): the row pointer advances on the scalar
+    // unit and the lane offset never changes, so a step spends no vector instruction on addressing.
+    double* row = a.out + (int64_t)blockIdx.x * 256;
+    const unsigned lane_bytes = threadIdx.x * 8u;
+    // (hipcc picks the scalar-base form for the first store only and rebuilds a 64-bit vector address inside the
+    // loop, hence the explicit instruction)
+    auto store_row = [&](double* r, double v) {
+        asm volatile("global_store_dwordx2 %0, %1, %2 nt" : : "v"(lane_bytes), "v"(v), "s"(r) : "memory");
+    };
     double S = a.S0;
-    __builtin_nontemporal_store(S, col);
+    store_row(row, S);
     // One Philox block feeds two Box-Muller pairs = four steps.  The loop runs per PAIR with the
     // Philox call under a wave-uniform branch on even pairs, so the compiled body holds one copy of
     // the log / sincos / exp code (two copies push the polynomial constants out of the SGPR file).
     const int n_pairs = (a.n_steps + 1) >> 1;
     Philox4 w = {0u, 0u, 0u, 0u};
+    const PhiloxLane lane_rng = philox_lane_setup(id, STREAM_PRICE, a.k1);
 #pragma unroll 1
     for (int pr = 0; pr < n_pairs; ++pr) {
         uint32_t wa, wb;
         if ((pr & 1) == 0) {
-            w = philox4x32_10((uint32_t)id, (uint32_t)(id >> 32), (uint32_t)(pr >> 1), STREAM_PRICE, a.k0, a.k1);
+            w = philox4x32_10_lane(lane_rng, (uint32_t)(pr >> 1), a.k0, a.k1);
             wa = w.w0;
             wb = w.w1;
         } else {
@@ -58,14 +71,15 @@ __global__ __launch_bounds__(256) void k_gbm_paths(GbmArgs a) {
             wb = w.w3;
         }
         double e0, e1;  // exponents drift + vol*z of the pair's two steps
-        fm::box_muller_pair_affine(wa, wb, tab, a.vol, a.drift, e0, e1);
+        if (MODE == 2) fm::box_muller_pair_affine_scaled(wa, wb, tab, a.c_k, a.c_l, a.drift, e0, e1);
+        else fm::box_muller_pair_affine(wa, wb, tab, a.vol, a.drift, e0, e1);
         S = SMALL ? fm::scaled_exp_small(S, e0) : fm::scaled_exp(S, e0);
-        col += a.ld;
-        __builtin_nontemporal_store(S, col);
+        row += a.ld;
+        store_row(row, S);
         if (2 * pr + 1 < a.n_steps) {  // wave-uniform: false only for the last pair of an odd grid
             S = SMALL ? fm::scaled_exp_small(S, e1) : fm::scaled_exp(S, e1);
-            col += a.ld;
-            __builtin_nontemporal_store(S, col);
+            row += a.ld;
+            store_row(row, S);
         }
     }
     if (PAYOFF) {
@@ -160,11 +174,19 @@ int launch_gbm(mcg_ctx* ctx, mcg_paths* P, uint64_t seed, double S0, double r, d
     {
         TimedLaunch t(ctx, MCG_K_GBM);
         const bool small = std::fabs(a.drift) + std::fabs(a.vol) * fm::MAX_ABS_NORMAL <= fm::SMALL_EXP_BOUND;
+        const int mode = !small ? 0 : (a.vol > 1e-100 ? 2 : 1);  // vol^2 (-2 ln u) must stay a normal positive double
+        a.c_k = -0x1.62e42fefa39efp+0 * (a.vol * a.vol);
+        a.c_l = -2.0 * (a.vol * a.vol);
         const dim3 grid((unsigned)n_blocks), block(256);
-        if (want_payoff && small) hipLaunchKernelGGL((k_gbm_paths<true, true>), grid, block, 0, ctx->stream, a);
-        else if (want_payoff) hipLaunchKernelGGL((k_gbm_paths<true, false>), grid, block, 0, ctx->stream, a);
-        else if (small) hipLaunchKernelGGL((k_gbm_paths<false, true>), grid, block, 0, ctx->stream, a);
-        else hipLaunchKernelGGL((k_gbm_paths<false, false>), grid, block, 0, ctx->stream, a);
+        if (want_payoff) {
+            if (mode == 2) hipLaunchKernelGGL((k_gbm_paths<true, 2>), grid, block, 0, ctx->stream, a);
+            else if (mode == 1) hipLaunchKernelGGL((k_gbm_paths<true, 1>), grid, block, 0, ctx->stream, a);
+            else hipLaunchKernelGGL((k_gbm_paths<true, 0>), grid, block, 0, ctx->stream, a);
+        } else {
+            if (mode == 2) hipLaunchKernelGGL((k_gbm_paths<false, 2>), grid, block, 0, ctx->stream, a);
+            else if (mode == 1) hipLaunchKernelGGL((k_gbm_paths<false, 1>), grid, block, 0, ctx->stream, a);
+            else hipLaunchKernelGGL((k_gbm_paths<false, 0>), grid, block, 0, ctx->stream, a);
+        }
     }
     MCG_HIP(hipGetLastError());
     if (want_payoff) {
