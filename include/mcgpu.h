@@ -219,7 +219,8 @@ int mcg_timing_get(mcg_ctx* ctx, int kernel /* enum mcg_kernel */, double* total
  * fn 0: y[0] = 1*e^x          fn 1: y[0] = -2 ln x (x in (0,1])       fn 2: y[0] = sqrt(x)
  * fn 3: x holds a 32-bit Philox word wb as a double; y[0], y[1] = cos, sin(2 pi ((wb>>8)+1/2) 2^-24)
  * fn 4: x holds a path id as a double; y[0..3] = the four normals of block 0, stream 0, seed 1
- * fn 5: as 4 through the reference-grade (device library) implementation. */
+ * fn 5: as 4 through the reference-grade (device library) implementation.
+ * fn 6: y[0] = e^x for |x| <= 0.125 (the branch-free step exponential)   fn 7: the same for |x| <= 0.1. */
 int mcg_debug_eval(mcg_ctx* ctx, int fn, const double* x, double* y, int64_t n);
 
 #ifdef __cplusplus

@@ -115,8 +115,22 @@ __device__ __forceinline__ double scaled_exp_small(double S, double a) {
     return __builtin_fma(S, em1, S);
 }
 
+// S * e^a for |a| <= 0.1: one term less (q of degree 6, max rel err 2^-54.2 = 0.4 ulp before rounding).
+constexpr double SMALL6_EXP_BOUND = 0.1;
+__device__ __forceinline__ double scaled_exp_small6(double S, double a) {
+    double q = 0x1.a02eb88e6a6ffp-16;
+    q = fma_sc(q, a, 0x1.a033e66a22569p-13);
+    q = fma_sc(q, a, 0x1.6c16c10206fa6p-10);
+    q = fma_sc(q, a, 0x1.1111108c7c825p-7);
+    q = fma_sc(q, a, 0x1.555555555664ep-5);
+    q = fma_sc(q, a, 0x1.5555555557fc2p-3);
+    q = fma_sc(q, a, 0x1.0000000000000p-1);
+    const double em1 = __builtin_fma(a * a, q, a);
+    return __builtin_fma(S, em1, S);
+}
+
 // -2 ln u for u in (0,1).  u = z * 2^k with z = frexp mantissa in [0.5, 1) (v_frexp_exp_i32_f64, v_frexp_mant_f64); i = top seven mantissa bits = interval of z, r = z/c_i - 1 via one FMA with the tabulated 1/c_i;
-// ln z = ln c_i + log1p(r), log1p(r) = r - r^2/2 + r^3 p(r), p of degree 4 on |r| <= 0.0045 (max rel err 2^-61).
+// ln z = ln c_i + log1p(r), log1p(r) = r + r^2 q(r), q of degree 5 on |r| <= 0.0045 (max rel err 2^-61.6).
 // The last interval [1 - 2^-8, 1) has c = 1 exactly, so u -> 1 keeps full relative accuracy (no cancellation).
 // tab: LDS, entry i = {1/c_i, -2 ln c_i}.
 struct LogSplit {
@@ -137,13 +151,13 @@ __device__ __forceinline__ double neg2log(double u, const double2* tab) {
     const LogSplit sp = log_split(u);
     const double2 e = tab[sp.idx];
     const double r = __builtin_fma(sp.z, e.x, -1.0);
-    const double r2 = r * r;
-    double p = 0x1.2493c2a2efcc3p-3;
-    p = fma_sc(p, r, -0x1.5556fe0374498p-3);
-    p = fma_sc(p, r, 0x1.999999991c5b3p-3);
-    p = fma_sc(p, r, -0x1.ffffffff7319dp-3);
-    p = fma_sc(p, r, 0x1.5555555555555p-2);
-    const double l1p = __builtin_fma(r2 * r, p, __builtin_fma(r2, -0.5, r));  // log1p(r)
+    double q = 0x1.24940e22d9958p-3;
+    q = fma_sc(q, r, -0x1.555752f357b5cp-3);
+    q = fma_sc(q, r, 0x1.99999998b8291p-3);
+    q = fma_sc(q, r, -0x1.ffffffff02617p-3);
+    q = fma_sc(q, r, 0x1.5555555555556p-2);
+    q = fma_sc(q, r, -0x1.0000000000000p-1);
+    const double l1p = __builtin_fma(r * r, q, r);  // log1p(r)
     // -2 ln u = -2 k ln2 + (-2 ln c) - 2 log1p(r)
     const double base = __builtin_fma((double)sp.k, -0x1.62e42fefa39efp+0, e.y);
     return __builtin_fma(-2.0, l1p, base);
@@ -156,13 +170,13 @@ __device__ __forceinline__ double neg2log_scaled(double u, const double2* tab, d
     const LogSplit sp = log_split(u);
     const double2 e = tab[sp.idx];
     const double r = __builtin_fma(sp.z, e.x, -1.0);
-    const double r2 = r * r;
-    double p = 0x1.2493c2a2efcc3p-3;
-    p = fma_sc(p, r, -0x1.5556fe0374498p-3);
-    p = fma_sc(p, r, 0x1.999999991c5b3p-3);
-    p = fma_sc(p, r, -0x1.ffffffff7319dp-3);
-    p = fma_sc(p, r, 0x1.5555555555555p-2);
-    const double l1p = __builtin_fma(r2 * r, p, __builtin_fma(r2, -0.5, r));
+    double q = 0x1.24940e22d9958p-3;
+    q = fma_sc(q, r, -0x1.555752f357b5cp-3);
+    q = fma_sc(q, r, 0x1.99999998b8291p-3);
+    q = fma_sc(q, r, -0x1.ffffffff02617p-3);
+    q = fma_sc(q, r, 0x1.5555555555556p-2);
+    q = fma_sc(q, r, -0x1.0000000000000p-1);
+    const double l1p = __builtin_fma(r * r, q, r);
     const double base = __builtin_fma((double)sp.k, c_k, e.y);
     return __builtin_fma(c_l, l1p, base);
 }

@@ -30,13 +30,14 @@ struct GbmArgs {
 
 // MODE 0: any parameters.  MODE 1 (SMALL): the host has checked |drift| + vol * 7.55 <= 0.125, so every step's exponent
 // fits fm::scaled_exp_small (no range reduction, two fewer polynomial terms).  MODE 2: SMALL and vol > 0 folded into
-// the logarithm (fm::neg2log_scaled): one multiply less per pair.
+// the logarithm (fm::neg2log_scaled): one multiply less per pair.  MODE 3: MODE 2 with the bound at 0.1, where e^a needs
+// one polynomial term less (fm::scaled_exp_small6).
 template <bool PAYOFF, int MODE>
 __global__ __launch_bounds__(256) void k_gbm_paths(GbmArgs a) {
     constexpr bool SMALL = MODE >= 1;
     __shared__ fm::Tables tabs;
     const fm::Tables* tab = &tabs;
-    if (MODE == 2) fm::load_tables_scaled(&tabs, a.log_tab, a.vol * a.vol);
+    if (MODE >= 2) fm::load_tables_scaled(&tabs, a.log_tab, a.vol * a.vol);
     else fm::load_tables(&tabs, a.log_tab);
     __syncthreads();
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -71,13 +72,13 @@ __global__ __launch_bounds__(256) void k_gbm_paths(GbmArgs a) {
             wb = w.w3;
         }
         double e0, e1;  // exponents drift + vol*z of the pair's two steps
-        if (MODE == 2) fm::box_muller_pair_affine_scaled(wa, wb, tab, a.c_k, a.c_l, a.drift, e0, e1);
+        if (MODE >= 2) fm::box_muller_pair_affine_scaled(wa, wb, tab, a.c_k, a.c_l, a.drift, e0, e1);
         else fm::box_muller_pair_affine(wa, wb, tab, a.vol, a.drift, e0, e1);
-        S = SMALL ? fm::scaled_exp_small(S, e0) : fm::scaled_exp(S, e0);
+        S = MODE == 3 ? fm::scaled_exp_small6(S, e0) : SMALL ? fm::scaled_exp_small(S, e0) : fm::scaled_exp(S, e0);
         row += a.ld;
         store_row(row, S);
         if (2 * pr + 1 < a.n_steps) {  // wave-uniform: false only for the last pair of an odd grid
-            S = SMALL ? fm::scaled_exp_small(S, e1) : fm::scaled_exp(S, e1);
+            S = MODE == 3 ? fm::scaled_exp_small6(S, e1) : SMALL ? fm::scaled_exp_small(S, e1) : fm::scaled_exp(S, e1);
             row += a.ld;
             store_row(row, S);
         }
@@ -174,16 +175,20 @@ int launch_gbm(mcg_ctx* ctx, mcg_paths* P, uint64_t seed, double S0, double r, d
     {
         TimedLaunch t(ctx, MCG_K_GBM);
         const bool small = std::fabs(a.drift) + std::fabs(a.vol) * fm::MAX_ABS_NORMAL <= fm::SMALL_EXP_BOUND;
-        const int mode = !small ? 0 : (a.vol > 1e-100 ? 2 : 1);  // vol^2 (-2 ln u) must stay a normal positive double
+        const double reach = std::fabs(a.drift) + std::fabs(a.vol) * fm::MAX_ABS_NORMAL;
+        // vol^2 (-2 ln u) must stay a normal positive double for modes 2 and 3
+        const int mode = !small ? 0 : !(a.vol > 1e-100) ? 1 : reach <= fm::SMALL6_EXP_BOUND ? 3 : 2;
         a.c_k = -0x1.62e42fefa39efp+0 * (a.vol * a.vol);
         a.c_l = -2.0 * (a.vol * a.vol);
         const dim3 grid((unsigned)n_blocks), block(256);
         if (want_payoff) {
-            if (mode == 2) hipLaunchKernelGGL((k_gbm_paths<true, 2>), grid, block, 0, ctx->stream, a);
+            if (mode == 3) hipLaunchKernelGGL((k_gbm_paths<true, 3>), grid, block, 0, ctx->stream, a);
+            else if (mode == 2) hipLaunchKernelGGL((k_gbm_paths<true, 2>), grid, block, 0, ctx->stream, a);
             else if (mode == 1) hipLaunchKernelGGL((k_gbm_paths<true, 1>), grid, block, 0, ctx->stream, a);
             else hipLaunchKernelGGL((k_gbm_paths<true, 0>), grid, block, 0, ctx->stream, a);
         } else {
-            if (mode == 2) hipLaunchKernelGGL((k_gbm_paths<false, 2>), grid, block, 0, ctx->stream, a);
+            if (mode == 3) hipLaunchKernelGGL((k_gbm_paths<false, 3>), grid, block, 0, ctx->stream, a);
+            else if (mode == 2) hipLaunchKernelGGL((k_gbm_paths<false, 2>), grid, block, 0, ctx->stream, a);
             else if (mode == 1) hipLaunchKernelGGL((k_gbm_paths<false, 1>), grid, block, 0, ctx->stream, a);
             else hipLaunchKernelGGL((k_gbm_paths<false, 0>), grid, block, 0, ctx->stream, a);
         }

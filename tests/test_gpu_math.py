@@ -42,6 +42,18 @@ def test_scaled_exp(eng):
     assert y[-2] == np.inf and y[-1] == 0.0
 
 
+def test_scaled_exp_small_variants(eng):
+    """The branch-free step exponentials on the ranges the host proves for them: |a| <= 0.125 (degree 9) and
+    |a| <= 0.1 (degree 8)."""
+    rs = np.random.RandomState(7)
+    for fn, bound in ((6, 0.125), (7, 0.1)):
+        x = np.concatenate([rs.uniform(-bound, bound, 3000), rs.normal(0, 0.0126, 3000).clip(-bound, bound),
+                            [0.0, bound, -bound, 1e-300, 5e-324]])
+        y = eng.debug_eval(fn, x)[:, 0]
+        worst = max(ulp_err(yi, mp.e ** mp.mpf(xi)) for xi, yi in zip(x, y))
+        assert worst <= 2.0, (fn, worst)
+
+
 def test_neg2log(eng):
     rs = np.random.RandomState(1)
     u = np.concatenate([rs.uniform(0, 1, 4000), 1 - rs.uniform(0, 1, 1500) ** 8, rs.uniform(0, 1, 1500) ** 12,
