@@ -15,6 +15,7 @@
 // registers with wavefront-shuffle reductions).
 #include <cstdio>
 #include <cstdlib>
+#include <mutex>
 
 #include "lsm_device.hpp"
 #include "mcg_internal.hpp"
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(256) void k_lsm_final(const double* V, int64_t n, d
 }
 
 // ------------------------------------------------------------------------------------------------
-// The whole sweep in ONE cooperative launch (single GPU, poly_order <= 4).  Every thread keeps the values V of
+// The whole sweep in ONE launch of co-resident, co-operating workgroups (single GPU, poly_order <= 4).  Every thread keeps the values V of
 // its PPT paths in registers for the entire sweep, so the value vector never touches HBM, and -- when they fit
 // (KEEP) -- also the date's prices between the regression pass and the update pass, so that the path matrix is read
 // exactly once: 8 B per path and date instead of the 32 B of the per-date kernels (16 B without KEEP).
@@ -197,8 +198,8 @@ __global__ __launch_bounds__(256) void k_lsm_final(const double* V, int64_t n, d
 // partials right after reading them and into coef[parity] once the NEXT date's partials have all arrived (every
 // workgroup has then used those coefficients); it waits for the acknowledgement of these stores (s_waitcnt) before
 // it publishes anything newer.  The path matrix is read-only and V never leaves the registers, so nothing else
-// needs coherence.  The grid is sized by the occupancy query and launched with hipLaunchCooperativeKernel (all
-// workgroups co-resident); every spin is bounded and raises a flag instead of hanging.
+// needs coherence.  The grid is sized by the occupancy query (minus a margin) so that all workgroups are co-resident,
+// one such kernel runs at a time per process, and every spin is bounded and raises a flag instead of hanging.
 // Sharded runs keep the per-date kernels: their all-reduce is issued from the host between two launches.
 constexpr unsigned LSM_SENTINEL32 = 0xFFF85EA7u;  // both halves of the reserved NaN (hipMemsetD32 fills the buffers)
 constexpr int LSM_COOP_MAX_GRID = 1024;           // 16 slots per lane and moment in workgroup 0
@@ -449,13 +450,13 @@ const CoopVariant* coop_variants_for(int nb) {
 
 }  // namespace
 
-// Returns MCG_OK with *done = true when the cooperative sweep ran; *done = false when this shape has to take the
-// per-date kernels (too many paths for the register file, order too high, no cooperative launch).
+// Returns MCG_OK with *done = true when the one-launch sweep ran; *done = false when this shape has to take the
+// per-date kernels (too many paths for the register file, order too high, or a time-out earlier on this context).
 static int run_lsm_coop(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double maturity, double dt, int is_call,
                         int nb, double* sums3, bool* done) {
     *done = false;
     const CoopVariant* vars = coop_variants_for(nb);
-    if (!vars || !ctx->coop_launch) return MCG_OK;
+    if (!vars || !ctx->coop_launch) return MCG_OK;  // coop_launch: cleared after a hand-shake time-out
     const int64_t N = P->n_paths;
     const int nm = 3 * nb - 1;
     // Few paths per thread keep each workgroup's serial work per date short, a small grid keeps the reduction in
@@ -468,7 +469,7 @@ static int run_lsm_coop(mcg_ctx* ctx, const mcg_paths* P, double r, double K, do
         if (vars[k].ppt < min_ppt) continue;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, vars[k].fn, 256, 0) != hipSuccess || occ < 1) continue;
         // The occupancy query can read one workgroup per CU high for kernels with ~100 SGPRs (MI355X_MICROARCH.md,
-        // "Correctness boundaries"), and a cooperative launch accepts the over-sized grid: stay an eighth below it.
+        // "Correctness boundaries"), and nothing would reject the over-sized grid: stay an eighth below it.
         const int64_t g_max = std::min<int64_t>((int64_t)std::min(occ, 4) * ctx->n_cus * 7 / 8, LSM_COOP_MAX_GRID);
         const int64_t per_block = 256 * (int64_t)vars[k].ppt;
         if (g_max * per_block < N) continue;
@@ -500,17 +501,25 @@ static int run_lsm_coop(mcg_ctx* ctx, const mcg_paths* P, double r, double K, do
     MCG_HIP(hipMemsetAsync(a.timeout, 0, sizeof(unsigned), ctx->stream));
     void* params[] = {&a};
     {
-        TimedLaunch t(ctx, MCG_K_LSM_SWEEP);
-        MCG_HIP(hipLaunchCooperativeKernel(use->fn, dim3((unsigned)grid), dim3(256), params, 0, ctx->stream));
+        // One such kernel at a time per process: two grids of spinning workgroups that are each only partly resident
+        // would wait for each other.  The lock is held until the stream has drained.  (An ordinary launch, not
+        // hipLaunchCooperativeKernel: nothing of the cooperative-groups runtime is used, the grid is sized to be
+        // co-resident by the occupancy query above, and rocprofv3 crashes at exit after a cooperative launch.)
+        static std::mutex one_at_a_time;
+        std::lock_guard<std::mutex> hold(one_at_a_time);
+        {
+            TimedLaunch t(ctx, MCG_K_LSM_SWEEP);
+            MCG_HIP(hipLaunchKernel(use->fn, dim3((unsigned)grid), dim3(256), params, 0, ctx->stream));
+        }
+        MCG_HIP(hipMemcpyAsync(ctx->h_scalars + SC_BARRIER, a.timeout, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+        rc = finish_sums(ctx, grid, N, sums3);  // synchronises the stream
     }
-    MCG_HIP(hipMemcpyAsync(ctx->h_scalars + SC_BARRIER, a.timeout, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
-    rc = finish_sums(ctx, grid, N, sums3);  // synchronises the stream
     if (rc) return rc;
     if (reinterpret_cast<const unsigned*>(ctx->h_scalars + SC_BARRIER)[0] != 0) {
         // A spin gave up: the grid was not co-resident after all.  The result is discarded, this context stops using
-        // the cooperative sweep, and the caller runs the per-date kernels.
+        // the one-launch sweep, and the caller runs the per-date kernels.
         ctx->coop_launch = false;
-        std::fprintf(stderr, "mcgpu: LSM cooperative sweep timed out; using the per-date kernels from now on\n");
+        std::fprintf(stderr, "mcgpu: one-launch LSM sweep timed out; using the per-date kernels from now on\n");
         return MCG_OK;
     }
     *done = true;

@@ -223,10 +223,7 @@ static int init_impl(mcg_ctx** out, int device, bool adopt, void* external_strea
     if (!ctx) return fail(MCG_ERR_OOM, "host allocation failed");
     ctx->device = device;
     ctx->n_cus = prop.multiProcessorCount;
-    {
-        int coop = 0;
-        if (hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, device) == hipSuccess) ctx->coop_launch = coop != 0;
-    }
+    ctx->coop_launch = true;
     if (adopt) {
         ctx->stream = (hipStream_t)external_stream;
         ctx->owns_stream = false;

@@ -42,7 +42,7 @@ struct mcg_ctx {
     hipStream_t stream = nullptr;
     bool owns_stream = false;
     int n_cus = 256;
-    bool coop_launch = false;    // hipDeviceAttributeCooperativeLaunch
+    bool coop_launch = false;    // the one-launch LSM sweep (k_lsm_coop) is allowed on this context
 
     // cached device buffers (path matrices are tens of GB: never hipMalloc per call in steady state)
     std::vector<mcg::PoolBuf> pool;
