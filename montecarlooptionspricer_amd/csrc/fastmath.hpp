@@ -36,7 +36,9 @@ __device__ __forceinline__ double from_words(uint32_t hi, uint32_t lo) { return 
 
 // q*r + C with the constant C read from a scalar register pair.  hipcc otherwise keeps hoisted
 // constants in VGPRs and lowers each Horner step to v_mov_b64 + v_fmac_f64 (the two-address form
-// clobbers its addend); one VOP3 v_fma_f64 with an SGPR addend needs no copy.
+// clobbers its addend); one VOP3 v_fma_f64 with an SGPR addend needs no copy.  (Tried: pinning only the constant with
+// an empty asm and leaving the FMA to the compiler -- that removes the `s_nop 0` hipcc puts behind an asm FMA whose
+// result the next instruction reads, 20 per Philox block, but costs two copies and seven scalar spills: no gain.)
 __device__ __forceinline__ double fma_sc(double q, double r, double C) {
     double out;
     asm("v_fma_f64 %0, %1, %2, %3" : "=v"(out) : "v"(q), "v"(r), "s"(C));

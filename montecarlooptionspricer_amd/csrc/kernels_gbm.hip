@@ -54,33 +54,40 @@ __global__ __launch_bounds__(256) void k_gbm_paths(GbmArgs a) {
     };
     double S = a.S0;
     store_row(row, S);
-    // One Philox block feeds two Box-Muller pairs = four steps.  The loop runs per PAIR with the
-    // Philox call under a wave-uniform branch on even pairs, so the compiled body holds one copy of
-    // the log / sincos / exp code (two copies push the polynomial constants out of the SGPR file).
-    const int n_pairs = (a.n_steps + 1) >> 1;
-    Philox4 w = {0u, 0u, 0u, 0u};
+    // One Philox block feeds two Box-Muller pairs = four steps.  The main loop takes whole blocks (both pairs
+    // written out, so no register copies select a pair); the tail runs pair by pair over the last <= 3 steps.
     const PhiloxLane lane_rng = philox_lane_setup(id, STREAM_PRICE, a.k1);
-#pragma unroll 1
-    for (int pr = 0; pr < n_pairs; ++pr) {
-        uint32_t wa, wb;
-        if ((pr & 1) == 0) {
-            w = philox4x32_10_lane(lane_rng, (uint32_t)(pr >> 1), a.k0, a.k1);
-            wa = w.w0;
-            wb = w.w1;
-        } else {
-            wa = w.w2;
-            wb = w.w3;
-        }
-        double e0, e1;  // exponents drift + vol*z of the pair's two steps
-        if (MODE >= 2) fm::box_muller_pair_affine_scaled(wa, wb, tab, a.c_k, a.c_l, a.drift, e0, e1);
-        else fm::box_muller_pair_affine(wa, wb, tab, a.vol, a.drift, e0, e1);
-        S = MODE == 3 ? fm::scaled_exp_small6(S, e0) : SMALL ? fm::scaled_exp_small(S, e0) : fm::scaled_exp(S, e0);
+    auto step = [&](double e) {
+        S = MODE == 3 ? fm::scaled_exp_small6(S, e) : SMALL ? fm::scaled_exp_small(S, e) : fm::scaled_exp(S, e);
         row += a.ld;
         store_row(row, S);
-        if (2 * pr + 1 < a.n_steps) {  // wave-uniform: false only for the last pair of an odd grid
-            S = MODE == 3 ? fm::scaled_exp_small6(S, e1) : SMALL ? fm::scaled_exp_small(S, e1) : fm::scaled_exp(S, e1);
-            row += a.ld;
-            store_row(row, S);
+    };
+    auto pair_exponents = [&](uint32_t wa, uint32_t wb, double& e0, double& e1) {  // drift + vol*z of two steps
+        if (MODE >= 2) fm::box_muller_pair_affine_scaled(wa, wb, tab, a.c_k, a.c_l, a.drift, e0, e1);
+        else fm::box_muller_pair_affine(wa, wb, tab, a.vol, a.drift, e0, e1);
+    };
+    const int n_blocks = a.n_steps >> 2;
+#pragma unroll 1
+    for (int b = 0; b < n_blocks; ++b) {
+        const Philox4 w = philox4x32_10_lane(lane_rng, (uint32_t)b, a.k0, a.k1);
+        double e0, e1;
+        pair_exponents(w.w0, w.w1, e0, e1);
+        step(e0);
+        step(e1);
+        pair_exponents(w.w2, w.w3, e0, e1);
+        step(e0);
+        step(e1);
+    }
+    const int rest = a.n_steps & 3;
+    if (rest) {  // wave-uniform
+        const Philox4 w = philox4x32_10_lane(lane_rng, (uint32_t)n_blocks, a.k0, a.k1);
+        double e0, e1;
+        pair_exponents(w.w0, w.w1, e0, e1);
+        step(e0);
+        if (rest >= 2) step(e1);
+        if (rest == 3) {
+            pair_exponents(w.w2, w.w3, e0, e1);
+            step(e0);
         }
     }
     if (PAYOFF) {
