@@ -56,7 +56,10 @@ __host__ __device__ inline int rb_pairs_per_block(int M) { return M < 32 ? 256 :
 // Output staging (FFT variants): one 4G-step tile of the workgroup's pairs, [4G rows][pairs + 1 pad] double2,
 // double-buffered while LDS allows (LT = 2), so that the step-major rows leave as (pairs * 16)-byte runs
 // instead of one 16-byte piece per lane.
-__host__ __device__ inline int rb_stage_bufs(int M) { return rb_log_tiles(M) == 2 ? 2 : 1; }
+#ifndef RB_NBUF
+#define RB_NBUF 2
+#endif
+__host__ __device__ inline int rb_stage_bufs(int M) { return rb_log_tiles(M) == 2 ? RB_NBUF : 1; }
 __host__ __device__ inline size_t rb_stage_units(int M) {  // double2 units per buffer
     return M < 32 ? 0 : (size_t)(M >> rb_log_tiles(M)) * (size_t)(rb_pairs_per_block(M) + 1);
 }
@@ -122,7 +125,7 @@ __device__ __forceinline__ void rb_generate_fft(const RbArgs& a, int64_t block_i
     constexpr int NT = 1 << LT;  // 4-step tiles per lane
     constexpr int PW = 4 * P;    // pairs per workgroup
     constexpr int RS = PW + 1;   // staging row stride in 16-byte units (one unit of padding)
-    constexpr int NBUF = LT == 2 ? 2 : 1;
+    constexpr int NBUF = LT == 2 ? RB_NBUF : 1;
     const RbLds L = rb_stage_lds(a, smem, tabs);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> (6 - LG), c = lane & (P - 1);
