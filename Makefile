@@ -7,7 +7,8 @@ PKG     := montecarlooptionspricer_amd
 OBJDIR  := build/obj
 LIB     := $(PKG)/lib/libmcgpu.so
 
-# HIPFLAGS_EXTRA: experiment switches (e.g. -DRB_NO_STORE, -DRB_WAVES=3), empty for the product build
+# HIPFLAGS_EXTRA: experiment switches for timing studies (-DRB_NO_STORE: generator without its stores, -DRB_NBUF=1,
+# -DRB_WAVES=3, -DRB_LT_DEFAULT=3), empty for the product build
 HIPFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Iinclude -Wall -Wno-unused-function $(HIPFLAGS_EXTRA)
 # host-only TUs: no FMA contraction so the estimators match the reference bit for bit
 HOSTFLAGS := -O2 -std=c++17 -fPIC -ffp-contract=off -Iinclude -Wall -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include

@@ -350,11 +350,7 @@ __global__ __launch_bounds__(256, (PPT >= 16 ? 2 : 3)) void k_lsm_coop(LsmCoopAr
             // all partials of this date are in: every workgroup is past the previous date's coefficients
             if (threadIdx.x < 10) lsm_st_shared(a.coef + 16 * (parity ^ 1) + threadIdx.x, lsm_sentinel());
             __syncthreads();
-#ifdef LSM_EXP_NOSOLVE
-            if (threadIdx.x < 10) sm_coef[threadIdx.x] = threadIdx.x == 9 ? sm_mom[0] : 0.01 * sm_mom[1] / (sm_mom[0] + 1.0);
-#else
             if (threadIdx.x == 0) lsm_solve_nb<NB>(sm_mom, 1.0, sm_coef);
-#endif
             __builtin_amdgcn_s_waitcnt(0);  // the recycling stores are acknowledged before anything newer goes out
             __syncthreads();
             if (threadIdx.x < 10) lsm_st_shared(coef_now + threadIdx.x, sm_coef[threadIdx.x]);
