@@ -20,6 +20,7 @@ from oracle.binding import Oracle, synthetic_history
 pytestmark = pytest.mark.gpu
 
 SEED = 20251031
+RB_S0 = 100.0
 DT = 1.0 / 252.0
 
 
@@ -59,6 +60,22 @@ def test_gbm_paths_match_oracle(eng, orc, n_paths, n_steps):
     assert (got[0] == 100.0).all()
     assert rel_err(got, want) < 1e-11
     P.free()
+
+
+@pytest.mark.parametrize("n_steps", [2, 3, 4, 5, 6, 9, 11])
+def test_gbm_block_loop_tails_and_64_bit_path_ids(eng, orc, n_steps):
+    """The generator runs per Philox block (4 steps) with a tail of 1-3 steps, and the Philox counter carries the full
+    64-bit global path id: ids beyond 2^32 and a large 64-bit seed must match the oracle as well."""
+    begin = (1 << 33) + 7
+    seed = 0xFEDCBA9876543210
+    P = eng.gbm(seed, 100.0, 0.04, 0.2, DT, n_steps, 130, path_begin=begin)
+    want = orc.paths_gbm(seed, 100.0, 0.04, 0.2, DT, n_steps, begin, 130)
+    assert rel_err(P.to_host_step_major(), want) < 1e-11
+    P.free()
+    Q = eng.rbergomi(seed, RB_S0, 0.04, 0.04, 0.1, 1.9, -0.9, DT, n_steps, 66, path_begin=begin + 1)
+    want = orc.paths_rbergomi(seed, RB_S0, 0.04, 0.04, 0.1, 1.9, -0.9, DT, n_steps, begin + 1, 66)
+    assert rel_err(Q.to_host_step_major(), want) < 1e-9
+    Q.free()
 
 
 def test_gbm_layouts_and_sharding_are_exact(eng):
