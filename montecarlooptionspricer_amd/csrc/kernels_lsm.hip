@@ -14,6 +14,7 @@
 // HBM-bound streaming; no MFMA (the "GEMM" A^T A is a (p+1)^2 moment accumulation, done in
 // registers with wavefront-shuffle reductions).
 #include <cstdio>
+#include <atomic>
 #include <cstdlib>
 #include <mutex>
 
@@ -460,10 +461,15 @@ static int run_lsm_coop(mcg_ctx* ctx, const mcg_paths* P, double r, double K, do
     const CoopVariant* use = nullptr;
     int grid = 0;
     static const int min_ppt = std::getenv("MCG_LSM_COOP_MIN_PPT") ? std::atoi(std::getenv("MCG_LSM_COOP_MIN_PPT")) : 0;  // experiments
+    static std::atomic<int> occ_cache[10][2];  // workgroups per CU of each variant (0 = not asked yet); same on every device
     for (int k = 0; k < 2; ++k) {
-        int occ = 0;
         if (vars[k].ppt < min_ppt) continue;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, vars[k].fn, 256, 0) != hipSuccess || occ < 1) continue;
+        int occ = occ_cache[nb][k].load(std::memory_order_relaxed);
+        if (occ == 0) {
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, vars[k].fn, 256, 0) != hipSuccess || occ < 1) occ = -1;
+            occ_cache[nb][k].store(occ, std::memory_order_relaxed);
+        }
+        if (occ < 1) continue;
         // The occupancy query can read one workgroup per CU high for kernels with ~100 SGPRs (MI355X_MICROARCH.md,
         // "Correctness boundaries"), and nothing would reject the over-sized grid: stay an eighth below it.
         const int64_t g_max = std::min<int64_t>((int64_t)std::min(occ, 4) * ctx->n_cus * 7 / 8, LSM_COOP_MAX_GRID);
