@@ -212,6 +212,7 @@ __global__ __launch_bounds__(256) void k_batch_branching(BatchArgs a) {
     double v[2] = {0.0, 0.0};
     if (p < a.n_paths) {
         const uint64_t id = ((uint64_t)blockIdx.x << 32) + (uint64_t)p;
+        const PhiloxLane lane_rng = philox_lane_setup(id, 2u, a.k1);
         const int quads = (a.num_branches + 3) >> 2;
         const double inv_b = a.num_branches > 0 ? 1.0 / (double)a.num_branches : 0.0;
         const int ex_last = row.n_steps - 1;
@@ -229,8 +230,7 @@ __global__ __launch_bounds__(256) void k_batch_branching(BatchArgs a) {
                 const double* frow = a.F + (int64_t)(e + 1) * a.ld + base;
                 double sum = 0.0;
                 for (int q = 0; q < quads; ++q) {
-                    const Philox4 w = philox4x32_10((uint32_t)id, (uint32_t)(id >> 32), (uint32_t)(e * quads + q), 2u,
-                                                    a.k0, a.k1);
+                    const Philox4 w = philox4x32_10_lane(lane_rng, (uint32_t)(e * quads + q), a.k0, a.k1);
                     const uint32_t ws[4] = {w.w0, w.w1, w.w2, w.w3};
 #pragma unroll
                     for (int s = 0; s < 4; ++s)

@@ -59,6 +59,7 @@ __global__ __launch_bounds__(256) void k_branch_bounds(BranchArgs a) {
     double v[2] = {0.0, 0.0};
     for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < a.n; p += (int64_t)gridDim.x * 256) {
         const uint64_t id = a.path_begin + (uint64_t)p;
+        const PhiloxLane lane_rng = philox_lane_setup(id, STREAM_BRANCH, a.k1);  // block numbers below are wave-uniform
         double lower = 0.0, upper = 0.0;
         bool have_lower = false;
         for (int e = 0; e < a.n_ex; ++e) {
@@ -73,8 +74,7 @@ __global__ __launch_bounds__(256) void k_branch_bounds(BranchArgs a) {
                 const double* row = a.F + (int64_t)(t_idx + 1) * a.ld;
                 double sum = 0.0;
                 for (int q = 0; q < quads; ++q) {
-                    const Philox4 w = philox4x32_10((uint32_t)id, (uint32_t)(id >> 32), (uint32_t)(e * quads + q),
-                                                    STREAM_BRANCH, a.k0, a.k1);
+                    const Philox4 w = philox4x32_10_lane(lane_rng, (uint32_t)(e * quads + q), a.k0, a.k1);
                     const uint32_t ws[4] = {w.w0, w.w1, w.w2, w.w3};
 #pragma unroll
                     for (int s = 0; s < 4; ++s) {
