@@ -22,6 +22,7 @@
 // shuffle scan over the G lanes, S = exp(.), and each lane stores {S(path 2q), S(path 2q+1)} as one 16-byte
 // store (lanes of equal g cover 64/G pairs = a contiguous (64/G)*16-byte run of the step-major row).
 #pragma once
+#include <type_traits>
 #include "devmath.hpp"
 #include "fastmath.hpp"
 
@@ -108,6 +109,22 @@ __device__ __forceinline__ void rb_store_pair(double* row_a, double sa, double s
     }
 }
 
+// x from lane (l ^ DELTA).  Strides 1, 2 (inside a quad) and 8 (half a 16-lane row) are DPP moves on the vector ALU --
+// a few cycles instead of the ~100-cycle round trip of ds_bpermute through LDS that every other stride takes.
+template <int DELTA>
+__device__ __forceinline__ double lane_xor(double x) {
+    if constexpr (DELTA == 1 || DELTA == 2 || DELTA == 8) {
+        constexpr int ctrl = DELTA == 1 ? 0xB1      // quad_perm [1,0,3,2]
+                             : DELTA == 2 ? 0x4E    // quad_perm [2,3,0,1]
+                                          : 0x128;  // row_ror:8
+        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), ctrl, 0xF, 0xF, false);
+        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), ctrl, 0xF, 0xF, false);
+        return __hiloint2double(hi, lo);
+    } else {
+        return __shfl_xor(x, DELTA, 64);
+    }
+}
+
 // bit reversal of the low LT bits of t (LT = 2 or 3)
 template <int LT>
 __device__ __forceinline__ constexpr int rb_rev(int t) {
@@ -187,11 +204,11 @@ __device__ __forceinline__ void rb_generate_fft(const RbArgs& a, int64_t block_i
     // A butterfly (lo, up) -> (lo + w up, lo - w up) has its two ends in lanes g and g ^ 2^b.  Each lane first
     // multiplies its own value by w_eff (w in the upper lane, 1 in the lower), the lanes swap, and the result is
     // partner + sgn * own (sgn = +1 lower, -1 upper): no per-element selects.
-#pragma unroll
-    for (int b = 0; b < LG; ++b) {
+    auto lane_stage = [&](auto b_tag) {
+        constexpr int b = decltype(b_tag)::value;
+        constexpr int DELTA = P << b;
         const bool upper = ((g >> b) & 1) != 0;
         const double sgn = upper ? -1.0 : 1.0;
-        const int delta = P << b;
         const int j_hi = (g & ((1 << b) - 1)) << 2;  // twiddle exponent j = j_hi | v, stage s = 3 + b
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
@@ -201,12 +218,18 @@ __device__ __forceinline__ void rb_generate_fft(const RbArgs& a, int64_t block_i
             for (int t = 0; t < NT; ++t) {
                 const double mr = xr[t * 4 + v], mi = xi[t * 4 + v];
                 const double tr = wx * mr - wy * mi, ti = wx * mi + wy * mr;
-                const double pr = __shfl_xor(tr, delta, 64), pi = __shfl_xor(ti, delta, 64);
+                const double pr = lane_xor<DELTA>(tr), pi = lane_xor<DELTA>(ti);
                 xr[t * 4 + v] = fma(sgn, tr, pr);
                 xi[t * 4 + v] = fma(sgn, ti, pi);
             }
         }
-    }
+    };
+    if constexpr (LG > 0) lane_stage(std::integral_constant<int, 0>{});
+    if constexpr (LG > 1) lane_stage(std::integral_constant<int, 1>{});
+    if constexpr (LG > 2) lane_stage(std::integral_constant<int, 2>{});
+    if constexpr (LG > 3) lane_stage(std::integral_constant<int, 3>{});
+    if constexpr (LG > 4) lane_stage(std::integral_constant<int, 4>{});
+    if constexpr (LG > 5) lane_stage(std::integral_constant<int, 5>{});
 
     // ---- stages 3+LG .. 2+LG+LT: index bits 2+LG .. (t): butterflies between registers ----
 #pragma unroll
