@@ -125,6 +125,29 @@ __device__ __forceinline__ double lane_xor(double x) {
     }
 }
 
+// Strides 16 and 32: gfx950's v_permlane16_swap / v_permlane32_swap exchange halves BETWEEN TWO registers (odd 16-lane
+// rows of a with even rows of b; upper 32 lanes of a with lower 32 lanes of b).  Applied to two values a, b of one
+// lane, the lane whose stride bit is 0 ends up with both ends of a's butterfly and its partner with both ends of
+// b's: every lane then computes one complete butterfly (one complex multiply instead of two half ones) and a
+// second swap sends the results home.  No LDS, no address registers, a few cycles of latency.
+template <int DELTA>
+__device__ __forceinline__ void lane_swap(double& a, double& b) {
+    typedef unsigned v2u __attribute__((ext_vector_type(2)));
+    static_assert(DELTA == 16 || DELTA == 32, "permlane swaps exist for strides 16 and 32");
+    const unsigned alo = (unsigned)__double2loint(a), ahi = (unsigned)__double2hiint(a);
+    const unsigned blo = (unsigned)__double2loint(b), bhi = (unsigned)__double2hiint(b);
+    v2u lo, hi;
+    if constexpr (DELTA == 16) {
+        lo = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
+        hi = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+    } else {
+        lo = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
+        hi = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+    }
+    a = __hiloint2double((int)hi.x, (int)lo.x);
+    b = __hiloint2double((int)hi.y, (int)lo.y);
+}
+
 // bit reversal of the low LT bits of t (LT = 2 or 3)
 template <int LT>
 __device__ __forceinline__ constexpr int rb_rev(int t) {
@@ -207,9 +230,30 @@ __device__ __forceinline__ void rb_generate_fft(const RbArgs& a, int64_t block_i
     auto lane_stage = [&](auto b_tag) {
         constexpr int b = decltype(b_tag)::value;
         constexpr int DELTA = P << b;
+        const int j_hi = (g & ((1 << b) - 1)) << 2;  // twiddle exponent j = j_hi | v, stage s = 3 + b
+        if constexpr (DELTA == 16 || DELTA == 32) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const double2 w = L.tw[(j_hi | v) << (LG + LT - 1 - b)];
+#pragma unroll
+                for (int tp = 0; tp < NT / 2; ++tp) {
+                    const int i0 = (2 * tp) * 4 + v, i1 = (2 * tp + 1) * 4 + v;
+                    lane_swap<DELTA>(xr[i0], xr[i1]);  // now [i0] = lower end, [i1] = upper end of ONE butterfly
+                    lane_swap<DELTA>(xi[i0], xi[i1]);
+                    const double wr = w.x * xr[i1] - w.y * xi[i1], wi = w.x * xi[i1] + w.y * xr[i1];
+                    double lo_r = xr[i0] + wr, lo_i = xi[i0] + wi, hi_r = xr[i0] - wr, hi_i = xi[i0] - wi;
+                    lane_swap<DELTA>(lo_r, hi_r);
+                    lane_swap<DELTA>(lo_i, hi_i);
+                    xr[i0] = lo_r;
+                    xr[i1] = hi_r;
+                    xi[i0] = lo_i;
+                    xi[i1] = hi_i;
+                }
+            }
+            return;
+        }
         const bool upper = ((g >> b) & 1) != 0;
         const double sgn = upper ? -1.0 : 1.0;
-        const int j_hi = (g & ((1 << b) - 1)) << 2;  // twiddle exponent j = j_hi | v, stage s = 3 + b
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
             const double2 w = L.tw[(j_hi | v) << (LG + LT - 1 - b)];
