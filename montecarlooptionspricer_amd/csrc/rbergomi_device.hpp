@@ -130,14 +130,28 @@ __device__ __forceinline__ double lane_xor(double x) {
 // lane, the lane whose stride bit is 0 ends up with both ends of a's butterfly and its partner with both ends of
 // b's: every lane then computes one complete butterfly (one complex multiply instead of two half ones) and a
 // second swap sends the results home.  No LDS, no address registers, a few cycles of latency.
+// Stride 4 has no swap instruction; two bank-masked DPP moves per 32-bit word do the same (row_shr:4 into banks 1 and
+// 3, row_shl:4 into banks 0 and 2).
 template <int DELTA>
 __device__ __forceinline__ void lane_swap(double& a, double& b) {
     typedef unsigned v2u __attribute__((ext_vector_type(2)));
-    static_assert(DELTA == 16 || DELTA == 32, "permlane swaps exist for strides 16 and 32");
+    static_assert(DELTA == 4 || DELTA == 16 || DELTA == 32, "swap strides: 4 (DPP), 16 and 32 (permlane swaps)");
+    if constexpr (DELTA == 4) {
+        const int alo = __double2loint(a), ahi = __double2hiint(a), blo = __double2loint(b), bhi = __double2hiint(b);
+        // a' : lanes with stride bit 1 (banks 1, 3) take b from lane - 4; b' : lanes with stride bit 0 take a from lane + 4
+        const int nalo = __builtin_amdgcn_update_dpp(alo, blo, 0x114, 0xF, 0xA, false);
+        const int nahi = __builtin_amdgcn_update_dpp(ahi, bhi, 0x114, 0xF, 0xA, false);
+        const int nblo = __builtin_amdgcn_update_dpp(blo, alo, 0x104, 0xF, 0x5, false);
+        const int nbhi = __builtin_amdgcn_update_dpp(bhi, ahi, 0x104, 0xF, 0x5, false);
+        a = __hiloint2double(nahi, nalo);
+        b = __hiloint2double(nbhi, nblo);
+        return;
+    }
     const unsigned alo = (unsigned)__double2loint(a), ahi = (unsigned)__double2hiint(a);
     const unsigned blo = (unsigned)__double2loint(b), bhi = (unsigned)__double2hiint(b);
     v2u lo, hi;
-    if constexpr (DELTA == 16) {
+    if constexpr (DELTA == 4) {
+    } else if constexpr (DELTA == 16) {
         lo = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
         hi = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
     } else {
@@ -231,7 +245,7 @@ __device__ __forceinline__ void rb_generate_fft(const RbArgs& a, int64_t block_i
         constexpr int b = decltype(b_tag)::value;
         constexpr int DELTA = P << b;
         const int j_hi = (g & ((1 << b) - 1)) << 2;  // twiddle exponent j = j_hi | v, stage s = 3 + b
-        if constexpr (DELTA == 16 || DELTA == 32) {
+        if constexpr (DELTA == 4 || DELTA == 16 || DELTA == 32) {
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 const double2 w = L.tw[(j_hi | v) << (LG + LT - 1 - b)];
