@@ -111,14 +111,26 @@ __device__ __forceinline__ void rb_store_pair(double* row_a, double sa, double s
 
 // x from lane (l ^ DELTA).  Strides 1, 2 (inside a quad) and 8 (half a 16-lane row) are DPP moves on the vector ALU --
 // a few cycles instead of the ~100-cycle round trip of ds_bpermute through LDS that every other stride takes.
+#ifndef RB_SWAP4
+#define RB_SWAP4 4  // 4: stride-4 stage as complete butterflies through DPP swaps; 0: as a DPP exchange
+#endif
 template <int DELTA>
 __device__ __forceinline__ double lane_xor(double x) {
     if constexpr (DELTA == 1 || DELTA == 2 || DELTA == 8) {
         constexpr int ctrl = DELTA == 1 ? 0xB1      // quad_perm [1,0,3,2]
                              : DELTA == 2 ? 0x4E    // quad_perm [2,3,0,1]
                                           : 0x128;  // row_ror:8
-        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), ctrl, 0xF, 0xF, false);
-        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), ctrl, 0xF, 0xF, false);
+        // (mov_dpp: no `old` operand -- every lane has a valid source here, and update_dpp(0, ...) costs a v_mov of
+        // the zero into the destination before every DPP move)
+        const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), ctrl, 0xF, 0xF, true);
+        const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), ctrl, 0xF, 0xF, true);
+        return __hiloint2double(hi, lo);
+    } else if constexpr (DELTA == 4) {
+        // banks 1 and 3 (lanes 4-7, 12-15 of a row) read lane - 4, then banks 0 and 2 read lane + 4 into the same register
+        int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), 0x114, 0xF, 0xA, true);
+        int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), 0x114, 0xF, 0xA, true);
+        lo = __builtin_amdgcn_update_dpp(lo, __double2loint(x), 0x104, 0xF, 0x5, false);
+        hi = __builtin_amdgcn_update_dpp(hi, __double2hiint(x), 0x104, 0xF, 0x5, false);
         return __hiloint2double(hi, lo);
     } else {
         return __shfl_xor(x, DELTA, 64);
@@ -245,7 +257,7 @@ __device__ __forceinline__ void rb_generate_fft(const RbArgs& a, int64_t block_i
         constexpr int b = decltype(b_tag)::value;
         constexpr int DELTA = P << b;
         const int j_hi = (g & ((1 << b) - 1)) << 2;  // twiddle exponent j = j_hi | v, stage s = 3 + b
-        if constexpr (DELTA == 4 || DELTA == 16 || DELTA == 32) {
+        if constexpr (DELTA == RB_SWAP4 || DELTA == 16 || DELTA == 32) {
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 const double2 w = L.tw[(j_hi | v) << (LG + LT - 1 - b)];
