@@ -74,3 +74,28 @@ def test_reference_error_strings_without_gpu():
     assert mc.RoughVolatility().GenerateStockPricePaths([100.0, 101.0, 102.0], 7, 0).shape == (0, 8)
     z = mc.RoughVolatility().GenerateStockPricePaths([100.0, 101.0, 102.0], 0, 3)
     assert z.shape == (3, 1) and (z == 102.0).all()
+
+
+def test_device_math_tables_and_coefficients_come_from_the_generator(tmp_path):
+    """csrc/fastmath_tables.hpp is the byte-for-byte output of tools/gen_coeffs.py, and the polynomial coefficients
+    pasted into csrc/fastmath.hpp are the ones the generator prints (mpmath, 60 digits, Chebyshev-node fits)."""
+    import os
+    import re
+    import subprocess
+    import sys
+    pytest.importorskip("mpmath")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / "tables.hpp"
+    res = subprocess.run([sys.executable, os.path.join(root, "tools", "gen_coeffs.py")], capture_output=True, text=True,
+                         env=dict(os.environ, MCG_TABLES_OUT=str(out)), timeout=300)
+    assert res.returncode == 0, res.stderr
+    committed = open(os.path.join(root, "montecarlooptionspricer_amd", "csrc", "fastmath_tables.hpp")).read()
+    assert out.read_text() == committed
+    header = open(os.path.join(root, "montecarlooptionspricer_amd", "csrc", "fastmath.hpp")).read()
+    lines = res.stdout.splitlines()
+    for tag in ("LOG_Q deg 5", "EXP_SMALL_Q deg 6", "EXP_SMALL_Q deg 7", "EXP_Q deg 9"):
+        idx = next(i for i, l in enumerate(lines) if l.strip() == "// " + tag)
+        coefs = re.findall(r"-?0x[0-9a-f.]+p[+-]\d+", lines[idx + 1])
+        assert coefs, tag
+        for c in coefs:
+            assert c.lstrip("-") in header, (tag, c)
