@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256) void k_lsm_final(const double* V, int64_t n, d
 // one such kernel runs at a time per process, and every spin is bounded and raises a flag instead of hanging.
 // Sharded runs keep the per-date kernels: their all-reduce is issued from the host between two launches.
 constexpr unsigned LSM_SENTINEL32 = 0xFFF85EA7u;  // both halves of the reserved NaN (hipMemsetD32 fills the buffers)
-constexpr int LSM_COOP_MAX_GRID = 1024;           // 16 slots per lane and moment in workgroup 0
+constexpr int LSM_COOP_MAX_GRID = 512;            // 8 slots per lane and moment in workgroup 0, two moments in flight
 
 struct LsmCoopArgs {
     const double* data;
@@ -313,20 +313,27 @@ __global__ __launch_bounds__(256, (PPT >= 16 ? 2 : 3)) void k_lsm_coop(LsmCoopAr
         if (blockIdx.x == 0) {
             // the same fixed-order reduction as k_lsm_reduce_solve: wave w sums moments w, w+4, ...; lane l the
             // workgroups l, l+64, ...
-            for (int t = wave; t < NM; t += 4) {
-                double* slot = part + (int64_t)t * G;
-                double v[LSM_COOP_MAX_GRID / 64];
+            // Two of the wave's moments per round: all their slots are polled together, so the usual date costs one
+            // round trip to the coherence point, not one per moment.
+            for (int t0 = wave; t0 < NM; t0 += 8) {
+                const int t1 = t0 + 4;
+                const bool two = t1 < NM;
+                double* slot0 = part + (int64_t)t0 * G;
+                double* slot1 = part + (int64_t)(two ? t1 : t0) * G;
+                constexpr int K = LSM_COOP_MAX_GRID / 64;
+                double v0[K], v1[K];
                 unsigned spins = 0;
                 bool missing = !gave_up;  // after one timeout nothing is waited for any more: the run is void
                 while (missing) {
 #pragma unroll
-                    for (int k = 0; k < LSM_COOP_MAX_GRID / 64; ++k) {
+                    for (int k = 0; k < K; ++k) {
                         const unsigned b = lane + 64u * k;
-                        v[k] = b < G ? lsm_ld_shared(slot + b) : 0.0;
+                        v0[k] = b < G ? lsm_ld_shared(slot0 + b) : 0.0;
+                        v1[k] = b < G ? lsm_ld_shared(slot1 + b) : 0.0;
                     }
                     missing = false;
 #pragma unroll
-                    for (int k = 0; k < LSM_COOP_MAX_GRID / 64; ++k) missing |= lsm_is_sentinel(v[k]);
+                    for (int k = 0; k < K; ++k) missing = missing || lsm_is_sentinel(v0[k]) || lsm_is_sentinel(v1[k]);
                     if (missing) {
                         __builtin_amdgcn_s_sleep(1);
                         if (++spins > LSM_SPIN_LIMIT) {
@@ -336,17 +343,23 @@ __global__ __launch_bounds__(256, (PPT >= 16 ? 2 : 3)) void k_lsm_coop(LsmCoopAr
                         }
                     }
                 }
-                double sum = 0.0;
+                double sum0 = 0.0, sum1 = 0.0;
 #pragma unroll
-                for (int k = 0; k < LSM_COOP_MAX_GRID / 64; ++k) {
+                for (int k = 0; k < K; ++k) {
                     const unsigned b = lane + 64u * k;
                     if (b < G) {
-                        sum += v[k];
-                        lsm_st_shared(slot + b, lsm_sentinel());  // recycled two dates from now
+                        sum0 += v0[k];
+                        sum1 += v1[k];
+                        lsm_st_shared(slot0 + b, lsm_sentinel());  // recycled two dates from now
+                        if (two) lsm_st_shared(slot1 + b, lsm_sentinel());
                     }
                 }
-                sum = wave_sum(sum);
-                if (lane == 0) sm_mom[t] = sum;
+                sum0 = wave_sum(sum0);
+                sum1 = wave_sum(sum1);
+                if (lane == 0) {
+                    sm_mom[t0] = sum0;
+                    if (two) sm_mom[t1] = sum1;
+                }
             }
             // all partials of this date are in: every workgroup is past the previous date's coefficients
             if (threadIdx.x < 10) lsm_st_shared(a.coef + 16 * (parity ^ 1) + threadIdx.x, lsm_sentinel());
