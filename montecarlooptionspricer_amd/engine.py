@@ -133,8 +133,12 @@ class PathEngine:
         import torch
         import torch.distributed as dist
 
+        views = {}  # (ptr, count) -> tensor aliasing the context's workspace (a handful of fixed addresses)
+
         def _ar(ptr: int, count: int, _stream: int) -> None:
-            t = torch.as_tensor(_DevView(ptr, count), device=torch.device("cuda", self.device))
+            t = views.get((ptr, count))
+            if t is None:
+                t = views[(ptr, count)] = torch.as_tensor(_DevView(ptr, count), device=torch.device("cuda", self.device))
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
 
         self.set_allreduce(_ar)
