@@ -165,6 +165,10 @@ def main() -> None:
 
     RAMP_LAUNCHES = 12
 
+    def run_ramp():
+        for _ in range(RAMP_LAUNCHES):
+            eng.gbm(seed, S0, r, sigma, dt, n_steps, count, path_begin=begin).free()  # asynchronous, one reused buffer
+
     def fence(ramp=False):
         """barrier + synchronize on both sides of the timed region.
         ramp: an MI355X that has been idle needs ~12 launches of this kernel (50 ms) to settle at its clock under this
@@ -172,17 +176,19 @@ def main() -> None:
         and it drops out of that state again during the 0.2-2 ms the host spends in the barrier.  The throughput of
         interest is the steady one, so before the start barrier every rank queues RAMP_LAUNCHES untimed generator
         launches (asynchronously, one reused buffer): the device is at load while the host sits in the barrier and the
-        queue has drained before the clock starts.  Same at every N; reported as config.untimed_ramp_launches."""
+        queue has drained before the clock starts.  Same at every N; reported as config.untimed_ramp_launches (the same
+        ramp also precedes the W warm-up steps)."""
         eng.synchronize()
         torch.cuda.synchronize()
         if ramp:
-            for _ in range(RAMP_LAUNCHES):
-                eng.gbm(seed, S0, r, sigma, dt, n_steps, count, path_begin=begin).free()  # asynchronous
+            run_ramp()
         if dist is not None:
             dist.barrier()
         eng.synchronize()
         torch.cuda.synchronize()
 
+    run_ramp()  # also ahead of the W warm-up steps: every launch of the measured kernel variant runs at the steady clock,
+    #             so the rocprofv3 average over all of them agrees with the average over the K timed ones
     for _ in range(args.warmup):
         one_pass()
     fence(ramp=True)
