@@ -99,3 +99,30 @@ def test_device_math_tables_and_coefficients_come_from_the_generator(tmp_path):
         assert coefs, tag
         for c in coefs:
             assert c.lstrip("-") in header, (tag, c)
+
+
+def test_committed_bench_line_has_the_contract_fields():
+    """profiles/r01_bench_n1.json is the line bench.py printed on the GPU box: the driver's contract fields plus the
+    roofline and cpu_baseline objects must all be there, and be mutually consistent."""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    j = json.load(open(os.path.join(root, "profiles", "r01_bench_n1.json")))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline", "parity"):
+        assert k in j, k
+    assert j["metric"] == "Mpaths/sec at 252 steps" and j["unit"] == "Mpaths/s" and j["dtype"] == "f64"
+    assert j["scaling"] == "weak" and j["higher_is_better"] is True and j["vs_baseline"] is None
+    assert "workload" in j["config"] and "model" not in j["config"]
+    r = j["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    alg = 8.0 * 253 * j["config"]["paths_per_gpu"]
+    assert r["algorithmic_bytes_per_launch"] == alg
+    assert abs(r["achieved"] - alg / (r["kernel_avg_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
+    assert r["traffic"] is None or 0.99 * alg < r["traffic"] < 1.05 * alg          # PMC bytes ~ algorithmic bytes
+    # whole-job throughput = paths of all ranks / time
+    assert abs(j["value"] - j["config"]["global_paths"] / (j["ms_per_step"] * 1e-3) / 1e6) < 1e-6 * j["value"]
+    c = j["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["unit"] == "Mpaths/s" and "sample" in c
+    assert j["parity"]["abs_err_over_std_err"] <= 2.0
