@@ -5,15 +5,17 @@
 //
 // Pinning status (see DESIGN.md "Oracle"):
 //   * path-engine numerics (estimators, FFT, lambda, phi, fractionalGaussian, forwardVariance,
-//     payoff): PINNED bit-for-bit against the compiled reference (oracle/_ref/libmcref.so, built
-//     from /root/reference/src/models/RoughVolatility.cpp) via tests/golden/*.json.
+//     payoff), AsymptoticAnalysis and the BranchingProcesses lower bound: PINNED bit-for-bit against the
+//     compiled reference (oracle/_ref/libmcref.so, built in place from /root/reference/src/models/
+//     {RoughVolatility,AsymptoticAnalysisPricer,BranchingProcessPricer}.cpp) via tests/golden/*.npz.
 //   * path generation: the reference is unseeded (std::random_device per call), so parity is
 //     statistical; "mt" mode below reproduces the reference's RNG consumption order with an explicit
 //     seed, "philox" mode mirrors the device algorithm draw-for-draw.
-//   * LSM: PARITY UNPINNED at the Eigen boundary -- Eigen3 is not in this image and the reference
-//     has no tests; `orc_lsm_price` restates LSMPricer.cpp with an independent one-sided Jacobi SVD
-//     (min-norm least squares, Eigen's rank threshold) and is cross-checked against LAPACK gelsd
-//     (numpy.linalg.lstsq) in tests/.
+//   * LSM and MartingaleOptimization: PARITY UNPINNED at the Eigen boundary -- Eigen3 is not in this image and
+//     the reference has no tests; `orc_lsm_price` / `orc_martingale_price` restate the two pricers with an
+//     independent one-sided Jacobi SVD (min-norm least squares, Eigen's rank threshold) and are cross-checked
+//     against LAPACK gelsd (numpy.linalg.lstsq) in tests/.
+//   * BranchingProcesses upper bound: the reference resamples with an unseeded mt19937; compared statistically.
 //
 // Every function cites the reference lines it follows (paths relative to /root/reference).
 // Build: g++ -O2 -std=c++17 -ffp-contract=off -fopenmp -shared -fPIC (oracle/Makefile).
