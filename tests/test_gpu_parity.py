@@ -646,3 +646,33 @@ def test_full_size_c3_c4_properties(eng):
     fwd = math.exp(0.04 * T) * (c - p) + 100.0
     assert abs(fwd - 100.0 * math.exp(0.04 * T)) <= 2.5 * math.exp(0.04 * T) * math.hypot(cse, pse)
     assert math.isfinite(c) and c > 0
+
+
+def test_lsm_prices_vs_independent_reference_samples(eng, orc):
+    """SURVEY 8(d) parity statistic for the LSM configs: z = |price_gpu - price_ref| / std-err <= 2, where price_ref is
+    the CPU-restated reference LSM on INDEPENDENT samples (different generator, different draws): C3-shaped (GBM,
+    50 dates) against eight oracle samples of 1e5 paths, C5-shaped (rBergomi, reference-faithful "mt" generator:
+    fresh mt19937 streams, complex FFT per path) against six samples of 2e4 paths.  The spread BETWEEN the samples
+    is the error bar: the per-path standard error of an LSM price ignores the noise of the shared regression
+    coefficients and is about half of it at these sizes."""
+    def spread(prices):
+        a = np.asarray(prices)
+        return float(a.mean()), float(a.std(ddof=1)) / math.sqrt(len(a))
+
+    ref, ref_se = spread([orc.lsm_price(orc.paths_gbm(1000 + k, 100.0, 0.04, 0.2, 0.02, 50, 0, 100_000), 0.04, 100.0, 1.0, 0.02,
+                                        False, 2) for k in range(8)])
+    P = eng.gbm(SEED, 100.0, 0.04, 0.2, 0.02, 50, 1_000_000)
+    am, ase = eng.price_lsm(P, 0.04, 100.0, 1.0, 0.02, False, 2)
+    P.free()
+    z = abs(am - ref) / math.hypot(2.0 * ase, ref_se)
+    assert z <= 2.0, ("C3", am, ase, ref, ref_se, z)
+
+    steps, T = 64, 64 * DT
+    ref, ref_se = spread([orc.lsm_price(orc.generate_paths_mt(RB["S0"], RB["r"], RB["xi"], RB["H"], RB["eta"], RB["rho"], steps,
+                                                              20_000, 2024 + k), RB["r"], 100.0, T, DT, False, 2, step_major=False)
+                          for k in range(6)])
+    R = eng.rbergomi(SEED, RB["S0"], RB["r"], RB["xi"], RB["H"], RB["eta"], RB["rho"], DT, steps, 400_000)
+    am, ase = eng.price_lsm(R, RB["r"], 100.0, T, DT, False, 2)
+    R.free()
+    z = abs(am - ref) / math.hypot(2.0 * ase, ref_se)
+    assert z <= 2.0, ("C5-shaped", am, ase, ref, ref_se, z)
