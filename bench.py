@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: Mpaths/s at 252 steps (BASELINE.json metric).
 
-Workload (BASELINE.json configs[1], "C2"): European call, GBM, 10M paths x 252 steps per GPU,
+Default workload (BASELINE.json configs[1], "C2"): European call, GBM, 10M paths x 252 steps per GPU,
 S0 = K = 100, r = 0.04, sigma = 0.2, dt = 1/252, Philox seed 20251031.  One "step" = one full pass
 of the hot path: Philox normals -> GBM stepping -> the (253 x 10M) fp64 matrix written to HBM ->
 per-path payoff -> wavefront-shuffle reduction -> (N>1: one all-reduce of 3 doubles) -> price.
@@ -11,9 +11,16 @@ Inputs are parameters only, so everything is resident when the timed region star
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
+`--config c5` runs BASELINE.json configs[4] instead: rBergomi (H = 0.1, eta = 1.9) American put, Longstaff-Schwartz
+order 2, 252 steps, 8M paths per GPU (N = 8: the 64M-path job), one step = generate the shard's matrix + the backward
+sweep with one all-reduce of the 3p+2 regression moments per exercise date.
+
 Weak scaling: every rank owns `--paths` global path ids [rank*paths, (rank+1)*paths) of ONE Philox
-stream; no data-path collective except the 3-double payoff all-reduce.  Prints ONE JSON line on
-rank 0 with the driver's contract fields plus "roofline" and "cpu_baseline" (N=1 only).
+stream; no data-path collective except the payoff / moment all-reduces.  The collective is the library's built-in RCCL
+communicator (mcg_comm_init_rank: issued from C on the ctx's stream, nothing on the host waits per date); `--collective
+torch` routes it through torch.distributed instead.  Prints ONE JSON line on rank 0 with the driver's contract fields
+plus "roofline", "cpu_baseline" (N=1 only) and, for the default run at N=1, "extra.configs": C3, C4 and the C5 shard
+timed once each after the headline loop.
 """
 from __future__ import annotations
 
@@ -29,6 +36,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
+N_SIMDS = 1024         # 256 CUs x 4 SIMDs
+SEED = 20251031
+DT = 1.0 / 252.0
+RB = dict(S0=100.0, r=0.04, xi=0.04, H=0.1, eta=1.9, rho=-0.9)
 
 
 def bs_call(S0, K, r, sigma, T):
@@ -101,18 +112,129 @@ def reference_parity(eng, mc, ref_price: dict, n_steps: int, seed: int) -> dict:
             "abs_diff_over_combined_std_err": abs(price - ref_price["mean_payoff"]) / comb if comb > 0 else None}
 
 
+def rough_regime_parity(eng) -> dict:
+    """C4 / C5 parameters against the committed sample of the compiled reference (tests/golden/
+    rough_regime_reference.json, oracle/gen_rough_fixture.py): undiscounted call and put at 252 and 512 steps."""
+    path = os.path.join(ROOT, "tests", "golden", "rough_regime_reference.json")
+    if not os.path.exists(path):
+        return {}
+    fx = json.load(open(path))
+    p, out = fx["params"], {}
+    for steps in ("252", "512"):
+        fix = fx["samples"][steps]
+        for is_call, idx, name in ((True, 1, "call"), (False, 2, "put")):
+            P = eng.rbergomi(SEED, p["S0"], p["r"], p["xi"], p["H"], p["eta"], p["rho"], DT, int(steps), 4_000_000,
+                             payoff=(p["strike"], is_call))
+            m, se = eng.price_european(P, p["strike"], 0.0, 0.0, is_call)
+            P.free()
+            out[f"{name}_{steps}_steps"] = {"gpu": m, "gpu_std_err": se, "reference": fix["mean"][idx],
+                                            "reference_std_err": fix["std_err"][idx], "reference_paths": fix["paths"],
+                                            "abs_diff_over_combined_std_err":
+                                                abs(m - fix["mean"][idx]) / math.hypot(se, fix["std_err"][idx])}
+    return out
+
+
+def valu_profile(name: str):
+    """Committed PMC summary of a kernel (profiles/*_valu_counters.json): VALU instructions per launch at the profiled
+    path count and the shader clock measured in the same passes.  None when no profile is committed."""
+    best = None
+    pdir = os.path.join(ROOT, "profiles")
+    for f in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+        if f.endswith("_valu_counters.json") and name in f:
+            best = os.path.join(pdir, f)  # sorted: the latest round wins
+    if not best:
+        return None
+    try:
+        j = json.load(open(best))
+        return {"insts": j["counters_mean_per_launch"]["SQ_INSTS_VALU"], "clock_GHz": j["derived"]["shader_clock_GHz"],
+                "paths": j.get("paths_per_launch"), "source": os.path.relpath(best, ROOT)}
+    except Exception:
+        return None
+
+
+def extra_configs(eng, N) -> list:
+    """C3, C4 and the C5 shard on this GPU, once each (one untimed pass, then 3 timed), after the headline loop:
+    ms per pass, Mpaths/s, the dominant kernel's average launch time and what it achieves against the HBM roofline
+    (SURVEY 8d algorithmic bytes) and against the VALU issue rate (instruction count from the committed PMC profile)."""
+    reps = 3
+    out = []
+
+    def c3():
+        P = eng.gbm(SEED, 100.0, 0.04, 0.2, 0.02, 50, 1_000_000)
+        r = eng.price_lsm(P, 0.04, 100.0, 1.0, 0.02, False, 2)
+        P.free()
+        return r
+
+    def c4():
+        P = eng.rbergomi(SEED, RB["S0"], RB["r"], RB["xi"], RB["H"], RB["eta"], RB["rho"], DT, 512, 4_000_000, payoff=(100.0, True))
+        r = eng.price_european(P, 100.0, RB["r"], 512 * DT, True)
+        P.free()
+        return r
+
+    def c5():
+        P = eng.rbergomi(SEED, RB["S0"], RB["r"], RB["xi"], RB["H"], RB["eta"], RB["rho"], DT, 252, 8_000_000)
+        r = eng.price_lsm(P, RB["r"], 100.0, 1.0, DT, False, 2)
+        P.free()
+        return r
+
+    # (name, pass, paths, dominant kernel id, algorithmic bytes of ALL launches of that kernel in one pass, valu profile key)
+    specs = [
+        ("C3: American put, LSM order 2, GBM, 1M paths x 50 exercise dates", c3, 1_000_000, N.K_LSM_SWEEP,
+         40.0 * 50 * 1_000_000, None),
+        ("C4: rBergomi European call (H=0.1), 4M paths x 512 steps", c4, 4_000_000, N.K_RBERGOMI, 8.0 * 513 * 4_000_000, "c4"),
+        ("C5 shard: rBergomi American put LSM order 2, 8M paths x 252 steps (1/8 of the 64M job)", c5, 8_000_000,
+         N.K_LSM_SWEEP, 40.0 * 252 * 8_000_000, None),
+    ]
+    for name, fn, paths, kid, alg_bytes, vkey in specs:
+        fn()
+        eng.synchronize()
+        eng.timing_reset()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            res = fn()
+        eng.synchronize()
+        ms = (time.perf_counter() - t0) / reps * 1e3
+        kernels = {}
+        for k, kname in N.KERNEL_NAMES.items():
+            tot, cnt = eng.timing_get(k)
+            if cnt:
+                kernels[kname] = {"ms_per_pass": tot / reps, "launches_per_pass": cnt // reps}
+        dom = kernels[N.KERNEL_NAMES[kid]]
+        row = {"config": name, "paths": paths, "ms_per_pass": ms, "Mpaths_per_s": paths / ms / 1e3,
+               "price": res[0], "std_err": res[1], "kernels": kernels, "dominant_kernel": N.KERNEL_NAMES[kid],
+               "dominant_kernel_ms_per_pass": dom["ms_per_pass"],
+               "algorithmic_bytes_per_pass": alg_bytes,
+               "hbm_frac": alg_bytes / (dom["ms_per_pass"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        if "rbergomi" in kernels:  # the generation half, against the HBM-write roofline of its own matrix
+            steps = 512 if name.startswith("C4") else 252
+            g = kernels["rbergomi"]["ms_per_pass"]
+            row["generation_hbm_frac"] = 8.0 * (steps + 1) * paths / (g * 1e-3) / 1e9 / HBM_PEAK_GBS
+            vp = valu_profile("c4" if steps == 512 else "c5gen")
+            if vp and vp.get("paths"):
+                insts = vp["insts"] * paths / vp["paths"]
+                row["generation_valu_issue_frac"] = insts * 4.0 / (N_SIMDS * vp["clock_GHz"] * 1e9 * g * 1e-3)
+                row["valu_source"] = (f"{vp['source']}: SQ_INSTS_VALU per launch scaled to {paths} paths x 4 cycles / "
+                                      f"({N_SIMDS} SIMDs x {vp['clock_GHz']:.2f} GHz measured there x kernel time measured here)")
+        out.append(row)
+    return out
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10, help="timed passes of the hot path")
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--paths", type=int, default=10_000_000, help="paths per GPU (C2: 10M)")
+    ap.add_argument("--config", default="c2", choices=["c2", "c5"], help="c2: GBM European (headline); c5: rBergomi LSM shard")
+    ap.add_argument("--paths", type=int, default=0, help="paths per GPU (default: 10M for c2, 8M for c5)")
     ap.add_argument("--time-steps", type=int, default=252)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--collective", default=os.environ.get("MCG_COLLECTIVE", "torch"), choices=["torch", "rccl"])
+    ap.add_argument("--no-extra", action="store_true", help="skip the C3/C4/C5-shard timings after the headline loop")
+    ap.add_argument("--collective", default=os.environ.get("MCG_COLLECTIVE", "rccl"), choices=["rccl", "torch"])
     ap.add_argument("--backend", default=os.environ.get("MCG_DIST_BACKEND", "nccl"), choices=["nccl", "gloo"],
                     help="torch.distributed backend; gloo lets several ranks share one GPU (rehearsal only)")
     args = ap.parse_args()
+    if args.paths <= 0:
+        args.paths = 10_000_000 if args.config == "c2" else 8_000_000
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -139,35 +261,65 @@ def main() -> None:
         else:
             dist.init_process_group(backend="gloo", rank=rank, world_size=world)
 
-    S0, K, r, sigma, dt = 100.0, 100.0, 0.04, 0.2, 1.0 / 252.0
-    n_steps, seed = args.time_steps, 20251031
+    S0, K, r, sigma, dt = 100.0, 100.0, 0.04, 0.2, DT
+    n_steps, seed = args.time_steps, SEED
     T = n_steps * dt
     total_paths = args.paths * world
-    begin, count = shard_range(total_paths, rank, world)
+    begin, count = shard_range(total_paths, rank, world, align=2 if args.config == "c5" else 1)
 
     stream = torch.cuda.current_stream().cuda_stream if dist is not None else None
     eng = mc.PathEngine(device, stream=stream)
+    collective = "none"
     if dist is not None:
-        if args.collective == "rccl":
+        collective = args.collective
+        if collective == "rccl":
             def bcast(uid):
                 box = [uid]
                 dist.broadcast_object_list(box, src=0)
                 return box[0]
-            eng.init_rccl(rank, world, bcast)
+            try:
+                eng.init_rccl(rank, world, bcast)
+            except mc.McgError as e:           # communicator set-up failed on this node: use torch's, and say so
+                print(f"bench: built-in RCCL communicator unavailable ({e}); using torch.distributed", file=sys.stderr)
+                collective = "torch (built-in RCCL init failed)"
+            ok = torch.tensor([1 if collective == "rccl" else 0], device="cuda")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)    # all ranks take the same route
+            if int(ok.item()) == 0:
+                collective = collective if collective != "rccl" else "torch (built-in RCCL init failed on a peer)"
+                eng.use_torch_distributed()
         else:
             eng.use_torch_distributed()
 
-    def one_pass():
-        P = eng.gbm(seed, S0, r, sigma, dt, n_steps, count, path_begin=begin, payoff=(K, True))
-        price, se = eng.price_european(P, K, r, T, True)
-        P.free()
-        return price, se
+    if args.config == "c2":
+        k_main = N.K_GBM
+        alg_bytes = 8.0 * (n_steps + 1) * count          # SURVEY 8(d): 8*(steps+1) B written per path
 
-    RAMP_LAUNCHES = 12
+        def one_pass():
+            P = eng.gbm(seed, S0, r, sigma, dt, n_steps, count, path_begin=begin, payoff=(K, True))
+            price, se = eng.price_european(P, K, r, T, True)
+            P.free()
+            return price, se
+
+        def ramp_launch():
+            eng.gbm(seed, S0, r, sigma, dt, n_steps, count, path_begin=begin).free()
+    else:
+        k_main = N.K_RBERGOMI
+        alg_bytes = 8.0 * (n_steps + 1) * count
+
+        def one_pass():
+            P = eng.rbergomi(seed, RB["S0"], RB["r"], RB["xi"], RB["H"], RB["eta"], RB["rho"], dt, n_steps, count, path_begin=begin)
+            price, se = eng.price_lsm(P, RB["r"], K, T, dt, False, 2)
+            P.free()
+            return price, se
+
+        def ramp_launch():
+            eng.rbergomi(seed, RB["S0"], RB["r"], RB["xi"], RB["H"], RB["eta"], RB["rho"], dt, n_steps, count, path_begin=begin).free()
+
+    RAMP_LAUNCHES = 12 if args.config == "c2" else 4
 
     def run_ramp():
         for _ in range(RAMP_LAUNCHES):
-            eng.gbm(seed, S0, r, sigma, dt, n_steps, count, path_begin=begin).free()  # asynchronous, one reused buffer
+            ramp_launch()  # asynchronous, one reused buffer
 
     def fence(ramp=False):
         """barrier + synchronize on both sides of the timed region.
@@ -203,41 +355,63 @@ def main() -> None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    k_ms, k_n = eng.timing_get(N.K_GBM)
-    eng.timing_enable(False)
+    k_ms, k_n = eng.timing_get(k_main)
+    sweep_ms, sweep_n = eng.timing_get(N.K_LSM_SWEEP)
+    solve_ms, solve_n = eng.timing_get(N.K_LSM_SOLVE)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = total_paths * args.steps / elapsed / 1e6
-        alg_bytes = 8.0 * (n_steps + 1) * count          # SURVEY 8(d): 8*(steps+1) B written per path
         k_avg_ms = k_ms / max(k_n, 1)
         achieved = alg_bytes / (k_avg_ms * 1e-3) / 1e9
-        traffic = None
+        traffic, traffic_source = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
+        if args.config == "c2" and os.path.exists(pmc):
             try:
                 j = json.load(open(pmc))
                 if j.get("paths") == count and j.get("time_steps") == n_steps:
                     traffic = j.get("hbm_bytes_per_launch")
+                    traffic_source = ("profiles/pmc_traffic.json (committed: rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes "
+                                      "of this command, tools/pmc_traffic.sh; not re-measured in this run)")
             except Exception:
                 traffic = None
-        ref = bs_call(S0, K, r, sigma, T)
+        if args.config == "c2":
+            workload = "C2: European call, GBM, 10M paths x 252 steps per GPU, fp64 matrix written"
+            sharding = f"contiguous path ids over {world} rank(s); one 3-double all-reduce"
+            ref = bs_call(S0, K, r, sigma, T)
+            parity = {"price": price, "std_err": se, "black_scholes": ref,
+                      "abs_err_over_std_err": abs(price - ref) / se if se > 0 else None}
+            kernel_name = "k_gbm_paths"
+        else:
+            workload = ("C5: rBergomi (H=0.1, eta=1.9) American put, Longstaff-Schwartz order 2, 8M paths x 252 steps per GPU "
+                        "(8 GPUs: the 64M-path job), fp64 matrix written then swept backwards")
+            sharding = (f"contiguous even-aligned path ids over {world} rank(s); per exercise date one all-reduce of 8 "
+                        "regression moments, then 3 doubles of final sums")
+            parity = {"price": price, "std_err": se}
+            kernel_name = "k_rbergomi_fft"
         out = {
             "metric": "Mpaths/sec at 252 steps", "value": value, "unit": "Mpaths/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "C2: European call, GBM, 10M paths x 252 steps per GPU, fp64 matrix written",
+            "config": {"workload": workload,
                        "paths_per_gpu": args.paths, "time_steps": n_steps, "global_paths": total_paths,
-                       "sharding": f"contiguous path ids over {world} rank(s); one 3-double all-reduce",
-                       "S0": S0, "K": K, "r": r, "sigma": sigma, "seed": seed,
+                       "sharding": sharding, "collective": collective,
+                       "S0": S0, "K": K, "r": r, "sigma": sigma if args.config == "c2" else None, "seed": seed,
                        "untimed_ramp_launches": RAMP_LAUNCHES},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_gbm_paths",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                         "kernel": kernel_name,
                          "kernel_avg_ms": k_avg_ms, "launches": int(k_n),
                          "algorithmic_bytes_per_launch": alg_bytes},
-            "parity": {"price": price, "std_err": se, "black_scholes": ref,
-                       "abs_err_over_std_err": abs(price - ref) / se if se > 0 else None},
+            "parity": parity,
         }
+        if args.config == "c5":
+            per_pass = max(args.steps, 1)
+            out["roofline"]["lsm"] = {
+                "sweep_ms_per_pass": sweep_ms / per_pass, "sweep_launches_per_pass": sweep_n // per_pass,
+                "solve_ms_per_pass": solve_ms / per_pass, "solve_launches_per_pass": solve_n // per_pass,
+                "algorithmic_bytes_per_pass": 40.0 * n_steps * count,   # 40 B per path and date
+                "hbm_frac": 40.0 * n_steps * count / max(sweep_ms / per_pass * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 cb = cpu_baseline(n_steps)
@@ -248,7 +422,14 @@ def main() -> None:
             except Exception as e:  # the baseline is reported, never required for the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "Mpaths/s", "cores": 0, "kind": "port",
                                        "sample": f"failed: {e}"}
+        if world == 1 and dist is None and args.config == "c2" and not args.no_extra:
+            try:
+                out["parity"]["rough_regime_vs_reference_sample"] = rough_regime_parity(eng)
+                out["extra"] = {"configs": extra_configs(eng, N)}
+            except Exception as e:
+                out["extra"] = {"configs": [], "error": str(e)}
         print(json.dumps(out), flush=True)
+    eng.timing_enable(False)
     eng.close()
     if dist is not None:
         dist.barrier()

@@ -84,6 +84,7 @@ def load_library():
     L.mcg_paths_free.argtypes = [vp]
     L.mcg_price_european.argtypes = [vp, vp, C.c_double, C.c_double, C.c_double, C.c_int, dp, dp]
     L.mcg_price_lsm.argtypes = [vp, vp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, dp, dp]
+    L.mcg_lsm_one_launch_enabled.argtypes = [vp, C.POINTER(C.c_int)]
     L.mcg_price_asymptotic.argtypes = [vp, vp] + [C.c_double] * 4 + [C.c_int, C.c_double, C.c_double, dp]
     L.mcg_compat_asymptotic_price.argtypes = [dp, C.c_int64, C.c_int] + [C.c_double] * 4 + [C.c_int, C.c_double, C.c_double, dp]
     L.mcg_price_martingale.argtypes = [vp, vp] + [C.c_double] * 4 + [C.c_int, C.c_int, C.c_int, dp, dp, dp]

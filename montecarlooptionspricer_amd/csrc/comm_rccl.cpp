@@ -5,8 +5,10 @@
 // nothing on the host waits for it.
 #include <dlfcn.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <string>
 
 #include "mcg_internal.hpp"
 
@@ -31,13 +33,19 @@ std::once_flag g_once;
 std::string g_load_err;
 
 void load_rccl() {
+    // MCG_RCCL_LIB (tests: a path that does not exist exercises the failure branch) replaces the search list
+    const char* forced = std::getenv("MCG_RCCL_LIB");
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    std::string why = "?";
     for (const char* n : names) {
-        g_rccl.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        g_rccl.lib = dlopen(forced ? forced : n, RTLD_NOW | RTLD_LOCAL);
         if (g_rccl.lib) break;
+        const char* e = dlerror();  // one call: dlerror() clears the message it returns
+        if (e) why = e;
+        if (forced) break;
     }
     if (!g_rccl.lib) {
-        g_load_err = std::string("cannot dlopen librccl: ") + (dlerror() ? dlerror() : "?");
+        g_load_err = "cannot dlopen librccl: " + why;
         return;
     }
     g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(g_rccl.lib, "ncclGetUniqueId");
@@ -74,6 +82,21 @@ int rccl_allreduce(void* user, double* buf, int count, void* stream) {
 
 }  // namespace
 
+namespace mcg {
+
+// mcg_finalize: give the communicator back (after the stream has drained).
+void comm_release(mcg_ctx* ctx) {
+    if (!ctx->rccl_comm) return;
+    if (g_rccl.lib && g_rccl.CommDestroy) (void)g_rccl.CommDestroy((comm_t)ctx->rccl_comm);
+    ctx->rccl_comm = nullptr;
+    if (ctx->allreduce == rccl_allreduce) {
+        ctx->allreduce = nullptr;
+        ctx->allreduce_user = nullptr;
+    }
+}
+
+}  // namespace mcg
+
 extern "C" {
 
 int mcg_comm_unique_id(unsigned char id[128]) {
@@ -93,6 +116,7 @@ int mcg_comm_init_rank(mcg_ctx* ctx, const unsigned char id[128], int n_ranks, i
     MCG_HIP(hipSetDevice(ctx->device));
     NcclId nid;
     std::memcpy(nid.internal, id, 128);
+    mcg::comm_release(ctx);  // a second init on the same ctx replaces the communicator
     comm_t comm = nullptr;
     int rc = g_rccl.CommInitRank(&comm, n_ranks, nid, rank);
     if (rc != 0) return mcg::fail(MCG_ERR_COMM, "ncclCommInitRank failed: %s", nccl_err(rc));

@@ -45,6 +45,7 @@ struct BranchArgs {
     const int* ex;        // [n_ex] exercise column indices with t <= maturity (leading part of the list)
     const double* disc;   // [n_cols]
     int n_ex, ex_last, num_branches;
+    int n_cols;           // rows of S and F: the continuation of date t gathers from row t+1 < n_cols only
     double K;
     int is_call;
     double* partials;     // [grid][2]: sum of lower, sum of upper
@@ -70,7 +71,9 @@ __global__ __launch_bounds__(256) void k_branch_bounds(BranchArgs a) {
                 have_lower = true;
             }
             double better = now;
-            if (t_idx < a.ex_last && a.num_branches > 0) {  // :104-121
+            // :104-121.  A trailing exercise index at or beyond the last column (the reference tolerates one behind
+            // its `t > maturity` break, :97-99) leaves its `k` loop (:110) empty for t_idx = n_cols-1: continuation 0.
+            if (t_idx < a.ex_last && t_idx + 1 < a.n_cols && a.num_branches > 0) {
                 const double* row = a.F + (int64_t)(t_idx + 1) * a.ld;
                 double sum = 0.0;
                 for (int q = 0; q < quads; ++q) {
@@ -111,8 +114,8 @@ int run_branching(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double m
     std::vector<int> ex;
     for (int e = 0; e < n_ex_in; ++e) {
         const int t_idx = exercise_times[e];
+        if (t_idx * dt > maturity) break;  // :57-59, :97-99 (tested before the column is touched, like the reference)
         if (t_idx < 0 || t_idx >= n_cols) return fail(MCG_ERR_INVALID, "BranchingProcesses: exercise time %d outside [0,%d)", t_idx, n_cols);
-        if (t_idx * dt > maturity) break;  // :57-59, :97-99
         ex.push_back(t_idx);
     }
     const int ex_last = exercise_times[n_ex_in - 1];  // exerciseTimes.back(), :104
@@ -152,6 +155,7 @@ int run_branching(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double m
     a.disc = ctx->weights;
     a.n_ex = (int)ex.size();
     a.ex_last = ex_last;
+    a.n_cols = n_cols;
     a.num_branches = num_branches;
     a.K = K;
     a.is_call = is_call;

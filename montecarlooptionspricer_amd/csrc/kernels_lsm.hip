@@ -214,6 +214,7 @@ struct LsmCoopArgs {
     double* partials;  // [2][NM][gridDim.x], sentinel-filled
     double* coef;      // [2][16], sentinel-filled: coefficients, [9] = ITM count
     unsigned* timeout; // set when a spin gives up
+    unsigned spin_limit; // polling rounds before a spin gives up (LSM_SPIN_LIMIT; MCG_LSM_SPIN_LIMIT in tests)
     double* out;       // [2 * gridDim.x]: per-block {sum V, sum V^2}
 };
 
@@ -249,7 +250,9 @@ __global__ __launch_bounds__(256, (PPT >= 16 ? 2 : 3)) void k_lsm_coop(LsmCoopAr
     // columns first + q * stride exist for q < n_live (one per-lane integer instead of PPT lane masks)
     const int n_live = (int64_t)first < a.n ? (int)std::min<int64_t>(PPT, (a.n - 1 - first) / stride + 1) : 0;
     int parity = 0;
-    bool gave_up = false;  // this thread has hit the spin limit once
+    bool gave_up = a.spin_limit == 0;  // this thread has hit the spin limit once (limit 0, tests: from the start)
+    if (gave_up && blockIdx.x == 0 && threadIdx.x == 0)
+        __hip_atomic_store(a.timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     double V[PPT];
     {
         const double* last = a.data + (int64_t)(a.n_cols - 1) * a.ld;
@@ -336,7 +339,7 @@ __global__ __launch_bounds__(256, (PPT >= 16 ? 2 : 3)) void k_lsm_coop(LsmCoopAr
                     for (int k = 0; k < K; ++k) missing = missing || lsm_is_sentinel(v0[k]) || lsm_is_sentinel(v1[k]);
                     if (missing) {
                         __builtin_amdgcn_s_sleep(1);
-                        if (++spins > LSM_SPIN_LIMIT) {
+                        if (++spins > a.spin_limit) {
                             __hip_atomic_store(a.timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             gave_up = true;
                             break;
@@ -374,7 +377,7 @@ __global__ __launch_bounds__(256, (PPT >= 16 ? 2 : 3)) void k_lsm_coop(LsmCoopAr
                 unsigned spins = 0;
                 while (lsm_is_sentinel(cv) && !gave_up) {
                     __builtin_amdgcn_s_sleep(1);
-                    if (++spins > LSM_SPIN_LIMIT) {
+                    if (++spins > a.spin_limit) {
                         __hip_atomic_store(a.timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         gave_up = true;
                         break;
@@ -512,6 +515,10 @@ static int run_lsm_coop(mcg_ctx* ctx, const mcg_paths* P, double r, double K, do
     a.partials = ctx->partials + 2 * (size_t)grid;
     a.coef = a.partials + 2 * (size_t)nm * grid;
     a.timeout = reinterpret_cast<unsigned*>(ctx->scalars + SC_BARRIER);
+    // test hook: MCG_LSM_SPIN_LIMIT=0 makes every wait give up at once and raises the time-out flag, which drives
+    // the time-out -> per-date fall-back branch below on a healthy device (read on every call: tests flip it)
+    a.spin_limit = LSM_SPIN_LIMIT;
+    if (const char* e = std::getenv("MCG_LSM_SPIN_LIMIT")) a.spin_limit = (unsigned)std::strtoul(e, nullptr, 10);
     MCG_HIP(hipMemsetD32Async((hipDeviceptr_t)a.partials, (int)LSM_SENTINEL32, 2 * n_slots, ctx->stream));
     MCG_HIP(hipMemsetAsync(a.timeout, 0, sizeof(unsigned), ctx->stream));
     void* params[] = {&a};

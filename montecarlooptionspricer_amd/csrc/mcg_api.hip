@@ -1,5 +1,6 @@
 // C ABI of libmcgpu.so (include/mcgpu.h): context, device-buffer pool, error plumbing, timing,
 // path-matrix handles and layout conversion.  The numerical kernels live in kernels_*.hip.
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -86,7 +87,12 @@ TimedLaunch::TimedLaunch(mcg_ctx* c, int k) : ctx(c), kernel(k), on(c->timing) {
         ev = ctx->ev_free.back();
         ctx->ev_free.pop_back();
     } else {
-        if (hipEventCreate(&ev.a) != hipSuccess || hipEventCreate(&ev.b) != hipSuccess) {
+        if (hipEventCreate(&ev.a) != hipSuccess) {
+            on = false;
+            return;
+        }
+        if (hipEventCreate(&ev.b) != hipSuccess) {
+            (void)hipEventDestroy(ev.a);
             on = false;
             return;
         }
@@ -135,6 +141,7 @@ int paths_new(mcg_ctx* ctx, int64_t n_paths, int n_steps, uint64_t path_begin, m
         return rc;
     }
     P->data = (double*)p;
+    ctx->live_paths.push_back(P);
     *out = P;
     return MCG_OK;
 }
@@ -160,12 +167,17 @@ __global__ __launch_bounds__(256) void k_transpose(const double* __restrict__ sr
 static int transpose(mcg_ctx* ctx, const double* src, int64_t src_ld, double* dst, int64_t dst_ld, int64_t R,
                      int64_t C) {
     if (R == 0 || C == 0) return MCG_OK;
-    const int64_t gx = (C + 31) / 32, gy = (R + 31) / 32;
-    if (gy > 65535) return fail(MCG_ERR_INVALID, "transpose: too many rows for one launch");
-    {
-        TimedLaunch t(ctx, MCG_K_TRANSPOSE);
-        hipLaunchKernelGGL(k_transpose, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, ctx->stream, src, src_ld, dst,
-                           dst_ld, R, C);
+    // gridDim.y and gridDim.x are limited (65535 and 2^31-1 blocks): walk over-long dimensions in slabs
+    constexpr int64_t MAX_Y = 65535ll * 32, MAX_X = 0x7fffffffll / 32 * 32;
+    for (int64_t r0 = 0; r0 < R; r0 += MAX_Y) {
+        const int64_t Rs = std::min(R - r0, MAX_Y);
+        for (int64_t c0 = 0; c0 < C; c0 += MAX_X) {
+            const int64_t Cs = std::min(C - c0, MAX_X);
+            const int64_t gx = (Cs + 31) / 32, gy = (Rs + 31) / 32;
+            TimedLaunch t(ctx, MCG_K_TRANSPOSE);
+            hipLaunchKernelGGL(k_transpose, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, ctx->stream,
+                               src + r0 * src_ld + c0, src_ld, dst + c0 * dst_ld + r0, dst_ld, Rs, Cs);
+        }
     }
     MCG_HIP(hipGetLastError());
     return MCG_OK;
@@ -259,6 +271,13 @@ int mcg_finalize(mcg_ctx* ctx) {
     if (!ctx) return MCG_OK;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    comm_release(ctx);
+    for (mcg_paths* P : ctx->live_paths) {  // handles the caller still holds: orphan them (see mcg_paths_free)
+        if (P->data) (void)hipFree(P->data);
+        P->data = nullptr;
+        P->ctx = nullptr;
+    }
+    ctx->live_paths.clear();
     for (auto& b : ctx->pool) (void)hipFree(b.ptr);
     ctx->pool.clear();
     for (auto& kv : ctx->ev_live) {
@@ -418,6 +437,7 @@ int mcg_paths_from_host(mcg_ctx* ctx, const double* row_major, int64_t n_paths, 
 int mcg_paths_to_host(const mcg_paths* P, double* row_major_out) {
     if (!P || !row_major_out) return fail(MCG_ERR_INVALID, "paths/out is NULL");
     mcg_ctx* ctx = P->ctx;
+    if (!ctx) return fail(MCG_ERR_INVALID, "paths outlived their ctx (mcg_finalize was called first)");
     if (P->n_paths == 0) return MCG_OK;
     MCG_HIP(hipSetDevice(ctx->device));
     const int n_cols = P->n_steps + 1;
@@ -442,6 +462,7 @@ int mcg_paths_to_host(const mcg_paths* P, double* row_major_out) {
 
 int mcg_paths_to_host_step_major(const mcg_paths* P, double* out) {
     if (!P || !out) return fail(MCG_ERR_INVALID, "paths/out is NULL");
+    if (!P->ctx) return fail(MCG_ERR_INVALID, "paths outlived their ctx (mcg_finalize was called first)");
     if (P->n_paths == 0) return MCG_OK;
     MCG_HIP(hipSetDevice(P->ctx->device));
     MCG_HIP(hipMemcpy2DAsync(out, (size_t)P->n_paths * sizeof(double), P->data, (size_t)P->ld * sizeof(double),
@@ -462,7 +483,16 @@ int mcg_paths_info(const mcg_paths* P, int64_t* n_paths, int* n_steps, int64_t* 
 
 int mcg_paths_free(mcg_paths* P) {
     if (!P) return MCG_OK;
-    if (P->data) pool_release(P->ctx, P->data, P->bytes);
+    if (mcg_ctx* ctx = P->ctx) {  // NULL: the ctx was finalized first and took the device memory with it
+        if (P->data) pool_release(ctx, P->data, P->bytes);
+        for (size_t i = ctx->live_paths.size(); i-- > 0;) {  // usually the most recent handle
+            if (ctx->live_paths[i] == P) {
+                ctx->live_paths[i] = ctx->live_paths.back();
+                ctx->live_paths.pop_back();
+                break;
+            }
+        }
+    }
     delete P;
     return MCG_OK;
 }
@@ -508,6 +538,12 @@ int mcg_price_lsm(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double m
     if (P->n_paths < 1 && !ctx->allreduce) return fail(MCG_ERR_EMPTY_PATHS, "LSM::PredictOptionPrice: Empty pricePaths.");
     MCG_HIP(hipSetDevice(ctx->device));
     return run_lsm(ctx, P, r, K, maturity, dt, is_call, poly_order, mean, std_err);
+}
+
+int mcg_lsm_one_launch_enabled(mcg_ctx* ctx, int* enabled) {
+    if (!ctx || !enabled) return fail(MCG_ERR_INVALID, "ctx/enabled is NULL");
+    *enabled = ctx->coop_launch ? 1 : 0;
+    return MCG_OK;
 }
 
 int mcg_price_asymptotic(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double maturity, double dt, int is_call,

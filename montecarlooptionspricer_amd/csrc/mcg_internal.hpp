@@ -46,6 +46,9 @@ struct mcg_ctx {
 
     // cached device buffers (path matrices are tens of GB: never hipMalloc per call in steady state)
     std::vector<mcg::PoolBuf> pool;
+    // path-matrix handles handed out and not yet freed: mcg_finalize takes their device memory back and orphans
+    // them (ctx = data = NULL), so a late mcg_paths_free only deletes the handle instead of touching a dead ctx
+    std::vector<mcg_paths*> live_paths;
     // small persistent workspace
     double* partials = nullptr;  // per-block partial sums
     size_t partials_cap = 0;     // in doubles
@@ -83,7 +86,7 @@ struct mcg_paths {
     bool has_sums = false;
     double sums_K = 0.0;
     int sums_is_call = 0;
-    double sums[3] = {0, 0, 0};  // host copy {sum, sumsq, n}, local shard
+    double sums[3] = {0, 0, 0};  // host copy {sum, sumsq, n}: all-reduced totals when the ctx has a collective
 };
 
 namespace mcg {
@@ -109,6 +112,8 @@ struct TimedLaunch {
     TimedLaunch(mcg_ctx* c, int k);
     ~TimedLaunch();
 };
+
+void comm_release(mcg_ctx* ctx);  // comm_rccl.cpp
 
 int paths_new(mcg_ctx* ctx, int64_t n_paths, int n_steps, uint64_t path_begin, mcg_paths** out);
 

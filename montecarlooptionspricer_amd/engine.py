@@ -8,6 +8,7 @@ cross-rank all-reduce.
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 from typing import Callable, Optional, Tuple
 
 import numpy as np
@@ -34,6 +35,7 @@ class PathMatrix:
         check(engine._L.mcg_paths_info(handle, C.byref(n_paths), C.byref(n_steps), C.byref(ld), C.byref(ptr)))
         self.n_paths, self.n_steps, self.ld = n_paths.value, n_steps.value, ld.value
         self.device_ptr = ptr.value or 0
+        engine._live.add(self)
 
     @property
     def nbytes_algorithmic(self) -> int:
@@ -55,9 +57,13 @@ class PathMatrix:
         return out
 
     def free(self) -> None:
-        if self._h is not None:
-            self._engine._L.mcg_paths_free(self._h)
-            self._h = None
+        """Give the device buffer back to the engine's pool.  Safe in any order with PathEngine.close(): close()
+        frees the matrices that are still alive first, so a late free() (or the garbage collector) finds nothing
+        left to do."""
+        h, self._h = self._h, None
+        if h is not None:
+            self._engine._live.discard(self)
+            self._engine._L.mcg_paths_free(h)
 
     def _alive(self):
         if self._h is None:
@@ -82,10 +88,13 @@ class PathEngine:
             check(self._L.mcg_init_on_stream(C.byref(self._ctx), int(device), C.c_void_p(int(stream))))
         self._cb = None  # keep the ctypes callback alive
         self.device = device
+        self._live = weakref.WeakSet()  # PathMatrix objects whose device buffer belongs to this ctx
 
     # -- lifecycle ------------------------------------------------------------------------------
     def close(self) -> None:
         if self._ctx:
+            for m in list(self._live):  # matrices nobody freed (an exception skipped P.free()): before the ctx goes
+                m.free()
             self._L.mcg_finalize(self._ctx)
             self._ctx = C.c_void_p()
 
@@ -203,6 +212,12 @@ class PathEngine:
         check(self._L.mcg_price_lsm(self._ctx, paths._h, r, K, maturity, dt, int(bool(is_call)), int(poly_order),
                                     C.byref(m), C.byref(se)))
         return m.value, se.value
+
+    def lsm_one_launch_enabled(self) -> bool:
+        """False once the one-launch LSM sweep's hand-shake has timed out on this ctx (mcg_lsm_one_launch_enabled)."""
+        v = C.c_int()
+        check(self._L.mcg_lsm_one_launch_enabled(self._ctx, C.byref(v)))
+        return bool(v.value)
 
     def price_asymptotic(self, paths: PathMatrix, r: float, K: float, maturity: float, dt: float, is_call: bool,
                          sigma: float, dividend: float) -> float:

@@ -14,6 +14,8 @@
 #include <random>
 #include <stdexcept>
 #include <string>
+#include <utility>
+#include <vector>
 
 #include "../../include/mcgpu/dropin.hpp"
 #include "../csrc/mcg_internal.hpp"
@@ -26,22 +28,38 @@ namespace {
 struct ThreadCtx {
     mcg_ctx* ctx = nullptr;
     // The reference's driver hands the SAME host matrix to four pricers in a row (PredictionGen.cpp:788-791).
-    // The last matrix this thread generated or uploaded stays on the device, keyed by shape and a checksum of
-    // every element, so the second to fourth pricer (and the first, right after GenerateStockPricePaths) skip
-    // the upload + transpose.
+    // The last matrix this thread generated or uploaded stays on the device together with a flat host copy of its
+    // contents; a later call reuses the device copy only after comparing EVERY element of the caller's matrix with
+    // that host copy (memcmp, row by row: microseconds for the driver's 250 x T rows), so a different matrix can
+    // never be priced by mistake.  Matrices above CACHE_MAX_BYTES are not cached (the copy would double their
+    // host footprint).
+    static constexpr size_t CACHE_MAX_BYTES = 64u << 20;
     mcg_paths* cached = nullptr;
     size_t cached_n = 0, cached_m = 0;
-    uint64_t cached_sum = 0;
+    std::vector<double> cached_flat;  // [cached_n][cached_m]
     ~ThreadCtx() {
         if (cached) mcg_paths_free(cached);
         if (ctx) mcg_finalize(ctx);
     }
-    void remember(mcg_paths* p, size_t n, size_t m, uint64_t sum) {
+    void forget() {
+        if (cached) mcg_paths_free(cached);
+        cached = nullptr;
+        cached_n = cached_m = 0;
+        cached_flat.clear();
+    }
+    // takes ownership of p and of the flat copy of its contents
+    void remember(mcg_paths* p, size_t n, size_t m, std::vector<double>&& flat) {
         if (cached && cached != p) mcg_paths_free(cached);
         cached = p;
         cached_n = n;
         cached_m = m;
-        cached_sum = sum;
+        cached_flat = std::move(flat);
+    }
+    bool holds(const std::vector<std::vector<double>>& rows, size_t m) const {
+        if (!cached || cached_n != rows.size() || cached_m != m) return false;
+        for (size_t i = 0; i < rows.size(); ++i)
+            if (std::memcmp(rows[i].data(), cached_flat.data() + i * m, m * sizeof(double)) != 0) return false;
+        return true;
     }
     mcg_ctx* get() {
         if (!ctx) {
@@ -76,36 +94,27 @@ struct PathsGuard {
     }
 };
 
-// 64-bit mix of every element's bit pattern (order-sensitive), ~10 GB/s on one core
-uint64_t checksum_rows(const std::vector<std::vector<double>>& rows, size_t m) {
-    uint64_t h = 0x9E3779B97F4A7C15ull ^ (rows.size() * 0x100000001B3ull) ^ m;
-    for (const auto& row : rows) {
-        const double* d = row.data();
-        for (size_t j = 0; j < m; ++j) {
-            uint64_t w;
-            std::memcpy(&w, d + j, sizeof w);
-            h = (h ^ w) * 0x100000001B3ull;
-            h ^= h >> 29;
-        }
-    }
-    return h;
-}
-
-// Device copy of a host path matrix: the thread's cached one when shape and checksum match, otherwise a fresh
-// upload (which becomes the cached one).  `what` prefixes the ragged-row error message.
-mcg_paths* device_matrix(const std::vector<std::vector<double>>& pricePaths, const char* ragged_msg) {
+// Device copy of a host path matrix: the thread's cached one when the contents are identical (ThreadCtx::holds),
+// otherwise a fresh upload (which becomes the cached one when it is small enough to keep a host copy of).
+// The returned handle is owned by the thread's cache or, for an uncached matrix, by `own` (freed by the caller's
+// guard).  `ragged_msg` is the error message for a row shorter than the first.
+mcg_paths* device_matrix(const std::vector<std::vector<double>>& pricePaths, const char* ragged_msg, PathsGuard& own) {
     const size_t N = pricePaths.size(), M = pricePaths[0].size();
     for (const auto& row : pricePaths)
         if (row.size() < M) throw std::runtime_error(ragged_msg);
-    const uint64_t sum = checksum_rows(pricePaths, M);
     mcg_ctx* ctx = t_ctx.get();
-    if (t_ctx.cached && t_ctx.cached_n == N && t_ctx.cached_m == M && t_ctx.cached_sum == sum) return t_ctx.cached;
+    if (t_ctx.holds(pricePaths, M)) return t_ctx.cached;
     std::vector<double> flat(N * M);
     for (size_t i = 0; i < N; ++i) std::copy(pricePaths[i].begin(), pricePaths[i].begin() + M, flat.begin() + i * M);
     PathsGuard g;
     if (mcg_paths_from_host(ctx, flat.data(), (int64_t)N, (int)M, &g.p) != MCG_OK) raise_last();
-    t_ctx.remember(g.p, N, M, sum);
-    return g.release();
+    if (flat.size() * sizeof(double) <= ThreadCtx::CACHE_MAX_BYTES) {
+        t_ctx.remember(g.p, N, M, std::move(flat));
+        return g.release();
+    }
+    t_ctx.forget();
+    own.p = g.release();
+    return own.p;
 }
 
 }  // namespace
@@ -144,7 +153,8 @@ std::vector<std::vector<double>> RoughVolatility::GenerateStockPricePaths(
     if (mcg_paths_to_host(g.p, flat.data()) != MCG_OK) raise_last();
     const size_t cols = (size_t)forward_steps + 1;
     for (size_t i = 0; i < (size_t)path_num; ++i) paths[i].assign(flat.begin() + i * cols, flat.begin() + (i + 1) * cols);
-    t_ctx.remember(g.release(), (size_t)path_num, cols, checksum_rows(paths, cols));  // the pricers come next
+    if (flat.size() * sizeof(double) <= ThreadCtx::CACHE_MAX_BYTES)
+        t_ctx.remember(g.release(), (size_t)path_num, cols, std::move(flat));  // the pricers come next
     return paths;
 }
 
@@ -153,7 +163,8 @@ double LSM::PredictOptionPrice(const std::vector<std::vector<double>>& pricePath
     if (pricePaths.empty() || pricePaths[0].empty())
         throw std::runtime_error("LSM::PredictOptionPrice: Empty pricePaths.");
     if (polyOrder < 0 || polyOrder > 8) throw std::invalid_argument("LSM: polyOrder must be in [0, 8]");
-    mcg_paths* P = device_matrix(pricePaths, "LSM: Invalid path index in regression");
+    PathsGuard own;
+    mcg_paths* P = device_matrix(pricePaths, "LSM: Invalid path index in regression", own);
     double price = 0.0;
     if (mcg_price_lsm(t_ctx.get(), P, r, strike, maturity, dt, isCall ? 1 : 0, polyOrder, &price, nullptr) != MCG_OK)
         raise_last();
@@ -169,7 +180,8 @@ double AsymptoticAnalysis::PredictOptionPrice(const std::vector<std::vector<doub
     for (const auto& row : pricePaths)
         if (row.size() != M) return 0.0;                                               // :57-61
     try {
-        mcg_paths* P = device_matrix(pricePaths, "AsymptoticAnalysis: ragged pricePaths.");
+        PathsGuard own;
+        mcg_paths* P = device_matrix(pricePaths, "AsymptoticAnalysis: ragged pricePaths.", own);
         double price = 0.0;
         if (mcg_price_asymptotic(t_ctx.get(), P, r, strike, maturity, dt, isCall ? 1 : 0, sigma, dividend, &price) != MCG_OK)
             raise_last();
@@ -186,7 +198,8 @@ double MartingaleOptimization::PredictOptionPrice(const std::vector<std::vector<
         throw std::runtime_error("MartingaleOptimization: Empty pricePaths.");                      // :31-33
     if (maxIterations <= 0) throw std::runtime_error("MartingaleOptimization: maxIterations must be positive.");  // :34-36
     if (polyOrder < 0 || polyOrder > 8) throw std::invalid_argument("MartingaleOptimization: polyOrder must be in [0, 8]");
-    mcg_paths* P = device_matrix(pricePaths, "MartingaleOptimization: ragged pricePaths.");
+    PathsGuard own;
+    mcg_paths* P = device_matrix(pricePaths, "MartingaleOptimization: ragged pricePaths.", own);
     double price = 0.0;
     if (mcg_price_martingale(t_ctx.get(), P, r, strike, maturity, dt, isCall ? 1 : 0, polyOrder, maxIterations, &price, nullptr,
                              nullptr) != MCG_OK)
@@ -200,7 +213,8 @@ double BranchingProcesses::PredictOptionPrice(const std::vector<std::vector<doub
     if (pricePaths.empty() || pricePaths[0].empty()) throw std::runtime_error("BranchingProcesses: Empty pricePaths.");
     if (exerciseTimes.empty()) throw std::runtime_error("BranchingProcesses: No exercise times.");
     if (strike <= 0.0) throw std::runtime_error("BranchingProcesses: Strike must be positive.");
-    mcg_paths* P = device_matrix(pricePaths, "BranchingProcesses: ragged pricePaths.");
+    PathsGuard own;
+    mcg_paths* P = device_matrix(pricePaths, "BranchingProcesses: ragged pricePaths.", own);
     double price = 0.0;
     if (mcg_price_branching(t_ctx.get(), P, r, strike, maturity, dt, isCall ? 1 : 0, numBranches, exerciseTimes.data(),
                             (int)exerciseTimes.size(), next_seed(), &price, nullptr, nullptr) != MCG_OK)

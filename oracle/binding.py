@@ -359,6 +359,17 @@ class Reference:
                                                                                     _dp, C.c_char_p, C.c_size_t]
             L.ref_asymptotic_price.restype = C.c_int
 
+        if hasattr(L, "ref_explicit_stats_omp"):
+            L.ref_explicit_stats_omp.argtypes = [C.c_double] * 6 + [C.c_int, C.c_long, C.c_double, _dp]
+            L.ref_explicit_stats_omp.restype = C.c_int
+
+    def explicit_stats(self, S0, r, xi, H, eta, rho, steps, total_paths, strike):
+        """Rough-regime sample through the reference's own private members (ref_harness.cpp: ref_explicit_stats_omp).
+        Returns (threads, sums[10], sums_of_squares[10]) of the per-path statistics STAT_NAMES."""
+        out = np.zeros(20)
+        th = self.L.ref_explicit_stats_omp(S0, r, xi, H, eta, rho, int(steps), int(total_paths), strike, _p(out))
+        return th, out[:10].copy(), out[10:].copy()
+
     def estimators(self, hist):
         h = np.ascontiguousarray(hist, dtype=np.float64)
         rets = np.empty(max(len(h) - 1, 0))
@@ -453,6 +464,29 @@ class Reference:
         out = np.zeros(4)
         th = self.L.ref_generate_paths_omp_payoff(_p(h), len(h), steps, total_paths, chunk, strike, int(is_call), _p(out))
         return th, out
+
+
+STAT_NAMES = ("S_T", "call_payoff", "put_payoff", "realised_var", "sq_ret_lag1", "sq_ret_lag8", "sq_ret_lag64",
+              "integrated_var", "mean_X2", "mean_X_lag1")
+
+
+def path_stats(step_major: np.ndarray, strike: float):
+    """The first seven statistics of ref_explicit_stats_omp (those that can be read off a price matrix), per path,
+    from a step-major matrix [steps+1][paths]: returns (sums[7], sums_of_squares[7], n_paths)."""
+    S = np.asarray(step_major, dtype=np.float64)
+    steps = S.shape[0] - 1
+    r2 = np.log(S[1:] / S[:-1]) ** 2
+    st = [S[-1], np.maximum(0.0, S[-1] - strike), np.maximum(0.0, strike - S[-1]), r2.sum(axis=0)]
+    for L in (1, 8, 64):
+        st.append((r2[:-L] * r2[L:]).sum(axis=0) / (steps - L) if steps > L else np.zeros(S.shape[1]))
+    st = np.array(st)
+    return st.sum(axis=1), (st * st).sum(axis=1), S.shape[1]
+
+
+def mean_and_se(sums, sums2, n):
+    m = np.asarray(sums) / n
+    var = np.maximum(0.0, (np.asarray(sums2) - n * m * m) / (n - 1))
+    return m, np.sqrt(var / n)
 
 
 def synthetic_history(n: int, seed: int = 42, s0: float = 100.0, mu: float = 0.05,

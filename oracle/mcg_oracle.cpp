@@ -929,7 +929,8 @@ int orc_branching_price(const double* paths, size_t path_stride, size_t step_str
                 if (tI * dt > maturity) break;
                 const double now = disc[tI] * payoff_of(call, S(p, tI), K);
                 double better = now;
-                if (tI < ex[n_ex - 1] && num_branches > 0) {
+                // (tI + 1 < M: for the last column the reference's `k` loop, :110, is empty -> continuation 0)
+                if (tI < ex[n_ex - 1] && tI + 1 < M && num_branches > 0) {
                     double sum = 0.0;
                     for (int q = 0; q < quads; ++q) {
                         const uint32_t ctr[4] = {(uint32_t)id, (uint32_t)(id >> 32), (uint32_t)(e_idx * quads + q), 2u};

@@ -189,6 +189,90 @@ int ref_generate_paths_omp_payoff(const double* hist, size_t n, int steps, long 
     return threads;
 }
 
+// Rough-regime sample of the reference with EXPLICIT parameters.  Through its public entry point the reference
+// only ever simulates history-estimated parameters (eta = 2 stdev(returns), :151-155: vol-of-vol ~0.03, H ~0.55),
+// so C4/C5's regime (H = 0.1, eta = 1.9) is reached here by calling the reference's OWN private members per path --
+// genComplexGaussians, fractionalGaussian, forwardVariance, gaussians, rbergomiLambda, rbergomiPhi, exactly as
+// GenerateStockPricePaths chains them (:337-352) -- followed by the ten-line stepping loop of :354-364 restated
+// below (it is inline in GenerateStockPricePaths and cannot be called separately).  Per path ten statistics are
+// formed and their sums and sums of squares over all paths returned in out20 = {sum s_0..s_9, sum s_0^2..s_9^2}:
+//   s0 S_T   s1 call payoff   s2 put payoff   (PayoffFunction at `strike`, undiscounted)
+//   s3 realised variance sum_j r_j^2, r_j = ln(S_j / S_{j-1})
+//   s4, s5, s6  mean_j r_j^2 r_{j+L}^2 for L = 1, 8, 64 (clustering of squared returns: the Volterra structure as
+//               it shows in the price matrix itself, so the same statistic can be taken from GPU paths)
+//   s7 integrated variance sum_j v_j dt   s8 mean_n X_n^2   s9 mean_n X_n X_{n+1}
+// Returns the number of threads used.
+int ref_explicit_stats_omp(double S0, double r, double xi, double H, double eta, double rho, int steps, long total_paths,
+                           double strike, double* out20) {
+    const double dt = 1.0 / 252.0;
+    double acc[20];
+    for (double& a : acc) a = 0.0;
+    int threads = 1;
+#ifdef _OPENMP
+    threads = omp_get_max_threads();
+#endif
+#pragma omp parallel
+    {
+        RoughVolatility rv;
+        std::vector<double> grid((size_t)steps + 1);
+        for (size_t i = 0; i <= (size_t)steps; ++i) grid[i] = i * dt;          // :337-340
+        const std::vector<double> lambda = rv.rbergomiLambda(grid, H);          // :342
+        const cvec phi = rv.rbergomiPhi(lambda, H);                             // :343
+        double loc[20];
+        for (double& a : loc) a = 0.0;
+        std::vector<double> S((size_t)steps + 1), ret((size_t)steps);
+#pragma omp for schedule(dynamic, 64)
+        for (long i = 0; i < total_paths; ++i) {
+            const cvec Z = rv.genComplexGaussians((size_t)steps);               // :347
+            const std::vector<double> X = rv.fractionalGaussian(phi, Z, H, eta);  // :348
+            const std::vector<double> v = rv.forwardVariance(X, grid, xi, H, eta);  // :349
+            const std::vector<double> W1 = rv.gaussians((size_t)steps);         // :351
+            const std::vector<double> W2 = rv.gaussians((size_t)steps);         // :352
+            S[0] = S0;                                                          // :354
+            for (size_t j = 1; j <= (size_t)steps; ++j) {                       // :355-364
+                const double dw1 = std::sqrt(dt) * W1[j - 1];
+                const double dw2 = std::sqrt(dt) * W2[j - 1];
+                const double dW = rho * dw1 + std::sqrt(1.0 - rho * rho) * dw2;
+                const double vt = v[j - 1];
+                const double drift = (r - 0.5 * vt) * dt;
+                const double diff = std::sqrt(std::max(0.0, vt)) * dW;
+                S[j] = S[j - 1] * std::exp(drift + diff);
+            }
+            double st[10];
+            st[0] = S[(size_t)steps];
+            st[1] = PayoffFunction(true, st[0], strike);
+            st[2] = PayoffFunction(false, st[0], strike);
+            double rvar = 0.0, iv = 0.0, x2 = 0.0, x1 = 0.0;
+            for (int j = 0; j < steps; ++j) {
+                ret[(size_t)j] = std::log(S[(size_t)j + 1] / S[(size_t)j]);
+                rvar += ret[(size_t)j] * ret[(size_t)j];
+                iv += v[(size_t)j] * dt;
+                x2 += X[(size_t)j] * X[(size_t)j];
+                if (j + 1 < steps) x1 += X[(size_t)j] * X[(size_t)j + 1];
+            }
+            st[3] = rvar;
+            const int lags[3] = {1, 8, 64};
+            for (int q = 0; q < 3; ++q) {
+                const int L = lags[q];
+                double c = 0.0;
+                for (int j = 0; j + L < steps; ++j) c += ret[(size_t)j] * ret[(size_t)j] * ret[(size_t)(j + L)] * ret[(size_t)(j + L)];
+                st[4 + q] = steps > L ? c / (steps - L) : 0.0;
+            }
+            st[7] = iv;
+            st[8] = x2 / steps;
+            st[9] = steps > 1 ? x1 / (steps - 1) : 0.0;
+            for (int q = 0; q < 10; ++q) {
+                loc[q] += st[q];
+                loc[10 + q] += st[q] * st[q];
+            }
+        }
+#pragma omp critical
+        for (int q = 0; q < 20; ++q) acc[q] += loc[q];
+    }
+    for (int q = 0; q < 20; ++q) out20[q] = acc[q];
+    return threads;
+}
+
 // AsymptoticAnalysis::PredictOptionPrice (src/models/AsymptoticAnalysisPricer.cpp:38-113) on a
 // row-major [n][m] matrix.  Returns 0, or 1 when the reference throws (message in err).
 int ref_asymptotic_price(const double* row_major, long n, int m, double r, double strike, double maturity,

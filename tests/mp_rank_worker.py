@@ -1,0 +1,76 @@
+"""One rank of a sharded pricing job on the PRODUCT path (libmcgpu through the C ABI): started as a fresh child
+process by tests/test_gpu_multirank.py, once per rank, all ranks on GPU 0.
+
+    python tests/mp_rank_worker.py <rank> <world> <port> <out.json>
+
+The collective is gloo (two ranks cannot share one device under RCCL): the callback installed with
+mcg_set_allreduce copies the handful of doubles to the host, all-reduces there and copies back, stream-ordered
+on the ctx's stream (= torch's current stream).  Everything else -- shard ranges, kernels, the per-date
+reduce / all-reduce / solve sequence of csrc/kernels_lsm.hip -- is exactly what an N-GPU run executes.
+"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+SEED, DT = 20251031, 1.0 / 252.0
+RB = dict(S0=100.0, r=0.04, xi=0.04, H=0.1, eta=1.9, rho=-0.9)
+JOBS = dict(euro_paths=300_001, lsm_paths=200_001, lsm_steps=50, rb_paths=100_003, rb_steps=64)
+
+
+def main() -> None:
+    rank, world, port, out_path = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+    import torch
+    import torch.distributed as dist
+
+    import montecarlooptionspricer_amd as mc
+    from montecarlooptionspricer_amd.engine import _DevView
+    from montecarlooptionspricer_amd.sharding import shard_range
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    eng = mc.PathEngine(0, stream=torch.cuda.current_stream().cuda_stream)
+    calls = []
+
+    def allreduce(ptr, count, _stream):
+        t = torch.as_tensor(_DevView(ptr, count), device="cuda:0")
+        h = t.cpu()                      # waits for the producing kernel on the shared stream
+        dist.all_reduce(h)
+        t.copy_(h)
+        calls.append(count)
+
+    eng.set_allreduce(allreduce)
+    res = {}
+
+    b, c = shard_range(JOBS["euro_paths"], rank, world)
+    P = eng.gbm(SEED, 100.0, 0.04, 0.2, DT, 252, c, path_begin=b, payoff=(100.0, True))
+    res["euro"] = eng.price_european(P, 100.0, 0.04, 1.0, True)
+    P.free()
+
+    b, c = shard_range(JOBS["lsm_paths"], rank, world)
+    P = eng.gbm(SEED, 100.0, 0.04, 0.2, 0.02, JOBS["lsm_steps"], c, path_begin=b)
+    res["gbm_lsm"] = eng.price_lsm(P, 0.04, 100.0, 1.0, 0.02, False, 2)
+    P.free()
+
+    b, c = shard_range(JOBS["rb_paths"], rank, world, align=2)
+    T = JOBS["rb_steps"] * DT
+    P = eng.rbergomi(SEED, RB["S0"], RB["r"], RB["xi"], RB["H"], RB["eta"], RB["rho"], DT, JOBS["rb_steps"], c, path_begin=b)
+    res["rb_lsm"] = eng.price_lsm(P, RB["r"], 100.0, T, DT, False, 2)
+    res["rb_euro_put"] = eng.price_european(P, 100.0, RB["r"], T, False)
+    P.free()
+
+    res["allreduce_calls"] = {"3": calls.count(3), "8": calls.count(8)}
+    res["shard"] = [b, c]
+    eng.close()
+    with open(f"{out_path}.{rank}", "w") as f:
+        json.dump(res, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

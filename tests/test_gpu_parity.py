@@ -278,6 +278,30 @@ def test_lsm_single_launch_sweep_from_concurrent_host_threads():
     assert all(o == want for o in out), (out, want)
 
 
+def test_lsm_one_launch_timeout_falls_back_to_per_date_kernels(monkeypatch):
+    """The hand-shake of the one-launch sweep gives up (forced: MCG_LSM_SPIN_LIMIT=0): the void result is discarded,
+    the call answers from the per-date kernels, the ctx stops using the one-launch sweep, nothing hangs."""
+    base = mc.PathEngine(0)
+    base.set_allreduce(lambda ptr, count, stream: None)     # a collective (identity) forces the per-date kernels
+    P = base.gbm(SEED, 100.0, 0.04, 0.2, 0.02, 20, 300_000)
+    want = base.price_lsm(P, 0.04, 100.0, 0.4, 0.02, False, 2)
+    P.free()
+    base.close()
+    e = mc.PathEngine(0)
+    Q = e.gbm(SEED, 100.0, 0.04, 0.2, 0.02, 20, 300_000)
+    assert e.lsm_one_launch_enabled()
+    one = e.price_lsm(Q, 0.04, 100.0, 0.4, 0.02, False, 2)   # healthy: the one-launch sweep answers
+    assert e.lsm_one_launch_enabled() and one == pytest.approx(want, rel=1e-11)
+    monkeypatch.setenv("MCG_LSM_SPIN_LIMIT", "0")
+    got = e.price_lsm(Q, 0.04, 100.0, 0.4, 0.02, False, 2)
+    assert not e.lsm_one_launch_enabled()
+    assert got == want                                       # identical kernels, identical summation order
+    monkeypatch.delenv("MCG_LSM_SPIN_LIMIT")
+    assert e.price_lsm(Q, 0.04, 100.0, 0.4, 0.02, False, 2) == want and not e.lsm_one_launch_enabled()   # sticky
+    Q.free()
+    e.close()
+
+
 def test_lsm_american_put_bounds(eng):
     """Sanity (not parity): American put >= European put (BS 6.0040 at these parameters)."""
     n, steps, dt = 200_000, 50, 0.02
@@ -535,6 +559,47 @@ def test_branching_matches_oracle_philox_mode(eng, orc, is_call, branches, strid
     P.free()
 
 
+def test_branching_trailing_exercise_index_beyond_the_matrix(eng, orc):
+    """An exercise list whose tail lies behind the maturity may name columns that do not exist: the reference never
+    touches them (its `t > maturity` break comes first, BranchingProcessPricer.cpp:57-59, :97-99) but still compares
+    every date with exerciseTimes.back() (:104), so the last real column takes the continuation branch with an empty
+    scan (:110).  Oracle "mt" (the reference's loops), oracle "philox" and the device agree on the lower bound; the
+    device equals oracle "philox" on the upper bound, with no out-of-range gather."""
+    steps = 12
+    P = eng.gbm(SEED, 100.0, 0.04, 0.25, DT, steps, 3000)
+    host = P.to_host_step_major()
+    ex = np.array(list(range(steps + 1)) + [steps + 5, 10_000], dtype=np.int32)   # 0..12 exist; 17 and 10000 do not
+    got = eng.price_branching(P, 0.04, 100.0, steps * DT, DT, False, 6, ex, seed=3)
+    want = orc.branching_price(host, 0.04, 100.0, steps * DT, DT, False, 6, ex, 3, mode="philox")
+    ref_like = orc.branching_price(host, 0.04, 100.0, steps * DT, DT, False, 6, ex, 3, mode="mt")
+    assert np.allclose(got, want, rtol=1e-12, atol=1e-14), (got, want)
+    assert got[1] == pytest.approx(ref_like[1], rel=1e-13)
+    with pytest.raises(mc.McgError, match="outside"):                              # inside the maturity it IS an error
+        eng.price_branching(P, 0.04, 100.0, 1.0, DT, False, 6, np.array([0, 5, 40], dtype=np.int32), seed=3)
+    P.free()
+
+
+def test_handles_survive_their_ctx_and_narrow_matrices_upload(eng):
+    """mcg_finalize before mcg_paths_free (an exception skipped P.free()): the handle is orphaned, a late free only
+    deletes it.  And a two-column matrix with more than 65535*32 paths goes through the layout kernels in slabs."""
+    e = mc.PathEngine(0)
+    P = e.gbm(SEED, 100.0, 0.04, 0.2, DT, 8, 1000)
+    L, h = e._L, P._h
+    e._live.discard(P)                 # bypass the Python-side bookkeeping: exercise the C ABI's own guard
+    e.close()
+    out = np.empty((1000, 9))
+    import ctypes as C
+    assert L.mcg_paths_to_host(h, out.ctypes.data_as(C.POINTER(C.c_double))) != 0
+    assert b"outlived" in L.mcg_last_error()
+    assert L.mcg_paths_free(h) == 0
+    P._h = None
+    n = 65535 * 32 + 777
+    m = np.random.RandomState(2).rand(n, 2)
+    Q = eng.from_host(m)
+    assert np.array_equal(Q.to_host(), m) and np.array_equal(Q.to_host_step_major(), m.T)
+    Q.free()
+
+
 def test_branching_class_api_and_errors(orc):
     hist = synthetic_history(300, seed=1)
     mc.set_compat_seed(5)
@@ -567,9 +632,14 @@ def _driver_rows(n, rs):
     return rows
 
 
-def test_batch_rows_equal_single_contract_entry_points(eng):
-    """Row i of the batch == the single-contract C ABI calls on paths (i << 32) + p of the same seed.
-    (kappa comes from a device DFT in the batch and from the host FFT otherwise: ~1e-13 apart.)"""
+def test_batch_rows_match_oracle_row_by_row(eng, orc):
+    """Row i of mcg_batch_price_rows against the ORACLE: the row's 250 paths are the rBergomi paths (i << 32) + p of the
+    same seed (generated by the single-contract entry point -- itself pinned to the oracle element-wise in
+    test_rbergomi_paths_match_oracle -- and downloaded), and each of the driver's four columns
+    (src/core/PredictionGen.cpp:788-791, :809-814) is recomputed on them by the CPU restatement: AsymptoticAnalysis
+    (pinned bit-exact to the compiled reference), BranchingProcesses in philox mode (same resampling draws), LSM and
+    MartingaleOptimization.  (kappa comes from a device DFT in the batch and from the host FFT in the single-contract
+    generator: paths ~1e-13 apart, which the regressions amplify: rtol 1e-7.)"""
     rs = np.random.RandomState(4)
     rows = _driver_rows(24, rs)
     rows[3]["sigma"] = 0.0          # AsymptoticAnalysis would throw  -> the driver writes zeros for the row
@@ -582,13 +652,22 @@ def test_batch_rows_equal_single_contract_entry_points(eng):
             assert (got[i] == 0.0).all()
             continue
         P = eng.rbergomi(77, d["S0"], 0.04, d["xi"], d["H"], d["eta"], d["rho"], DT, d["n_steps"], 250, path_begin=i << 32)
+        host = P.to_host_step_major()
         call = bool(d["is_call"])
-        want = [eng.price_asymptotic(P, 0.04, d["strike"], d["maturity"], DT, call, d["sigma"], d["dividend"]),
-                eng.price_branching(P, 0.04, d["strike"], d["maturity"], DT, call, 10, np.arange(d["n_steps"]), 77)[0],
-                eng.price_lsm(P, 0.04, d["strike"], d["maturity"], DT, call, 2)[0],
-                eng.price_martingale(P, 0.04, d["strike"], d["maturity"], DT, call, 2, 5)[0]]
-        P.free()
+        ex = np.arange(d["n_steps"], dtype=np.int32)
+        want = [orc.asymptotic_price(host, 0.04, d["strike"], d["maturity"], DT, call, d["sigma"], d["dividend"]),
+                orc.branching_price(host, 0.04, d["strike"], d["maturity"], DT, call, 10, ex, 77, mode="philox",
+                                    path_begin=i << 32)[0],
+                orc.lsm_price(host, 0.04, d["strike"], d["maturity"], DT, call, 2),
+                orc.martingale_price(host, 0.04, d["strike"], d["maturity"], DT, call, 2, 5)[0]]
         assert np.allclose(got[i], want, rtol=1e-7, atol=1e-9), (i, d, got[i], want)
+        # and the engine's own single-contract entry points on the same device matrix agree with the batch kernels
+        single = [eng.price_asymptotic(P, 0.04, d["strike"], d["maturity"], DT, call, d["sigma"], d["dividend"]),
+                  eng.price_branching(P, 0.04, d["strike"], d["maturity"], DT, call, 10, ex, 77)[0],
+                  eng.price_lsm(P, 0.04, d["strike"], d["maturity"], DT, call, 2)[0],
+                  eng.price_martingale(P, 0.04, d["strike"], d["maturity"], DT, call, 2, 5)[0]]
+        P.free()
+        assert np.allclose(got[i], single, rtol=1e-7, atol=1e-9), (i, d, got[i], single)
 
 
 def test_batch_rows_arguments(eng):
@@ -646,6 +725,38 @@ def test_full_size_c3_c4_properties(eng):
     fwd = math.exp(0.04 * T) * (c - p) + 100.0
     assert abs(fwd - 100.0 * math.exp(0.04 * T)) <= 2.5 * math.exp(0.04 * T) * math.hypot(cse, pse)
     assert math.isfinite(c) and c > 0
+
+
+@pytest.mark.parametrize("steps", [252, 512])
+def test_rough_regime_prices_and_structure_vs_compiled_reference_sample(eng, steps):
+    """C4 / C5 parameters (H = 0.1, eta = 1.9) against the committed sample of the COMPILED REFERENCE
+    (tests/golden/rough_regime_reference.json: 2e6 / 1e6 paths through the reference's own private members,
+    oracle/gen_rough_fixture.py).  North-star bar: |price - ref| <= 2 MC standard errors (combined), call and put, on
+    4M device paths.  Beyond the prices, the statistics that see the Volterra / forward-variance structure in the price
+    matrix itself -- E[S_T], realised variance, clustering of squared returns at lags 1, 8, 64 -- on 400k downloaded
+    device paths, within 3 combined standard errors each (five more comparisons per step count)."""
+    import json
+    import os
+    from oracle.binding import STAT_NAMES, mean_and_se, path_stats
+    fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "rough_regime_reference.json")))
+    p, fix = fx["params"], fx["samples"][str(steps)]
+    fm, fse = np.array(fix["mean"]), np.array(fix["std_err"])
+    K, n = p["strike"], 4_000_000
+    for is_call, idx in ((True, 1), (False, 2)):
+        P = eng.rbergomi(SEED, p["S0"], p["r"], p["xi"], p["H"], p["eta"], p["rho"], DT, steps, n, payoff=(K, is_call))
+        m, se = eng.price_european(P, K, 0.0, 0.0, is_call)        # r = 0, T = 0: the undiscounted mean payoff
+        P.free()
+        z = (m - fm[idx]) / math.hypot(se, fse[idx])
+        assert abs(z) <= 2.0, (steps, STAT_NAMES[idx], m, se, fm[idx], fse[idx], z)
+    s, s2, cnt = np.zeros(7), np.zeros(7), 0
+    for c in range(4):
+        P = eng.rbergomi(SEED + 1, p["S0"], p["r"], p["xi"], p["H"], p["eta"], p["rho"], DT, steps, 100_000, path_begin=c * 100_000)
+        a, b, k = path_stats(P.to_host_step_major(), K)
+        P.free()
+        s, s2, cnt = s + a, s2 + b, cnt + k
+    m, se = mean_and_se(s, s2, cnt)
+    z = (m - fm[:7]) / np.hypot(se, fse[:7])
+    assert (np.abs(z) <= 3.0).all(), (steps, dict(zip(STAT_NAMES, np.round(z, 2))), m, se)
 
 
 def test_lsm_prices_vs_independent_reference_samples(eng, orc):

@@ -126,3 +126,45 @@ def test_committed_bench_line_has_the_contract_fields():
     c = j["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["unit"] == "Mpaths/s" and "sample" in c
     assert j["parity"]["abs_err_over_std_err"] <= 2.0
+
+
+def test_close_frees_live_matrices_before_the_ctx_and_late_free_is_a_no_op():
+    """engine.py's ownership rule, checked without a device through a recording stand-in for the C library:
+    PathEngine.close() hands every PathMatrix that is still alive back BEFORE mcg_finalize, and a later
+    PathMatrix.free() / garbage collection does not call into the library again."""
+    import ctypes as C
+    import gc
+    import weakref
+
+    from montecarlooptionspricer_amd.engine import PathEngine, PathMatrix
+
+    calls = []
+
+    class FakeLib:
+        def mcg_paths_free(self, h):
+            calls.append(("free", h))
+            return 0
+
+        def mcg_finalize(self, ctx):
+            calls.append(("finalize", None))
+            return 0
+
+    eng = PathEngine.__new__(PathEngine)
+    eng._L, eng._ctx, eng._cb, eng.device, eng._live = FakeLib(), C.c_void_p(1), None, 0, weakref.WeakSet()
+    mats = []
+    for h in (11, 22, 33):
+        m = PathMatrix.__new__(PathMatrix)
+        m._engine, m._h = eng, h
+        eng._live.add(m)
+        mats.append(m)
+    mats[0].free()                                   # the ordinary order
+    assert calls == [("free", 11)] and len(eng._live) == 2
+    eng.close()
+    assert calls[1:] in ([("free", 22), ("free", 33), ("finalize", None)], [("free", 33), ("free", 22), ("finalize", None)])
+    n = len(calls)
+    for m in mats:
+        m.free()                                     # late: nothing left to do
+    del mats, m
+    gc.collect()
+    eng.close()                                      # idempotent
+    assert len(calls) == n
