@@ -17,6 +17,7 @@
 #include <atomic>
 #include <cstdlib>
 #include <mutex>
+#include <type_traits>
 
 #include "lsm_device.hpp"
 #include "mcg_internal.hpp"
@@ -215,6 +216,7 @@ struct LsmCoopArgs {
     double* coef;      // [2][16], sentinel-filled: coefficients, [9] = ITM count
     unsigned* timeout; // set when a spin gives up
     unsigned spin_limit; // polling rounds before a spin gives up (LSM_SPIN_LIMIT; MCG_LSM_SPIN_LIMIT in tests)
+    int u_full;          // k_lsm_big: units 0 .. u_full-1 lie inside the shard for EVERY thread (no masking needed)
     double* out;       // [2 * gridDim.x]: per-block {sum V, sum V^2}
 };
 
@@ -231,6 +233,119 @@ __device__ __forceinline__ double lsm_ld_shared(const double* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 constexpr unsigned LSM_SPIN_LIMIT = 1u << 20;  // rounds of ~1.5 us; a co-resident grid needs a handful
+
+// The per-date exchange of the one-launch sweeps (protocol: see the comment above), in its three parts.
+// G = number of workgroups that contribute partial moments, b = this workgroup's slot among them.
+
+// every contributing workgroup: block-reduce the per-thread moments and send them off
+template <int NB>
+__device__ __forceinline__ void lsm_publish_partials(const LsmCoopArgs& a, double (&m)[3 * NB - 1], unsigned G, unsigned b, int parity,
+                                                     double* red) {
+    constexpr int NM = 3 * NB - 1;
+    block_sum<NM, 4>(m, red);
+    double* part = a.partials + (int64_t)parity * NM * G;
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int t = 0; t < NM; ++t) lsm_st_shared(part + (int64_t)t * G + b, m[t]);
+    }
+}
+
+// the reducing workgroup: poll all G partials, fixed-order sum, solve, publish the coefficients (and leave them in
+// sm_coef for its own threads).  The same fixed-order reduction as k_lsm_reduce_solve: wave w sums moments w, w+4, ...;
+// lane l the workgroups l, l+64, ...  Two of the wave's moments per round: all their slots are polled together, so the
+// usual date costs one round trip to the coherence point, not one per moment.
+template <int NB>
+__device__ __forceinline__ void lsm_reduce_solve_publish(const LsmCoopArgs& a, unsigned G, int parity, bool& gave_up, double* sm_mom,
+                                                         double* sm_coef) {
+    constexpr int NM = 3 * NB - 1;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double* part = a.partials + (int64_t)parity * NM * G;
+    double* coef_now = a.coef + 16 * parity;
+    for (int t0 = wave; t0 < NM; t0 += 8) {
+        const int t1 = t0 + 4;
+        const bool two = t1 < NM;
+        double* slot0 = part + (int64_t)t0 * G;
+        double* slot1 = part + (int64_t)(two ? t1 : t0) * G;
+        constexpr int K = LSM_COOP_MAX_GRID / 64;
+        double v0[K], v1[K];
+        unsigned spins = 0;
+        bool missing = !gave_up;  // after one timeout nothing is waited for any more: the run is void
+        while (missing) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const unsigned b = lane + 64u * k;
+                v0[k] = b < G ? lsm_ld_shared(slot0 + b) : 0.0;
+                v1[k] = b < G ? lsm_ld_shared(slot1 + b) : 0.0;
+            }
+            missing = false;
+#pragma unroll
+            for (int k = 0; k < K; ++k) missing = missing || lsm_is_sentinel(v0[k]) || lsm_is_sentinel(v1[k]);
+            if (missing) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > a.spin_limit) {
+                    __hip_atomic_store(a.timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    gave_up = true;
+                    break;
+                }
+            }
+        }
+        double sum0 = 0.0, sum1 = 0.0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const unsigned b = lane + 64u * k;
+            if (b < G) {
+                sum0 += v0[k];
+                sum1 += v1[k];
+                lsm_st_shared(slot0 + b, lsm_sentinel());  // recycled two dates from now
+                if (two) lsm_st_shared(slot1 + b, lsm_sentinel());
+            }
+        }
+        sum0 = wave_sum(sum0);
+        sum1 = wave_sum(sum1);
+        if (lane == 0) {
+            sm_mom[t0] = sum0;
+            if (two) sm_mom[t1] = sum1;
+        }
+    }
+    // all partials of this date are in: every workgroup is past the previous date's coefficients
+    if (threadIdx.x < 10) lsm_st_shared(a.coef + 16 * (parity ^ 1) + threadIdx.x, lsm_sentinel());
+    __syncthreads();
+    if (threadIdx.x == 0) lsm_solve_nb<NB>(sm_mom, 1.0, sm_coef);
+    __builtin_amdgcn_s_waitcnt(0);  // the recycling stores are acknowledged before anything newer goes out
+    __syncthreads();
+    if (threadIdx.x < 10) lsm_st_shared(coef_now + threadIdx.x, sm_coef[threadIdx.x]);
+}
+
+// every other workgroup: lanes 0..9 poll one coefficient each into sm_coef
+__device__ __forceinline__ void lsm_poll_coefficients(const LsmCoopArgs& a, int parity, bool& gave_up, double* sm_coef) {
+    double* coef_now = a.coef + 16 * parity;
+    if (threadIdx.x < 10) {
+        double cv = lsm_ld_shared(coef_now + threadIdx.x);
+        unsigned spins = 0;
+        while (lsm_is_sentinel(cv) && !gave_up) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > a.spin_limit) {
+                __hip_atomic_store(a.timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                gave_up = true;
+                break;
+            }
+            cv = lsm_ld_shared(coef_now + threadIdx.x);
+        }
+        sm_coef[threadIdx.x] = cv;
+    }
+    __syncthreads();
+}
+
+// k_lsm_coop: workgroup 0 contributes AND reduces.  after_publish() runs right after this workgroup's partial moments
+// have left: the place to put loads in flight that should overlap the ~10 us the moments and coefficients travel.
+template <int NB, class F>
+__device__ __forceinline__ void lsm_exchange(const LsmCoopArgs& a, double (&m)[3 * NB - 1], int parity, bool& gave_up,
+                                             double* red, double* sm_mom, double* sm_coef, F&& after_publish) {
+    lsm_publish_partials<NB>(a, m, gridDim.x, blockIdx.x, parity, red);
+    after_publish();
+    if (blockIdx.x == 0) lsm_reduce_solve_publish<NB>(a, gridDim.x, parity, gave_up, sm_mom, sm_coef);
+    else lsm_poll_coefficients(a, parity, gave_up, sm_coef);
+}
 
 // Second launch bound = workgroups per CU the register budget must allow.
 template <int NB, int PPT, bool KEEP>
@@ -303,91 +418,11 @@ __global__ __launch_bounds__(256, (PPT >= 16 ? 2 : 3)) void k_lsm_coop(LsmCoopAr
                 }
             }
         }
-        block_sum<NM, 4>(m, red);
-        double* part = a.partials + (int64_t)parity * NM * G;
-        double* coef_now = a.coef + 16 * parity;
-        if (threadIdx.x == 0) {
-#pragma unroll
-            for (int t = 0; t < NM; ++t) lsm_st_shared(part + (int64_t)t * G + blockIdx.x, m[t]);
-        }
-        if constexpr (PREFETCH) {
-            if (j >= 1) load_row(j - 1, s_nxt);
-        }
-        if (blockIdx.x == 0) {
-            // the same fixed-order reduction as k_lsm_reduce_solve: wave w sums moments w, w+4, ...; lane l the
-            // workgroups l, l+64, ...
-            // Two of the wave's moments per round: all their slots are polled together, so the usual date costs one
-            // round trip to the coherence point, not one per moment.
-            for (int t0 = wave; t0 < NM; t0 += 8) {
-                const int t1 = t0 + 4;
-                const bool two = t1 < NM;
-                double* slot0 = part + (int64_t)t0 * G;
-                double* slot1 = part + (int64_t)(two ? t1 : t0) * G;
-                constexpr int K = LSM_COOP_MAX_GRID / 64;
-                double v0[K], v1[K];
-                unsigned spins = 0;
-                bool missing = !gave_up;  // after one timeout nothing is waited for any more: the run is void
-                while (missing) {
-#pragma unroll
-                    for (int k = 0; k < K; ++k) {
-                        const unsigned b = lane + 64u * k;
-                        v0[k] = b < G ? lsm_ld_shared(slot0 + b) : 0.0;
-                        v1[k] = b < G ? lsm_ld_shared(slot1 + b) : 0.0;
-                    }
-                    missing = false;
-#pragma unroll
-                    for (int k = 0; k < K; ++k) missing = missing || lsm_is_sentinel(v0[k]) || lsm_is_sentinel(v1[k]);
-                    if (missing) {
-                        __builtin_amdgcn_s_sleep(1);
-                        if (++spins > a.spin_limit) {
-                            __hip_atomic_store(a.timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            gave_up = true;
-                            break;
-                        }
-                    }
-                }
-                double sum0 = 0.0, sum1 = 0.0;
-#pragma unroll
-                for (int k = 0; k < K; ++k) {
-                    const unsigned b = lane + 64u * k;
-                    if (b < G) {
-                        sum0 += v0[k];
-                        sum1 += v1[k];
-                        lsm_st_shared(slot0 + b, lsm_sentinel());  // recycled two dates from now
-                        if (two) lsm_st_shared(slot1 + b, lsm_sentinel());
-                    }
-                }
-                sum0 = wave_sum(sum0);
-                sum1 = wave_sum(sum1);
-                if (lane == 0) {
-                    sm_mom[t0] = sum0;
-                    if (two) sm_mom[t1] = sum1;
-                }
+        lsm_exchange<NB>(a, m, parity, gave_up, red, sm_mom, sm_coef, [&]() {
+            if constexpr (PREFETCH) {
+                if (j >= 1) load_row(j - 1, s_nxt);
             }
-            // all partials of this date are in: every workgroup is past the previous date's coefficients
-            if (threadIdx.x < 10) lsm_st_shared(a.coef + 16 * (parity ^ 1) + threadIdx.x, lsm_sentinel());
-            __syncthreads();
-            if (threadIdx.x == 0) lsm_solve_nb<NB>(sm_mom, 1.0, sm_coef);
-            __builtin_amdgcn_s_waitcnt(0);  // the recycling stores are acknowledged before anything newer goes out
-            __syncthreads();
-            if (threadIdx.x < 10) lsm_st_shared(coef_now + threadIdx.x, sm_coef[threadIdx.x]);
-        } else {
-            if (threadIdx.x < 10) {
-                double cv = lsm_ld_shared(coef_now + threadIdx.x);
-                unsigned spins = 0;
-                while (lsm_is_sentinel(cv) && !gave_up) {
-                    __builtin_amdgcn_s_sleep(1);
-                    if (++spins > a.spin_limit) {
-                        __hip_atomic_store(a.timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        gave_up = true;
-                        break;
-                    }
-                    cv = lsm_ld_shared(coef_now + threadIdx.x);
-                }
-                sm_coef[threadIdx.x] = cv;
-            }
-            __syncthreads();
-        }
+        });
         double c[NB];
 #pragma unroll
         for (int t = 0; t < NB; ++t) c[t] = sm_coef[t];
@@ -437,16 +472,283 @@ __global__ __launch_bounds__(256, (PPT >= 16 ? 2 : 3)) void k_lsm_coop(LsmCoopAr
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The one-launch sweep for shards beyond the register-resident variant above: up to 64 paths per thread, i.e. 8.39M
+// paths on 512 co-resident workgroups (2 per CU) -- BASELINE.json's C5 shard (8M x 252) in ONE launch.
+// V lives in registers (two adjacent paths per 16-byte unit, NU units per thread: 128 of the 256 VGPRs at NU = 32),
+// which leaves no registers to stage loads in.  The path matrix therefore streams through an LDS ring filled by
+// LDS-DMA (global_load_lds_dwordx4: HBM -> LDS with no VGPR destination, 1 KiB per wave-instruction into the wave's
+// own slice of a slot, so no barrier guards the ring): 16 slots x 4 KiB = 64 KiB per workgroup, i.e. the loads of
+// eight units (S_j and S_{j-1}) are always in flight while one unit is being processed, and the first eight units
+// of the NEXT date are fetched while the moments and coefficients travel between the workgroups.
+// Per date j the loop is the per-date kernels' fused form -- update V with S_j, accumulate date j-1's moments from
+// S_{j-1} -- so every row is read twice, 16 B per path and date against their 32 (V never touches memory).  Reading
+// each row once would need it on chip between the two passes; tools/ubench_mall.hip shows the memory-side cache does
+// not provide that (a 64 MB row re-read 20 us later comes at HBM speed), and with V filling half the register file
+// the other half plus LDS cannot hold a row either.
+// Branch-free bodies (no exec-masked regions: the unrolled unit loop must stay one basic block so that the loads of
+// the next pipeline stage can be scheduled across it), written for the instruction count -- at 64 paths per thread
+// this loop, not HBM, is what a date costs.  PayoffFunction (include/core/common.h:8-14) as max(sg s + nsK, 0) with
+// (sg, nsK) = (1, -K) for a call and (-1, K) for a put: one FMA, same rounding as s - K / K - s.  A path that is not
+// in the money enters the sums with weight w = 0 (one select on the high word of 1.0), i.e. adds exact zeros; in the
+// money the products are the same x^t the other kernels form, bit for bit.
+struct LsmPay {
+    double sg, nsK;
+};
+__device__ __forceinline__ double lsm_pay(const LsmPay& p, double s) { return fmax(fma(p.sg, s, p.nsK), 0.0); }
+
+template <int NB>
+__device__ __forceinline__ void lsm_accumulate(double (&m)[3 * NB - 1], const LsmPay& p, double s, double v, double invK,
+                                               double disc) {
+    const double w = lsm_pay(p, s) > 1e-14 ? 1.0 : 0.0;  // regression inputs, LSMPricer.cpp:51-74
+    const double x = fma(s, invK, -1.0);
+    const double y = v * disc;
+    double pw = w;
+#pragma unroll
+    for (int t = 0; t < 2 * NB - 1; ++t) {
+        m[t] += pw;
+        if (t < NB) m[2 * NB - 1 + t] = fma(pw, y, m[2 * NB - 1 + t]);
+        if (t + 1 < 2 * NB - 1) pw *= x;
+    }
+}
+
+// per lane: mask bit set ? a : b
+__device__ __forceinline__ double lsm_select(unsigned long long mask, double a, double b) {
+    int lo, hi;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(lo) : "v"(__double2loint(b)), "v"(__double2loint(a)), "s"(mask));
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(hi) : "v"(__double2hiint(b)), "v"(__double2hiint(a)), "s"(mask));
+    return __hiloint2double(hi, lo);
+}
+
+template <int NB>
+__device__ __forceinline__ double lsm_update(const LsmPay& p, double s, double v_old, const double (&c)[NB],
+                                             unsigned long long any_itm /* all ones / zero: wave-uniform */,
+                                             double invK, double disc) {  // LSMPricer.cpp:78-94
+    const double pay = lsm_pay(p, s);
+    const double x = fma(s, invK, -1.0);
+    double cont = c[NB - 1];
+#pragma unroll
+    for (int t = NB - 2; t >= 0; --t) cont = fma(cont, x, c[t]);
+    // payoff == 1e-14 exactly falls through both of the reference's branches (:55 vs :91) and keeps 0
+    // The two selects are written as v_cndmask on a ballot mask: from `c ? a : b` hipcc builds a divergent branch
+    // around the polynomial here, i.e. four extra basic blocks and two exec-mask round trips per path.
+    const double v = lsm_select(__builtin_amdgcn_ballot_w64(pay < 1e-14), v_old, 0.0) * disc;
+    return lsm_select(__builtin_amdgcn_ballot_w64(pay > 1e-14) & any_itm, fmax(pay, cont), v);
+}
+
+// f(integral_constant<int, I>) for I = 0 .. N-1: a loop whose index is a compile-time constant in the body
+// (immediate operands of inline asm, slot numbers)
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+constexpr int LSM_RING_SLOTS = 16;  // x 256 lanes x 16 B = 64 KiB of dynamic LDS per workgroup
+
+// s_waitcnt with only the vector-memory counter set (gfx9 encoding: vmcnt in bits 3:0 and 15:14)
+__device__ __forceinline__ constexpr int lsm_vmcnt(int n) { return (n & 15) | ((n >> 4) << 14) | (7 << 4) | (15 << 8); }
+
+// The reducing workgroup of k_lsm_big: one exchange per regression date, the same dates in the same order as the
+// workers count them (LSMPricer.cpp:42-49).
+template <int NB>
+__device__ __forceinline__ void lsm_reduce_loop(const LsmCoopArgs& a, unsigned G, double* sm_mom, double* sm_coef) {
+    bool gave_up = a.spin_limit == 0;
+    if (gave_up && threadIdx.x == 0) __hip_atomic_store(a.timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int j = a.n_cols - 2;
+    for (; j >= 0 && j * a.dt > a.maturity; --j) {
+    }
+    int parity = 0;
+    for (; j >= 0; --j) {
+        lsm_reduce_solve_publish<NB>(a, G, parity, gave_up, sm_mom, sm_coef);
+        __syncthreads();  // sm_mom / sm_coef are rewritten on the next date
+        parity ^= 1;
+    }
+}
+
+template <int NB, int NU>
+__global__ __launch_bounds__(256, 2) void k_lsm_big(LsmCoopArgs a) {
+    constexpr int NM = 3 * NB - 1;
+    constexpr int LA = LSM_RING_SLOTS / 2;  // units in flight ahead of the one being processed
+    static_assert(NU % LA == 0, "a date's units fill the ring a whole number of times: slot numbers are compile-time");
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    extern __shared__ double2 ring[];  // [LSM_RING_SLOTS][256]; unit u: S_j in slot 2u mod 16, S_{j-1} in the next
+    __shared__ double red[NM * 4];
+    __shared__ double sm_mom[32];
+    __shared__ double sm_coef[16];
+    const bool call = a.is_call != 0;
+    const int tid = threadIdx.x, wave = tid >> 6;
+    // Workgroup 0 holds no paths: it only reduces and solves (lsm_reduce_loop).  As a separate branch of the kernel its
+    // registers are allocated without V -- inlined into the workers' exchange, the reduction and the solve would push
+    // V (128 registers) out to scratch once per date -- and it starts polling the moment a date begins.
+    const unsigned G = gridDim.x - 1;  // workers
+    if (blockIdx.x == 0) {
+        lsm_reduce_loop<NB>(a, G, sm_mom, sm_coef);
+        return;
+    }
+    const unsigned wg = blockIdx.x - 1;
+    // Unit u of this thread = columns 2 (first2 + u * su) and the one after it.  The lane's byte offset lane_off is the
+    // only per-lane part of an address (32 bits: a row of this kernel's shards is < 4 GB); row bases and the unit
+    // offsets u * su * 16 are wave-uniform and live on the scalar unit.
+    const unsigned first2 = wg * 256u + (unsigned)tid;
+    const unsigned lane_off = first2 * 16u;
+    int64_t su = (int64_t)G * 256;
+    const int64_t first = 2 * (int64_t)first2, stride = 2 * su;
+    // units 0 .. n0-1 of this thread exist; the last of them may hold one path only (n0 / n1: live first / second paths)
+    const int n0 = first < a.n ? (int)std::min<int64_t>(NU, (a.n - 1 - first) / stride + 1) : 0;
+    const int n1 = (n0 > 0 && first + (int64_t)(n0 - 1) * stride + 1 >= a.n) ? n0 - 1 : n0;
+    // A path beyond the shard is given a price far out of the money (payoff 0: its V stays 0 and it never enters a
+    // regression) by two selects on the loaded value; the arithmetic then needs no lane masks.  (The 2 NU masks are
+    // recomputed per use: kept, they would be spilled scalar registers.)
+    const double safe = call ? 0.0 : 2.0 * a.K + 1.0;
+    const LsmPay pf = {call ? 1.0 : -1.0, call ? -a.K : a.K};
+    auto sanitize = [&](double2 s, int u) {
+        int m0 = n0, m1 = n1;
+        asm volatile("" : "+v"(m0), "+v"(m1));
+        s.x = u < m0 ? s.x : safe;
+        s.y = u < m1 ? s.y : safe;
+        return s;
+    };
+    auto row_of = [&](int j) { return reinterpret_cast<const char*>(a.data + (int64_t)j * a.ld); };
+    // Unconditional loads (a predicated load is a branch).  A unit beyond the shard reads at most 512 NU columns past
+    // the row's end, i.e. inside the next row (the host launches this kernel for n >= 512 NU only); the terminal row,
+    // which has no next row, clamps its index instead.
+    auto unit_ptr = [&](const char* row, int u) {
+        asm volatile("" : "+s"(su));  // u * su recomputed on the scalar unit per use (hoisted: 2 SGPRs per unit and row)
+        return row + (int64_t)u * su * 16 + lane_off;
+    };
+    // LDS-DMA of unit u of `row` into ring slot `slot` (this wave's 1 KiB of it)
+    auto fetch = [&](const char* row, int u, int slot) {
+        double2* dst = ring + slot * 256 + wave * 64;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)unit_ptr(row, u),
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    };
+    const unsigned ring_lane = (unsigned)(size_t)(__attribute__((address_space(3))) void*)ring + (unsigned)tid * 16u;
+    int parity = 0;
+    bool gave_up = a.spin_limit == 0;
+
+    double V[2 * NU];
+    {
+        const double2* last = reinterpret_cast<const double2*>(row_of(a.n_cols - 1));
+        const unsigned last2 = (unsigned)(a.ld / 2 - 1);
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const double2 s = sanitize(last[min(first2 + (unsigned)u * (unsigned)su, last2)], u);
+            V[2 * u] = lsm_pay(pf, s.x);  // LSMPricer.cpp:37-40
+            V[2 * u + 1] = lsm_pay(pf, s.y);
+            if ((u % 8) == 7) asm volatile("" ::: "memory");  // eight loads in flight, not all NU
+        }
+    }
+    int j = a.n_cols - 2;
+    for (; j >= 0 && j * a.dt > a.maturity; --j) {  // LSMPricer.cpp:43-49, uniform over the grid
+#pragma unroll
+        for (int q = 0; q < 2 * NU; ++q) V[q] *= a.disc;
+    }
+    double m[NM];
+#pragma unroll
+    for (int t = 0; t < NM; ++t) m[t] = 0.0;
+    if (j >= 0) {  // moments of the first regression date (plain loads: nothing else is in flight yet)
+        const char* row = row_of(j);
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const double2 s = sanitize(*reinterpret_cast<const double2*>(unit_ptr(row, u)), u);
+            lsm_accumulate<NB>(m, pf, s.x, V[2 * u], a.invK, a.disc);
+            lsm_accumulate<NB>(m, pf, s.y, V[2 * u + 1], a.invK, a.disc);
+            if ((u % 8) == 7) asm volatile("" ::: "memory");
+        }
+    }
+    for (; j >= 0; --j) {  // every remaining date regresses (this_time <= maturity from here on)
+        const char* row_j = row_of(j);
+        // At j = 0 there is no earlier date: the pass still runs its moment half, on row 0 again, and nobody reads
+        // the result -- cheaper than a second copy of the loop or a branch per unit.
+        const char* row_n = row_of(j >= 1 ? j - 1 : 0);
+        lsm_publish_partials<NB>(a, m, G, wg, parity, red);
+#pragma unroll
+        for (int u = 0; u < LA; ++u) {  // the first units of this date travel while the moments and coefficients do
+            fetch(row_j, u, (2 * u) % LSM_RING_SLOTS);
+            fetch(row_n, u, (2 * u + 1) % LSM_RING_SLOTS);
+        }
+        lsm_poll_coefficients(a, parity, gave_up, sm_coef);
+        double c[NB];
+#pragma unroll
+        for (int t = 0; t < NB; ++t) c[t] = sm_coef[t];
+        const unsigned long long any_itm = sm_coef[9] > 0.0 ? ~0ull : 0ull;
+#pragma unroll
+        for (int t = 0; t < NM; ++t) m[t] = 0.0;
+        static_for<0, NU>([&](auto uc) {
+            constexpr int u = decltype(uc)::value;
+            // Units u .. min(u + LA, NU) - 1 have been requested, two DMAs each, and DMAs land in order: unit u is in
+            // LDS once at most 2 (that count - 1) are outstanding.  The ring is read by hand-written ds_read (through the
+            // compiler every LDS read would wait for ALL DMAs in flight), and the reads are complete before the slots are
+            // handed to unit u + LA.
+            constexpr int o0 = ((2 * u) % LSM_RING_SLOTS) * 4096, o1 = ((2 * u + 1) % LSM_RING_SLOTS) * 4096;
+            constexpr int pending = 2 * ((u + LA < NU ? LA : NU - u) - 1);
+            v2d r0, r1;
+            asm volatile(
+                "s_waitcnt vmcnt(%3)\n\t"
+                "ds_read_b128 %0, %2 offset:%4\n\t"
+                "ds_read_b128 %1, %2 offset:%5\n\t"
+                "s_waitcnt lgkmcnt(0)"
+                : "=&v"(r0), "=&v"(r1)
+                : "v"(ring_lane), "n"(pending), "n"(o0), "n"(o1)
+                : "memory");
+            if (u + LA < NU) {
+                fetch(row_j, u + LA, (2 * u) % LSM_RING_SLOTS);
+                fetch(row_n, u + LA, (2 * u + 1) % LSM_RING_SLOTS);
+            }
+            double2 sj = make_double2(r0.x, r0.y), sn = make_double2(r1.x, r1.y);
+            if (u >= a.u_full) {  // wave-uniform: only the shard's last unit or two can hold paths that do not exist
+                sj = sanitize(sj, u);
+                sn = sanitize(sn, u);
+            }
+            V[2 * u] = lsm_update<NB>(pf, sj.x, V[2 * u], c, any_itm, a.invK, a.disc);
+            V[2 * u + 1] = lsm_update<NB>(pf, sj.y, V[2 * u + 1], c, any_itm, a.invK, a.disc);
+            lsm_accumulate<NB>(m, pf, sn.x, V[2 * u], a.invK, a.disc);
+            lsm_accumulate<NB>(m, pf, sn.y, V[2 * u + 1], a.invK, a.disc);
+            // One unit's arithmetic at a time: interleaving more of them for ILP costs registers this kernel does not
+            // have (V alone is 128 of the 256), and two paths already give the scheduler independent chains.  The empty
+            // asm makes the moments "used" here: without it hipcc postpones every unit's accumulation to the end of the
+            // date and keeps all NU loaded values of row j-1 alive until then.
+#pragma unroll
+            for (int t = 0; t < NM; ++t) asm volatile("" : "+v"(m[t]));
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        parity ^= 1;
+    }
+    double f[2] = {0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < 2 * NU; ++q) {  // paths beyond the shard hold 0
+        f[0] += V[q];
+        f[1] += V[q] * V[q];
+    }
+    __syncthreads();
+    block_sum<2, 4>(f, red);
+    if (tid == 0) {
+        a.out[2 * (int64_t)wg] = f[0];
+        a.out[2 * (int64_t)wg + 1] = f[1];
+    }
+}
+
 namespace {
 
 struct CoopVariant {
     const void* fn;
-    int ppt;
+    int ppt;        // paths per thread
+    size_t dyn_lds; // dynamic LDS per workgroup (k_lsm_big: the LDS-DMA ring)
+    bool exact;     // occupancy is fixed by LDS (2 workgroups per CU): no margin below the query
 };
+
+constexpr int LSM_N_VARIANTS = 4;
 
 template <int NB>
 const CoopVariant* coop_variants() {
-    static const CoopVariant v[2] = {{(const void*)k_lsm_coop<NB, 4, true>, 4}, {(const void*)k_lsm_coop<NB, 16, true>, 16}};
+    static const CoopVariant v[LSM_N_VARIANTS] = {
+        {(const void*)k_lsm_coop<NB, 4, true>, 4, 0, false},
+        {(const void*)k_lsm_coop<NB, 16, true>, 16, 0, false},
+        {(const void*)k_lsm_big<NB, 16>, 32, LSM_RING_SLOTS * 256 * sizeof(double2), true},
+        {(const void*)k_lsm_big<NB, 32>, 64, LSM_RING_SLOTS * 256 * sizeof(double2), true}};
     return v;
 }
 
@@ -475,30 +777,43 @@ static int run_lsm_coop(mcg_ctx* ctx, const mcg_paths* P, double r, double K, do
     // Few paths per thread keep each workgroup's serial work per date short, a small grid keeps the reduction in
     // workgroup 0 short: take the fewest paths per thread that need at most two workgroups per CU, else the most.
     const CoopVariant* use = nullptr;
-    int grid = 0;
+    int grid = 0, workers = 0;
     static const int min_ppt = std::getenv("MCG_LSM_COOP_MIN_PPT") ? std::atoi(std::getenv("MCG_LSM_COOP_MIN_PPT")) : 0;  // experiments
-    static std::atomic<int> occ_cache[10][2];  // workgroups per CU of each variant (0 = not asked yet); same on every device
-    for (int k = 0; k < 2; ++k) {
+    static std::atomic<int> occ_cache[10][LSM_N_VARIANTS];  // workgroups per CU of each variant (0 = not asked yet); same on every device
+    for (int k = 0; k < LSM_N_VARIANTS; ++k) {
         if (vars[k].ppt < min_ppt) continue;
         int occ = occ_cache[nb][k].load(std::memory_order_relaxed);
         if (occ == 0) {
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, vars[k].fn, 256, 0) != hipSuccess || occ < 1) occ = -1;
+            if (vars[k].dyn_lds > 48 * 1024 &&
+                hipFuncSetAttribute(vars[k].fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vars[k].dyn_lds) != hipSuccess) {
+                (void)hipGetLastError();
+                occ = -1;
+            } else if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, vars[k].fn, 256, vars[k].dyn_lds) != hipSuccess || occ < 1) {
+                (void)hipGetLastError();
+                occ = -1;
+            }
             occ_cache[nb][k].store(occ, std::memory_order_relaxed);
         }
         if (occ < 1) continue;
         // The occupancy query can read one workgroup per CU high for kernels with ~100 SGPRs (MI355X_MICROARCH.md,
-        // "Correctness boundaries"), and nothing would reject the over-sized grid: stay an eighth below it.
-        const int64_t g_max = std::min<int64_t>((int64_t)std::min(occ, 4) * ctx->n_cus * 7 / 8, LSM_COOP_MAX_GRID);
+        // "Correctness boundaries"), and nothing would reject the over-sized grid: stay an eighth below it -- except
+        // where LDS alone fixes two workgroups per CU (k_lsm_big: 64 KiB each of the CU's 160).
+        const int64_t g_max = vars[k].exact ? std::min<int64_t>((int64_t)std::min(occ, 2) * ctx->n_cus, LSM_COOP_MAX_GRID)
+                                            : std::min<int64_t>((int64_t)std::min(occ, 4) * ctx->n_cus * 7 / 8, LSM_COOP_MAX_GRID);
         const int64_t per_block = 256 * (int64_t)vars[k].ppt;
-        if (g_max * per_block < N) continue;
+        // k_lsm_big: workgroup 0 only reduces and solves, the paths belong to workgroups 1 .. grid-1
+        const int64_t extra = vars[k].exact ? 1 : 0;
+        if ((g_max - extra) * per_block < N) continue;
+        if (vars[k].exact && N < 2 * per_block) continue;  // (its unmasked loads assume a row much longer than a unit stride)
         use = &vars[k];
-        grid = (int)((N + per_block - 1) / per_block);
+        workers = (int)((N + per_block - 1) / per_block);
+        grid = workers + (int)extra;
         if (grid <= 2 * ctx->n_cus) break;
     }
     if (!use) return MCG_OK;
-    // buffer: {sum, sum^2} per block | [2][nm][grid] moment slots | [2][16] coefficient slots
-    const size_t n_slots = 2 * (size_t)nm * grid + 32;
-    int rc = ensure_cap(ctx, &ctx->partials, &ctx->partials_cap, 2 * (size_t)grid + n_slots);
+    // buffer: {sum, sum^2} per contributing workgroup | [2][nm][workers] moment slots | [2][16] coefficient slots
+    const size_t n_slots = 2 * (size_t)nm * workers + 32;
+    int rc = ensure_cap(ctx, &ctx->partials, &ctx->partials_cap, 2 * (size_t)workers + n_slots);
     if (rc) return rc;
     LsmCoopArgs a;
     a.data = P->data;
@@ -512,11 +827,12 @@ static int run_lsm_coop(mcg_ctx* ctx, const mcg_paths* P, double r, double K, do
     a.disc = std::exp(-r * dt);  // LSMPricer.cpp:46,:69,:92
     a.is_call = is_call;
     a.out = ctx->partials;  // finish_sums reads {sum, sum^2} pairs from the head of the buffer
-    a.partials = ctx->partials + 2 * (size_t)grid;
-    a.coef = a.partials + 2 * (size_t)nm * grid;
+    a.partials = ctx->partials + 2 * (size_t)workers;
+    a.coef = a.partials + 2 * (size_t)nm * workers;
     a.timeout = reinterpret_cast<unsigned*>(ctx->scalars + SC_BARRIER);
     // test hook: MCG_LSM_SPIN_LIMIT=0 makes every wait give up at once and raises the time-out flag, which drives
     // the time-out -> per-date fall-back branch below on a healthy device (read on every call: tests flip it)
+    a.u_full = (int)(N / ((int64_t)workers * 512));  // (k_lsm_big: units per thread that every thread has in full)
     a.spin_limit = LSM_SPIN_LIMIT;
     if (const char* e = std::getenv("MCG_LSM_SPIN_LIMIT")) a.spin_limit = (unsigned)std::strtoul(e, nullptr, 10);
     MCG_HIP(hipMemsetD32Async((hipDeviceptr_t)a.partials, (int)LSM_SENTINEL32, 2 * n_slots, ctx->stream));
@@ -531,10 +847,10 @@ static int run_lsm_coop(mcg_ctx* ctx, const mcg_paths* P, double r, double K, do
         std::lock_guard<std::mutex> hold(one_at_a_time);
         {
             TimedLaunch t(ctx, MCG_K_LSM_SWEEP);
-            MCG_HIP(hipLaunchKernel(use->fn, dim3((unsigned)grid), dim3(256), params, 0, ctx->stream));
+            MCG_HIP(hipLaunchKernel(use->fn, dim3((unsigned)grid), dim3(256), params, use->dyn_lds, ctx->stream));
         }
         MCG_HIP(hipMemcpyAsync(ctx->h_scalars + SC_BARRIER, a.timeout, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
-        rc = finish_sums(ctx, grid, N, sums3);  // synchronises the stream
+        rc = finish_sums(ctx, workers, N, sums3);  // synchronises the stream
     }
     if (rc) return rc;
     if (reinterpret_cast<const unsigned*>(ctx->h_scalars + SC_BARRIER)[0] != 0) {
