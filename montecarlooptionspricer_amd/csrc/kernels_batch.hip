@@ -252,13 +252,14 @@ __global__ __launch_bounds__(256) void k_batch_branching(BatchArgs a) {
 // One wavefront per row, four rows per workgroup (lsm_wave_body).
 template <int NB>
 __global__ __launch_bounds__(256) void k_batch_lsm(BatchArgs a) {
+    __shared__ double ws[4][lsm_ws_doubles(NB) + LSM_COEF_DOUBLES];  // per wave: workspace of a refined date's solve
     const int64_t r_idx = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r_idx >= a.n_rows) return;
     const BatchRow row = a.rows[r_idx];
     if (!row.valid) return;
     double sum_v, sum_v2;
     lsm_wave_body<NB>(a.S + r_idx * 256, a.ld, a.n_paths, row.n_steps + 1, row.strike, row.maturity, a.dt, a.disc, row.is_call,
-                      sum_v, sum_v2);
+                      ws[threadIdx.x >> 6], sum_v, sum_v2);
     if ((threadIdx.x & 63) == 0) a.out[4 * r_idx + 2] = sum_v / (double)a.n_paths;
 }
 
@@ -322,7 +323,7 @@ __global__ __launch_bounds__(256) void k_batch_martingale(BatchArgs a) {
     if (threadIdx.x == 0) {
 #pragma unroll
         for (int q = 0; q <= NM; ++q) sm_mom[q] = m[q];
-        lsm_solve_nb<NB>(sm_mom, (double)NB, sm_coef);
+        lsm_solve_nb<NB>(sm_mom, (double)NB, 0.0, sm_coef);  // (K = 0: the refit of M is not refined, see lsm_solve_nb)
     }
     __syncthreads();
     const double primal = sm_mom[NM] / (double)a.n_paths;

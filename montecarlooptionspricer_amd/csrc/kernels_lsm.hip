@@ -34,7 +34,7 @@ struct LsmArgs {
     double K, invK, disc;
     int is_call;
     int upd;
-    const double* coef;   // device: coef[0..NB), coef[9] = number of ITM paths of date j (global)
+    const double* coef;   // device: the coefficient block of date j (lsm_device.hpp: LSM_C_*)
     double* partials;     // [NM][gridDim.x] (moment-major: the reduce kernel reads contiguously)
     int rev;              // walk the grid-stride chunks from the last to the first (see run_lsm)
 };
@@ -46,11 +46,12 @@ __global__ __launch_bounds__(256) void k_lsm_sweep(LsmArgs a) {
     __shared__ double red[NM * 4];
     const bool call = a.is_call != 0;
     double c[NB];
-    double n_itm = 0.0;
+    double n_itm = 0.0, center = 0.0;
     if (a.upd == UPD_REGRESS) {
 #pragma unroll
         for (int q = 0; q < NB; ++q) c[q] = a.coef[q];
-        n_itm = a.coef[9];
+        n_itm = a.coef[LSM_C_COUNT];
+        center = a.coef[LSM_C_CENTER];
     }
     double m[NM];
 #pragma unroll
@@ -71,11 +72,7 @@ __global__ __launch_bounds__(256) void k_lsm_sweep(LsmArgs a) {
             const double pay = payoff_of(call, s, a.K);
             const double vn = a.V[i] * a.disc;
             if (pay > 1e-14 && n_itm > 0.0) {  // :78-86
-                const double x = fma(s, a.invK, -1.0);
-                double cont = c[NB - 1];
-#pragma unroll
-                for (int q = NB - 2; q >= 0; --q) cont = fma(cont, x, c[q]);
-                v = fmax(pay, cont);
+                v = fmax(pay, lsm_continuation<NB>(c, center, fma(s, a.invK, -1.0)));
             } else if (pay < 1e-14) {  // :89-94
                 v = vn;
             } else {
@@ -107,13 +104,48 @@ __global__ __launch_bounds__(256) void k_lsm_sweep(LsmArgs a) {
     }
 }
 
+// What k_lsm_reduce_solve needs to re-fit a date about the mean of its regressor (lsm_solve_nb's refinement request):
+// the row the moments came from and the value vector they were formed with.  S == nullptr: never refine (sharded
+// runs -- the centred moments would need a second, data-dependent all-reduce -- and MartingaleOptimization's refit).
+struct LsmRefine {
+    const double* S;
+    const double* V;
+    int64_t n;
+    double K, disc;
+    int is_call;
+};
+
+template <int NB>
+__device__ __forceinline__ void lsm_refine_block(const LsmRefine& rf, double mu, double* red, double* mc_out) {
+    constexpr int NM = 3 * NB - 1;
+    const bool call = rf.is_call != 0;
+    const double invK = 1.0 / rf.K;
+    double m[NM];
+#pragma unroll
+    for (int t = 0; t < NM; ++t) m[t] = 0.0;
+    for (int64_t i = threadIdx.x; i < rf.n; i += 256) {
+        const double sv = rf.S[i];
+        lsm_accumulate_centered<NB>(m, payoff_of(call, sv, rf.K) > 1e-14, sv, rf.V[i], invK, mu, rf.disc);
+    }
+    block_sum<NM, 4>(m, red);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int t = 0; t < NM; ++t) mc_out[t] = m[t];
+    }
+}
+
 // One block.  do_reduce: partials[nm][n_blocks] -> moments[nm] in a fixed order (wave w sums moments
 // w, w+4, ...: lanes stride over the blocks, then a wavefront butterfly).  do_solve: moments -> coef.
 // Single GPU: both in one launch.  Sharded: reduce, all-reduce of `moments`, then solve.
+// A date that asks for refinement (rare: lsm_solve_nb) is re-accumulated about its mean by THIS block alone --
+// one workgroup streaming the row, slow and correct -- and solved by lsm_solve_centered.
 __global__ __launch_bounds__(256) void k_lsm_reduce_solve(const double* partials, int n_blocks, int nm, int nb,
                                                           double* moments, double* coef, int do_reduce, int do_solve,
-                                                          double min_count) {
+                                                          double min_count, LsmRefine rf) {
     __shared__ double sm[32];
+    __shared__ double sm_c[16];
+    __shared__ double red[26 * 4];
+    __shared__ double sm_ws[lsm_ws_doubles(9)];
     if (do_reduce) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         for (int q = wave; q < nm; q += 4) {
@@ -128,7 +160,29 @@ __global__ __launch_bounds__(256) void k_lsm_reduce_solve(const double* partials
         }
         __syncthreads();
     }
-    if (do_solve && threadIdx.x == 0) lsm_solve_one(do_reduce ? sm : moments, nb, min_count, coef);
+    if (!do_solve) return;
+    if (threadIdx.x == 0) {
+        lsm_solve_one(do_reduce ? sm : moments, nb, min_count, rf.S ? rf.K : 0.0, sm_c);
+        if (!rf.S) sm_c[LSM_C_REFINE] = 0.0;
+    }
+    __syncthreads();
+    if (sm_c[LSM_C_REFINE] != 0.0) {  // uniform
+        const double mu = sm_c[LSM_C_HINT];
+        switch (nb) {
+            case 1: lsm_refine_block<1>(rf, mu, red, sm); break;
+            case 2: lsm_refine_block<2>(rf, mu, red, sm); break;
+            case 3: lsm_refine_block<3>(rf, mu, red, sm); break;
+            case 4: lsm_refine_block<4>(rf, mu, red, sm); break;
+            case 5: lsm_refine_block<5>(rf, mu, red, sm); break;
+            case 6: lsm_refine_block<6>(rf, mu, red, sm); break;
+            case 7: lsm_refine_block<7>(rf, mu, red, sm); break;
+            case 8: lsm_refine_block<8>(rf, mu, red, sm); break;
+            default: lsm_refine_block<9>(rf, mu, red, sm); break;
+        }
+        if (threadIdx.x == 0) lsm_solve_centered(sm, nb, mu, rf.K, sm_c, sm_ws);
+        __syncthreads();
+    }
+    if (threadIdx.x < LSM_COEF_DOUBLES) coef[threadIdx.x] = sm_c[threadIdx.x];
 }
 
 template <int NB, int PPT>
@@ -143,8 +197,9 @@ __global__ __launch_bounds__(256) void k_lsm_small(const double* data, int64_t l
 template <int NB>
 __global__ __launch_bounds__(64) void k_lsm_small_wave(const double* data, int64_t ld, int n, int n_cols, double K,
                                                        double maturity, double dt, double disc, int is_call, double* out3) {
+    __shared__ double ws[lsm_ws_doubles(NB) + LSM_COEF_DOUBLES];
     double sum_v, sum_v2;
-    lsm_wave_body<NB>(data, ld, n, n_cols, K, maturity, dt, disc, is_call, sum_v, sum_v2);
+    lsm_wave_body<NB>(data, ld, n, n_cols, K, maturity, dt, disc, is_call, ws, sum_v, sum_v2);
     if (threadIdx.x == 0) {
         out3[0] = sum_v;
         out3[1] = sum_v2;
@@ -254,9 +309,11 @@ __device__ __forceinline__ void lsm_publish_partials(const LsmCoopArgs& a, doubl
 // sm_coef for its own threads).  The same fixed-order reduction as k_lsm_reduce_solve: wave w sums moments w, w+4, ...;
 // lane l the workgroups l, l+64, ...  Two of the wave's moments per round: all their slots are polled together, so the
 // usual date costs one round trip to the coherence point, not one per moment.
+// centered: this round carries the moments of a refinement pass about `mu` (lsm_solve_nb asked for it on the previous
+// round of the same date); ws = LDS workspace of lsm_solve_centered.
 template <int NB>
 __device__ __forceinline__ void lsm_reduce_solve_publish(const LsmCoopArgs& a, unsigned G, int parity, bool& gave_up, double* sm_mom,
-                                                         double* sm_coef) {
+                                                         double* sm_coef, bool centered, double mu, double* ws) {
     constexpr int NM = 3 * NB - 1;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double* part = a.partials + (int64_t)parity * NM * G;
@@ -308,18 +365,21 @@ __device__ __forceinline__ void lsm_reduce_solve_publish(const LsmCoopArgs& a, u
         }
     }
     // all partials of this date are in: every workgroup is past the previous date's coefficients
-    if (threadIdx.x < 10) lsm_st_shared(a.coef + 16 * (parity ^ 1) + threadIdx.x, lsm_sentinel());
+    if (threadIdx.x < LSM_COEF_DOUBLES) lsm_st_shared(a.coef + 16 * (parity ^ 1) + threadIdx.x, lsm_sentinel());
     __syncthreads();
-    if (threadIdx.x == 0) lsm_solve_nb<NB>(sm_mom, 1.0, sm_coef);
+    if (threadIdx.x == 0) {
+        if (centered) lsm_solve_centered(sm_mom, NB, mu, a.K, sm_coef, ws);
+        else lsm_solve_nb<NB>(sm_mom, 1.0, a.K, sm_coef);
+    }
     __builtin_amdgcn_s_waitcnt(0);  // the recycling stores are acknowledged before anything newer goes out
     __syncthreads();
-    if (threadIdx.x < 10) lsm_st_shared(coef_now + threadIdx.x, sm_coef[threadIdx.x]);
+    if (threadIdx.x < LSM_COEF_DOUBLES) lsm_st_shared(coef_now + threadIdx.x, sm_coef[threadIdx.x]);
 }
 
-// every other workgroup: lanes 0..9 poll one coefficient each into sm_coef
+// every other workgroup: the first LSM_COEF_DOUBLES lanes poll one entry of the coefficient block each into sm_coef
 __device__ __forceinline__ void lsm_poll_coefficients(const LsmCoopArgs& a, int parity, bool& gave_up, double* sm_coef) {
     double* coef_now = a.coef + 16 * parity;
-    if (threadIdx.x < 10) {
+    if (threadIdx.x < LSM_COEF_DOUBLES) {
         double cv = lsm_ld_shared(coef_now + threadIdx.x);
         unsigned spins = 0;
         while (lsm_is_sentinel(cv) && !gave_up) {
@@ -340,10 +400,11 @@ __device__ __forceinline__ void lsm_poll_coefficients(const LsmCoopArgs& a, int 
 // have left: the place to put loads in flight that should overlap the ~10 us the moments and coefficients travel.
 template <int NB, class F>
 __device__ __forceinline__ void lsm_exchange(const LsmCoopArgs& a, double (&m)[3 * NB - 1], int parity, bool& gave_up,
-                                             double* red, double* sm_mom, double* sm_coef, F&& after_publish) {
+                                             double* red, double* sm_mom, double* sm_coef, bool centered, double mu, double* ws,
+                                             F&& after_publish) {
     lsm_publish_partials<NB>(a, m, gridDim.x, blockIdx.x, parity, red);
     after_publish();
-    if (blockIdx.x == 0) lsm_reduce_solve_publish<NB>(a, gridDim.x, parity, gave_up, sm_mom, sm_coef);
+    if (blockIdx.x == 0) lsm_reduce_solve_publish<NB>(a, gridDim.x, parity, gave_up, sm_mom, sm_coef, centered, mu, ws);
     else lsm_poll_coefficients(a, parity, gave_up, sm_coef);
 }
 
@@ -354,9 +415,9 @@ __global__ __launch_bounds__(256, (PPT >= 16 ? 2 : 3)) void k_lsm_coop(LsmCoopAr
     __shared__ double red[NM * 4];
     __shared__ double sm_mom[32];
     __shared__ double sm_coef[16];
+    __shared__ double sm_ws[lsm_ws_doubles(NB)];
     const bool call = a.is_call != 0;
     const unsigned G = gridDim.x;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // Path q of this thread is column first + q * stride.  `first` is the only per-lane part of an address: rows and
     // the q * stride offsets are wave-uniform and stay in scalar registers (a per-lane 64-bit address per path would
     // cost as many VGPRs as V itself).
@@ -418,15 +479,28 @@ __global__ __launch_bounds__(256, (PPT >= 16 ? 2 : 3)) void k_lsm_coop(LsmCoopAr
                 }
             }
         }
-        lsm_exchange<NB>(a, m, parity, gave_up, red, sm_mom, sm_coef, [&]() {
+        lsm_exchange<NB>(a, m, parity, gave_up, red, sm_mom, sm_coef, false, 0.0, sm_ws, [&]() {
             if constexpr (PREFETCH) {
                 if (j >= 1) load_row(j - 1, s_nxt);
             }
         });
+        if (__builtin_amdgcn_readfirstlane(sm_coef[LSM_C_REFINE] != 0.0 ? 1 : 0)) {  // (the same LDS word in every lane)
+            // Grid-uniform (every workgroup holds the same coefficient block): the date is re-fitted about the mean of its
+            // regressor -- the prices and V are still in registers -- through one more exchange (lsm_solve_nb).
+            const double mu = sm_coef[LSM_C_HINT];
+            __syncthreads();  // everyone has read the block before the next exchange rewrites sm_coef
+#pragma unroll
+            for (int q = 0; q < NM; ++q) m[q] = 0.0;
+#pragma unroll
+            for (int q = 0; q < PPT; ++q)
+                lsm_accumulate_centered<NB>(m, q < n_live && payoff_of(call, s_j[q], a.K) > 1e-14, s_j[q], V[q], a.invK, mu, a.disc);
+            parity ^= 1;
+            lsm_exchange<NB>(a, m, parity, gave_up, red, sm_mom, sm_coef, true, mu, sm_ws, []() {});
+        }
         double c[NB];
 #pragma unroll
         for (int t = 0; t < NB; ++t) c[t] = sm_coef[t];
-        const double n_itm = sm_coef[9];
+        const double n_itm = sm_coef[LSM_C_COUNT], center = sm_coef[LSM_C_CENTER];
 #pragma unroll
         for (int q = 0; q < PPT; ++q) {  // :78-94
             const double s = s_j[q];
@@ -434,11 +508,7 @@ __global__ __launch_bounds__(256, (PPT >= 16 ? 2 : 3)) void k_lsm_coop(LsmCoopAr
             const double vn = V[q] * a.disc;
             double v;
             if (pay > 1e-14 && n_itm > 0.0) {
-                const double x = fma(s, a.invK, -1.0);
-                double cont = c[NB - 1];
-#pragma unroll
-                for (int t = NB - 2; t >= 0; --t) cont = fma(cont, x, c[t]);
-                v = fmax(pay, cont);
+                v = fmax(pay, lsm_continuation<NB>(c, center, fma(s, a.invK, -1.0)));
             } else if (pay < 1e-14) {
                 v = vn;
             } else {
@@ -521,14 +591,11 @@ __device__ __forceinline__ double lsm_select(unsigned long long mask, double a, 
 }
 
 template <int NB>
-__device__ __forceinline__ double lsm_update(const LsmPay& p, double s, double v_old, const double (&c)[NB],
+__device__ __forceinline__ double lsm_update(const LsmPay& p, double s, double v_old, const double (&c)[NB], double center,
                                              unsigned long long any_itm /* all ones / zero: wave-uniform */,
                                              double invK, double disc) {  // LSMPricer.cpp:78-94
     const double pay = lsm_pay(p, s);
-    const double x = fma(s, invK, -1.0);
-    double cont = c[NB - 1];
-#pragma unroll
-    for (int t = NB - 2; t >= 0; --t) cont = fma(cont, x, c[t]);
+    const double cont = lsm_continuation<NB>(c, center, fma(s, invK, -1.0));
     // payoff == 1e-14 exactly falls through both of the reference's branches (:55 vs :91) and keeps 0
     // The two selects are written as v_cndmask on a ballot mask: from `c ? a : b` hipcc builds a divergent branch
     // around the polynomial here, i.e. four extra basic blocks and two exec-mask round trips per path.
@@ -554,7 +621,7 @@ __device__ __forceinline__ constexpr int lsm_vmcnt(int n) { return (n & 15) | ((
 // The reducing workgroup of k_lsm_big: one exchange per regression date, the same dates in the same order as the
 // workers count them (LSMPricer.cpp:42-49).
 template <int NB>
-__device__ __forceinline__ void lsm_reduce_loop(const LsmCoopArgs& a, unsigned G, double* sm_mom, double* sm_coef) {
+__device__ __forceinline__ void lsm_reduce_loop(const LsmCoopArgs& a, unsigned G, double* sm_mom, double* sm_coef, double* ws) {
     bool gave_up = a.spin_limit == 0;
     if (gave_up && threadIdx.x == 0) __hip_atomic_store(a.timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     int j = a.n_cols - 2;
@@ -562,9 +629,17 @@ __device__ __forceinline__ void lsm_reduce_loop(const LsmCoopArgs& a, unsigned G
     }
     int parity = 0;
     for (; j >= 0; --j) {
-        lsm_reduce_solve_publish<NB>(a, G, parity, gave_up, sm_mom, sm_coef);
-        __syncthreads();  // sm_mom / sm_coef are rewritten on the next date
+        lsm_reduce_solve_publish<NB>(a, G, parity, gave_up, sm_mom, sm_coef, false, 0.0, ws);
+        __syncthreads();
+        const bool refine = __builtin_amdgcn_readfirstlane(sm_coef[LSM_C_REFINE] != 0.0 ? 1 : 0) != 0;
+        const double mu = sm_coef[LSM_C_HINT];
+        __syncthreads();  // sm_mom / sm_coef are rewritten on the next round
         parity ^= 1;
+        if (refine) {  // the workers answer a refinement request with one more round for the same date
+            lsm_reduce_solve_publish<NB>(a, G, parity, gave_up, sm_mom, sm_coef, true, mu, ws);
+            __syncthreads();
+            parity ^= 1;
+        }
     }
 }
 
@@ -578,6 +653,7 @@ __global__ __launch_bounds__(256, 2) void k_lsm_big(LsmCoopArgs a) {
     __shared__ double red[NM * 4];
     __shared__ double sm_mom[32];
     __shared__ double sm_coef[16];
+    __shared__ double sm_ws[lsm_ws_doubles(NB)];
     const bool call = a.is_call != 0;
     const int tid = threadIdx.x, wave = tid >> 6;
     // Workgroup 0 holds no paths: it only reduces and solves (lsm_reduce_loop).  As a separate branch of the kernel its
@@ -585,7 +661,7 @@ __global__ __launch_bounds__(256, 2) void k_lsm_big(LsmCoopArgs a) {
     // V (128 registers) out to scratch once per date -- and it starts polling the moment a date begins.
     const unsigned G = gridDim.x - 1;  // workers
     if (blockIdx.x == 0) {
-        lsm_reduce_loop<NB>(a, G, sm_mom, sm_coef);
+        lsm_reduce_loop<NB>(a, G, sm_mom, sm_coef, sm_ws);
         return;
     }
     const unsigned wg = blockIdx.x - 1;
@@ -671,10 +747,30 @@ __global__ __launch_bounds__(256, 2) void k_lsm_big(LsmCoopArgs a) {
             fetch(row_n, u, (2 * u + 1) % LSM_RING_SLOTS);
         }
         lsm_poll_coefficients(a, parity, gave_up, sm_coef);
+        if (__builtin_amdgcn_readfirstlane(sm_coef[LSM_C_REFINE] != 0.0 ? 1 : 0)) {  // (the same LDS word in every lane)
+            // Grid-uniform and rare (lsm_solve_nb): date j is re-fitted about the mean of its regressor.  Row j is read
+            // once more, by plain loads (V still holds the values its first moments were formed with), and the centred
+            // moments take one more exchange with the reducing workgroup.
+            const double mu = sm_coef[LSM_C_HINT];
+            __syncthreads();  // everyone has read the block before the next poll rewrites sm_coef
+#pragma unroll
+            for (int t = 0; t < NM; ++t) m[t] = 0.0;
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const double2 sv = sanitize(*reinterpret_cast<const double2*>(unit_ptr(row_j, u)), u);
+                lsm_accumulate_centered<NB>(m, lsm_pay(pf, sv.x) > 1e-14, sv.x, V[2 * u], a.invK, mu, a.disc);
+                lsm_accumulate_centered<NB>(m, lsm_pay(pf, sv.y) > 1e-14, sv.y, V[2 * u + 1], a.invK, mu, a.disc);
+                if ((u % 4) == 3) asm volatile("" ::: "memory");
+            }
+            parity ^= 1;
+            lsm_publish_partials<NB>(a, m, G, wg, parity, red);
+            lsm_poll_coefficients(a, parity, gave_up, sm_coef);
+        }
         double c[NB];
 #pragma unroll
         for (int t = 0; t < NB; ++t) c[t] = sm_coef[t];
-        const unsigned long long any_itm = sm_coef[9] > 0.0 ? ~0ull : 0ull;
+        const double center = sm_coef[LSM_C_CENTER];
+        const unsigned long long any_itm = sm_coef[LSM_C_COUNT] > 0.0 ? ~0ull : 0ull;
 #pragma unroll
         for (int t = 0; t < NM; ++t) m[t] = 0.0;
         static_for<0, NU>([&](auto uc) {
@@ -703,8 +799,8 @@ __global__ __launch_bounds__(256, 2) void k_lsm_big(LsmCoopArgs a) {
                 sj = sanitize(sj, u);
                 sn = sanitize(sn, u);
             }
-            V[2 * u] = lsm_update<NB>(pf, sj.x, V[2 * u], c, any_itm, a.invK, a.disc);
-            V[2 * u + 1] = lsm_update<NB>(pf, sj.y, V[2 * u + 1], c, any_itm, a.invK, a.disc);
+            V[2 * u] = lsm_update<NB>(pf, sj.x, V[2 * u], c, center, any_itm, a.invK, a.disc);
+            V[2 * u + 1] = lsm_update<NB>(pf, sj.y, V[2 * u + 1], c, center, any_itm, a.invK, a.disc);
             lsm_accumulate<NB>(m, pf, sn.x, V[2 * u], a.invK, a.disc);
             lsm_accumulate<NB>(m, pf, sn.y, V[2 * u + 1], a.invK, a.disc);
             // One unit's arithmetic at a time: interleaving more of them for ILP costs registers this kernel does not
@@ -866,24 +962,27 @@ static int run_lsm_coop(mcg_ctx* ctx, const mcg_paths* P, double r, double K, do
 
 // partials[grid][nm] -> moments (fixed order) -> optional all-reduce -> coefficients in ctx->scalars.
 // Shared by the LSM sweep and the MartingaleOptimization refit.
-int lsm_reduce_allreduce_solve(mcg_ctx* ctx, int grid, int nm, int nb, double min_count) {
+int lsm_reduce_allreduce_solve(mcg_ctx* ctx, int grid, int nm, int nb, double min_count, const double* refine_row,
+                               const double* refine_v, int64_t refine_n, double K, double disc, int is_call) {
     double* moments = ctx->scalars + SC_MOMENTS;
     double* coef = ctx->scalars + SC_COEF;
+    // refinement of an ill-conditioned date (lsm_solve_nb) is single-GPU only: see LsmRefine
+    LsmRefine rf{ctx->allreduce ? nullptr : refine_row, refine_v, refine_n, K, disc, is_call};
     if (ctx->allreduce) {
         {
             TimedLaunch t(ctx, MCG_K_LSM_SOLVE);
             hipLaunchKernelGGL(k_lsm_reduce_solve, dim3(1), dim3(256), 0, ctx->stream, ctx->partials, grid, nm, nb,
-                               moments, coef, 1, 0, min_count);
+                               moments, coef, 1, 0, min_count, rf);
         }
         if (ctx->allreduce(ctx->allreduce_user, moments, nm, (void*)ctx->stream) != 0)
             return fail(MCG_ERR_COMM, "all-reduce of regression moments failed");
         TimedLaunch t(ctx, MCG_K_LSM_SOLVE);
         hipLaunchKernelGGL(k_lsm_reduce_solve, dim3(1), dim3(256), 0, ctx->stream, ctx->partials, grid, nm, nb, moments,
-                           coef, 0, 1, min_count);
+                           coef, 0, 1, min_count, rf);
     } else {
         TimedLaunch t(ctx, MCG_K_LSM_SOLVE);
         hipLaunchKernelGGL(k_lsm_reduce_solve, dim3(1), dim3(256), 0, ctx->stream, ctx->partials, grid, nm, nb, moments,
-                           coef, 1, 1, min_count);
+                           coef, 1, 1, min_count, rf);
     }
     MCG_HIP(hipGetLastError());
     return MCG_OK;
@@ -998,8 +1097,8 @@ int run_lsm(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double maturit
 
     for (int j = M - 2; j >= 0; --j) {
         const bool reg = regress_at(j);
-        if (reg) {
-            int rcs = lsm_reduce_allreduce_solve(ctx, grid, nm, nb, 1.0);
+        if (reg) {  // the moments of date j came from row j and the value vector as it stands now
+            int rcs = lsm_reduce_allreduce_solve(ctx, grid, nm, nb, 1.0, row(j), ctx->lsm_v, N, K, disc, is_call);
             if (rcs) return rcs;
         }
         a.upd = reg ? UPD_REGRESS : UPD_DISCOUNT;

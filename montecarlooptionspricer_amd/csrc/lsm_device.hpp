@@ -5,21 +5,47 @@
 
 namespace mcg {
 
-// Solve the normal equations of the scaled basis from the (all-reduced) moments; one thread.
+// Layout of the coefficient block every solve writes (doubles): the fitted continuation value at price S is
+//   sum_t coef[t] y^t,  y = (S/K - 1) - coef[LSM_C_CENTER].
+constexpr int LSM_C_COUNT = 9;    // number of regression rows (in-the-money paths; global when sharded)
+constexpr int LSM_C_CENTER = 10;  // centre of the regressor (0 unless the date was refined)
+constexpr int LSM_C_REFINE = 11;  // 1: the caller should re-accumulate the moments about coef[LSM_C_HINT] and call
+constexpr int LSM_C_HINT = 12;    //    lsm_solve_centered; the coefficients already written are the fall-back
+constexpr int LSM_COEF_DOUBLES = 13;
+
+// LDS workspace of lsm_solve_centered for basis size nb (doubles)
+__host__ __device__ constexpr int lsm_ws_doubles(int nb) { return 7 * nb * nb + 8 * nb; }
+
+// First-pass solve from the moments of x = S/K - 1 (power sums m[0..2p], cross sums m[2p+1..3p+1]); one thread.
 // G[a][b] = m[a+b], rhs[a] = m[2p+1+a], equilibrated to unit diagonal.
-// Fast path: LDL^T without pivoting when every pivot stays above 1e-10 (the usual, well-conditioned
-// date: ~1 us).  Otherwise (one ITM path, all paths equal at j = 0, ...): cyclic Jacobi
-// eigen-decomposition and a pseudo-inverse with relative eigenvalue cut 1e-12, which yields the
-// projection the reference's min-norm SVD solve gives at the data points.
+//
+// What the reference computes (LSMPricer.cpp:61-76) is Eigen's bdcSvd().solve(b) on the RAW monomials 1, S, .., S^p:
+// the minimum-norm least-squares solution with singular values below min(rows, cols) eps sigma_max treated as zero.
+// Where that matrix has full numerical rank and the data are well spread, the fitted values are those of the unique
+// least-squares polynomial and any accurate method yields them: here LDL^T on the equilibrated normal equations of
+// the scaled regressor (cond ~1e2 instead of ~1e8; ~1 us).  The fast path is taken only when both hold:
+//   * every pivot > 1e-6 (normal equations then lose at most ~1e-10 of relative accuracy), and
+//   * est = (std(S) / max(mean(S), 1)^2)^p -- the size of sigma_min / sigma_max of the raw-monomial matrix for data
+//     of that spread -- exceeds Eigen's threshold by four orders of magnitude, so Eigen sees full rank as well.
+// Otherwise (few or nearly coincident in-the-money prices, all paths equal at j = 0, high orders whose raw monomials
+// Eigen itself truncates) the date is REFINED: coef[LSM_C_REFINE] = 1 asks the caller to re-accumulate the moments
+// about the mean coef[LSM_C_HINT] and to call lsm_solve_centered, which reproduces Eigen's truncated solve.  The
+// coefficients written here are then the fall-back for callers that cannot refine (sharded runs: a second,
+// data-dependent all-reduce per date cannot be scheduled from the host): cyclic Jacobi eigen-decomposition and a
+// pseudo-inverse with relative eigenvalue cut 1e-12, the projection on the numerical range of the scaled basis.
+// K <= 0 switches the refinement request off (MartingaleOptimization's refit).
 // NB is a template parameter so that every loop unrolls and G, Q live in registers: with a run-time size the
 // arrays go to scratch memory and the (serial, one-thread) solve takes ~20 us instead of ~2.
 template <int NB>
-__device__ __forceinline__ void lsm_solve_nb(const double* moments, double min_count, double* coef) {
+__device__ __forceinline__ void lsm_solve_nb(const double* moments, double min_count, double K, double* coef) {
     constexpr int nb = NB;
     double G[NB][NB], Q[NB][NB], rhs[NB], d[NB], sol[NB];
     const double count = moments[0];
-    coef[9] = count;
+    coef[LSM_C_COUNT] = count;
     for (int a = 0; a < 9; ++a) coef[a] = 0.0;
+    coef[LSM_C_CENTER] = 0.0;
+    coef[LSM_C_REFINE] = 0.0;
+    coef[LSM_C_HINT] = 0.0;
     if (!(count >= min_count) || !(count > 0.0)) return;  // too few samples: coefficients stay 0
     for (int a = 0; a < nb; ++a) {
         const double g = moments[2 * a];
@@ -31,6 +57,7 @@ __device__ __forceinline__ void lsm_solve_nb(const double* moments, double min_c
     }
     // ---- fast path: LDL^T in Q (L below the diagonal, D on it) ----
     bool ok = true;
+    double piv_min = 1.0;
     for (int j = 0; j < nb && ok; ++j) {
         double dj = G[j][j];
         for (int k = 0; k < j; ++k) dj -= Q[j][k] * Q[j][k] * Q[k][k];
@@ -38,12 +65,28 @@ __device__ __forceinline__ void lsm_solve_nb(const double* moments, double min_c
             ok = false;
             break;
         }
+        piv_min = fmin(piv_min, dj);
         Q[j][j] = dj;
         const double inv = 1.0 / dj;
         for (int i = j + 1; i < nb; ++i) {
             double v = G[i][j];
             for (int k = 0; k < j; ++k) v -= Q[i][k] * Q[j][k] * Q[k][k];
             Q[i][j] = v * inv;
+        }
+    }
+    bool trusted = ok;  // fast path accurate AND Eigen certainly at full rank
+    if (nb > 1 && K > 0.0) {
+        const double mean_x = moments[1] / count;
+        const double var_x = fmax(moments[2] / count - mean_x * mean_x, 0.0);
+        const double mean_s = K * (1.0 + mean_x);
+        const double scale = fmax(fabs(mean_s), 1.0);
+        const double ratio = K * sqrt(var_x) / (scale * scale);
+        double est = 1.0;
+        for (int t = 1; t < nb; ++t) est *= ratio;
+        trusted = ok && piv_min > 1e-6 && est > 1e4 * nb * 2.220446049250313e-16;
+        if (!trusted) {
+            coef[LSM_C_REFINE] = 1.0;
+            coef[LSM_C_HINT] = mean_x;
         }
     }
     if (ok) {
@@ -109,18 +152,209 @@ __device__ __forceinline__ void lsm_solve_nb(const double* moments, double min_c
     for (int a = 0; a < nb; ++a) coef[a] = sol[a] * d[a];
 }
 
+// The refined solve: Eigen's bdcSvd().solve(b) on the raw monomials (LSMPricer.cpp:76), reproduced from the moments
+// of the CENTRED regressor y = (S/K - 1) - mu (mu = mean over the regression rows, so the centred design matrix
+// A_y = [1, y, .., y^p] is as well conditioned as the data allow).  One thread; all matrices in the LDS workspace ws
+// (lsm_ws_doubles(nb) doubles): a rare path, kept out of the registers of the kernels that inline it.
+//   1. G_y = A_y^T A_y from the moments; equilibrate; cyclic Jacobi: G_y = D^-1 Q L Q^T D^-1.  Eigenvalues below
+//      1e-13 of the largest are exact duplicates in the data (columns of A_y that are numerically dependent
+//      whatever the basis) and are dropped.  F = L^1/2 Q^T D^-1 has F^T F = G_y, i.e. A_y = U_y F with orthonormal
+//      U_y, and z = F^-T A_y^T b = U_y^T b.
+//   2. The raw monomials are A_raw = A_y T, S^k = (K (1 + mu) + K y)^k = sum_i C(k,i) (K (1 + mu))^(k-i) K^i y^i,
+//      so A_raw = U_y B with B = F T (at most nb x nb): the singular values of B ARE Eigen's, and its left singular
+//      vectors W give Eigen's in U_y coordinates.  B = diag(row scales) x (well-conditioned), the case in which
+//      one-sided Jacobi on the rows delivers even the smallest singular values to high relative accuracy
+//      (Demmel-Veselic); checked against 60-digit arithmetic for spreads 1e-2 .. 1e-8 in tests/.
+//   3. Eigen's rule: keep sigma_i > min(rows, cols) eps sigma_max.  Fitted values = A_raw V_k S_k^-1 U_k^T b
+//      = A_y F^-1 P_k z with P_k the projector on the kept left singular vectors: the coefficients in y are
+//      F^-1 P_k z -- no raw-monomial coefficient (huge, cancelling) is ever formed.
+__device__ __noinline__ void lsm_solve_centered(const double* mc, int nb, double mu, double K, double* coef, double* ws) {
+    double* G = ws;                 // [nb][nb]
+    double* Q = G + nb * nb;        // [nb][nb]
+    double* F = Q + nb * nb;        // [nb][nb]  rows: kept eigen-directions
+    double* Fi = F + nb * nb;       // [nb][nb]  F^-1: Fi[a][e]
+    double* T = Fi + nb * nb;       // [nb][nb]
+    double* B = T + nb * nb;        // [nb][nb]  rows of B are rotated in place
+    double* W = B + nb * nb;        // [nb][nb]
+    double* d = W + nb * nb;        // [nb]
+    double* z = d + nb;             // [nb]
+    double* sig = z + nb;           // [nb]
+    double* pz = sig + nb;          // [nb]
+    const double count = mc[0];
+    for (int a = 0; a < 9; ++a) coef[a] = 0.0;
+    coef[LSM_C_COUNT] = count;
+    coef[LSM_C_CENTER] = mu;
+    coef[LSM_C_REFINE] = 0.0;
+    coef[LSM_C_HINT] = 0.0;
+    if (!(count > 0.0)) return;
+    for (int a = 0; a < nb; ++a) {
+        const double g = mc[2 * a];
+        d[a] = g > 0.0 ? 1.0 / sqrt(g) : 0.0;
+    }
+    for (int a = 0; a < nb; ++a)
+        for (int b = 0; b < nb; ++b) {
+            G[a * nb + b] = mc[a + b] * d[a] * d[b];
+            Q[a * nb + b] = a == b ? 1.0 : 0.0;
+        }
+    for (int sweep = 0; sweep < 60; ++sweep) {  // cyclic Jacobi on the symmetric G
+        double off = 0.0;
+        for (int p = 0; p < nb; ++p)
+            for (int q = p + 1; q < nb; ++q) off += G[p * nb + q] * G[p * nb + q];
+        if (off < 1e-60) break;
+        for (int p = 0; p < nb - 1; ++p) {
+            for (int q = p + 1; q < nb; ++q) {
+                const double apq = G[p * nb + q];
+                if (apq == 0.0) continue;
+                const double theta = (G[q * nb + q] - G[p * nb + p]) / (2.0 * apq);
+                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double cs = 1.0 / sqrt(t * t + 1.0), sn = t * cs;
+                for (int k = 0; k < nb; ++k) {
+                    const double gkp = G[k * nb + p], gkq = G[k * nb + q];
+                    G[k * nb + p] = cs * gkp - sn * gkq;
+                    G[k * nb + q] = sn * gkp + cs * gkq;
+                }
+                for (int k = 0; k < nb; ++k) {
+                    const double gpk = G[p * nb + k], gqk = G[q * nb + k];
+                    G[p * nb + k] = cs * gpk - sn * gqk;
+                    G[q * nb + k] = sn * gpk + cs * gqk;
+                }
+                for (int k = 0; k < nb; ++k) {
+                    const double qkp = Q[k * nb + p], qkq = Q[k * nb + q];
+                    Q[k * nb + p] = cs * qkp - sn * qkq;
+                    Q[k * nb + q] = sn * qkp + cs * qkq;
+                }
+            }
+        }
+    }
+    double lmax = 0.0;
+    for (int a = 0; a < nb; ++a) lmax = fmax(lmax, G[a * nb + a]);
+    int kk = 0;  // kept eigen-directions
+    for (int e = 0; e < nb; ++e) {
+        const double lam = G[e * nb + e];
+        if (!(lam > 1e-13 * lmax)) continue;
+        const double sq = sqrt(lam);
+        double ze = 0.0;
+        for (int a = 0; a < nb; ++a) {
+            F[kk * nb + a] = d[a] > 0.0 ? sq * Q[a * nb + e] / d[a] : 0.0;
+            Fi[a * nb + kk] = d[a] * Q[a * nb + e] / sq;
+            ze += Fi[a * nb + kk] * mc[2 * nb - 1 + a];
+        }
+        z[kk] = ze;
+        ++kk;
+    }
+    if (kk == 0) return;
+    const double c0 = K * (1.0 + mu);
+    for (int k = 0; k < nb; ++k) {  // T[i][k] = C(k,i) c0^(k-i) K^i
+        double binom = 1.0;
+        for (int i = 0; i <= k; ++i) {
+            double v = binom;
+            for (int t = 0; t < k - i; ++t) v *= c0;
+            for (int t = 0; t < i; ++t) v *= K;
+            T[i * nb + k] = v;
+            binom = binom * (double)(k - i) / (double)(i + 1);
+        }
+        for (int i = k + 1; i < nb; ++i) T[i * nb + k] = 0.0;
+    }
+    for (int e = 0; e < kk; ++e)
+        for (int k = 0; k < nb; ++k) {
+            double v = 0.0;
+            for (int i = 0; i < nb; ++i) v += F[e * nb + i] * T[i * nb + k];
+            B[e * nb + k] = v;
+        }
+    for (int a = 0; a < kk; ++a)
+        for (int b = 0; b < kk; ++b) W[a * kk + b] = a == b ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 60; ++sweep) {  // one-sided Jacobi: make the rows of B orthogonal, W collects the rotations
+        double worst = 0.0;
+        for (int p = 0; p < kk - 1; ++p) {
+            for (int q = p + 1; q < kk; ++q) {
+                double a2 = 0.0, c2 = 0.0, g = 0.0;
+                for (int k = 0; k < nb; ++k) {
+                    a2 += B[p * nb + k] * B[p * nb + k];
+                    c2 += B[q * nb + k] * B[q * nb + k];
+                    g += B[p * nb + k] * B[q * nb + k];
+                }
+                const double lim = sqrt(a2 * c2);
+                if (!(fabs(g) > 1e-19 * lim)) continue;
+                worst = fmax(worst, fabs(g) / lim);
+                const double zeta = (c2 - a2) / (2.0 * g);
+                const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;
+                for (int k = 0; k < nb; ++k) {
+                    const double bp = B[p * nb + k], bq = B[q * nb + k];
+                    B[p * nb + k] = cs * bp - sn * bq;
+                    B[q * nb + k] = sn * bp + cs * bq;
+                }
+                for (int k = 0; k < kk; ++k) {
+                    const double wp = W[k * kk + p], wq = W[k * kk + q];
+                    W[k * kk + p] = cs * wp - sn * wq;
+                    W[k * kk + q] = sn * wp + cs * wq;
+                }
+            }
+        }
+        if (worst < 1e-15) break;
+    }
+    double smax = 0.0;
+    for (int e = 0; e < kk; ++e) {
+        double v = 0.0;
+        for (int k = 0; k < nb; ++k) v += B[e * nb + k] * B[e * nb + k];
+        sig[e] = sqrt(v);
+        smax = fmax(smax, sig[e]);
+    }
+    const double thr = fmin(count, (double)nb) * 2.220446049250313e-16 * smax;  // Eigen: min(rows, cols) eps sigma_max
+    for (int a = 0; a < kk; ++a) pz[a] = 0.0;
+    for (int e = 0; e < kk; ++e) {
+        if (!(sig[e] > thr)) continue;
+        double proj = 0.0;
+        for (int a = 0; a < kk; ++a) proj += W[a * kk + e] * z[a];
+        for (int a = 0; a < kk; ++a) pz[a] += proj * W[a * kk + e];
+    }
+    for (int a = 0; a < nb; ++a) {
+        double v = 0.0;
+        for (int e = 0; e < kk; ++e) v += Fi[a * nb + e] * pz[e];
+        coef[a] = v;
+    }
+}
+
+// Regression inputs about a centre (the refinement pass): the same sums as every kernel's first pass with
+// y = (S/K - 1) - mu in place of x.
+template <int NB>
+__device__ __forceinline__ void lsm_accumulate_centered(double (&m)[3 * NB - 1], bool itm, double s, double v, double invK, double mu,
+                                                        double disc) {
+    if (itm) {
+        const double yv = fma(s, invK, -1.0) - mu;
+        const double b = v * disc;
+        double pw = 1.0;
+#pragma unroll
+        for (int t = 0; t < 2 * NB - 1; ++t) {
+            m[t] += pw;
+            if (t < NB) m[2 * NB - 1 + t] = fma(pw, b, m[2 * NB - 1 + t]);
+            pw *= yv;
+        }
+    }
+}
+
+// Continuation value from a coefficient block: Horner in y = x - centre (centre = 0 exactly unless refined).
+template <int NB>
+__device__ __forceinline__ double lsm_continuation(const double (&c)[NB], double center, double x) {
+    const double y = x - center;
+    double cont = c[NB - 1];
+#pragma unroll
+    for (int t = NB - 2; t >= 0; --t) cont = fma(cont, y, c[t]);
+    return cont;
+}
+
 // run-time order -> the unrolled instance
-__device__ inline void lsm_solve_one(const double* moments, int nb, double min_count, double* coef) {
+__device__ inline void lsm_solve_one(const double* moments, int nb, double min_count, double K, double* coef) {
     switch (nb) {
-        case 1: lsm_solve_nb<1>(moments, min_count, coef); break;
-        case 2: lsm_solve_nb<2>(moments, min_count, coef); break;
-        case 3: lsm_solve_nb<3>(moments, min_count, coef); break;
-        case 4: lsm_solve_nb<4>(moments, min_count, coef); break;
-        case 5: lsm_solve_nb<5>(moments, min_count, coef); break;
-        case 6: lsm_solve_nb<6>(moments, min_count, coef); break;
-        case 7: lsm_solve_nb<7>(moments, min_count, coef); break;
-        case 8: lsm_solve_nb<8>(moments, min_count, coef); break;
-        default: lsm_solve_nb<9>(moments, min_count, coef); break;
+        case 1: lsm_solve_nb<1>(moments, min_count, K, coef); break;
+        case 2: lsm_solve_nb<2>(moments, min_count, K, coef); break;
+        case 3: lsm_solve_nb<3>(moments, min_count, K, coef); break;
+        case 4: lsm_solve_nb<4>(moments, min_count, K, coef); break;
+        case 5: lsm_solve_nb<5>(moments, min_count, K, coef); break;
+        case 6: lsm_solve_nb<6>(moments, min_count, K, coef); break;
+        case 7: lsm_solve_nb<7>(moments, min_count, K, coef); break;
+        case 8: lsm_solve_nb<8>(moments, min_count, K, coef); break;
+        default: lsm_solve_nb<9>(moments, min_count, K, coef); break;
     }
 }
 
@@ -136,6 +370,7 @@ __device__ __forceinline__ void lsm_small_body(const double* data, int64_t ld, i
     __shared__ double red[NM * 4];
     __shared__ double sm_mom[32];
     __shared__ double sm_coef[16];
+    __shared__ double sm_ws[lsm_ws_doubles(NB)];
     const bool call = is_call != 0;
     const double invK = 1.0 / K;
     double V[PPT];
@@ -177,23 +412,34 @@ __device__ __forceinline__ void lsm_small_body(const double* data, int64_t ld, i
         if (threadIdx.x == 0) {
 #pragma unroll
             for (int t = 0; t < NM; ++t) sm_mom[t] = m[t];
-            lsm_solve_nb<NB>(sm_mom, 1.0, sm_coef);  // writes sm_coef[0..9], [9] = ITM count
+            lsm_solve_nb<NB>(sm_mom, 1.0, K, sm_coef);  // writes the coefficient block (lsm_device.hpp: LSM_C_*)
         }
         __syncthreads();
+        if (sm_coef[LSM_C_REFINE] != 0.0) {  // uniform: the date is re-fitted about the mean (see lsm_solve_nb)
+            const double mu = sm_coef[LSM_C_HINT];
+#pragma unroll
+            for (int q = 0; q < NM; ++q) m[q] = 0.0;
+#pragma unroll
+            for (int q = 0; q < PPT; ++q)
+                lsm_accumulate_centered<NB>(m, threadIdx.x + 256 * q < n && pay_j[q] > 1e-14, s_j[q], V[q], invK, mu, disc);
+            block_sum<NM, 4>(m, red);
+            if (threadIdx.x == 0) {
+#pragma unroll
+                for (int t = 0; t < NM; ++t) sm_mom[t] = m[t];
+                lsm_solve_centered(sm_mom, NB, mu, K, sm_coef, sm_ws);
+            }
+            __syncthreads();
+        }
         double c[NB];
 #pragma unroll
         for (int t = 0; t < NB; ++t) c[t] = sm_coef[t];
-        const double n_itm = sm_coef[9];
+        const double n_itm = sm_coef[LSM_C_COUNT], center = sm_coef[LSM_C_CENTER];
 #pragma unroll
         for (int q = 0; q < PPT; ++q) {
             const double vn = V[q] * disc;
             double v;
             if (pay_j[q] > 1e-14 && n_itm > 0.0) {
-                const double x = fma(s_j[q], invK, -1.0);
-                double cont = c[NB - 1];
-#pragma unroll
-                for (int t = NB - 2; t >= 0; --t) cont = fma(cont, x, c[t]);
-                v = fmax(pay_j[q], cont);
+                v = fmax(pay_j[q], lsm_continuation<NB>(c, center, fma(s_j[q], invK, -1.0)));
             } else if (pay_j[q] < 1e-14) {
                 v = vn;
             } else {
@@ -227,7 +473,9 @@ __device__ __forceinline__ void lsm_small_body(const double* data, int64_t ld, i
 // four times the throughput of lsm_small_body on the batched driver rows.  sum_v, sum_v2: sums of V and V^2 (all lanes).
 template <int NB>
 __device__ __forceinline__ void lsm_wave_body(const double* data, int64_t ld, int n, int n_cols, double K, double maturity,
-                                              double dt, double disc, int is_call, double& sum_v, double& sum_v2) {
+                                              double dt, double disc, int is_call, double* ws /* LDS, this wave's own:
+                                              lsm_ws_doubles(NB) + LSM_COEF_DOUBLES doubles */,
+                                              double& sum_v, double& sum_v2) {
     constexpr int NM = 3 * NB - 1;
     const int lane = threadIdx.x & 63;
     const bool call = is_call != 0;
@@ -267,20 +515,38 @@ __device__ __forceinline__ void lsm_wave_body(const double* data, int64_t ld, in
         }
 #pragma unroll
         for (int t = 0; t < NM; ++t) m[t] = wave_sum(m[t]);
-        double coef[10];
-        lsm_solve_nb<NB>(m, 1.0, coef);  // identical in every lane
-        const double n_itm = coef[9];
+        double coef[LSM_COEF_DOUBLES];
+        lsm_solve_nb<NB>(m, 1.0, K, coef);  // identical in every lane
+        if (coef[LSM_C_REFINE] != 0.0) {    // wave-uniform: re-fit about the mean (see lsm_solve_nb)
+            const double mu = coef[LSM_C_HINT];
+            double mc[NM];
+#pragma unroll
+            for (int t = 0; t < NM; ++t) mc[t] = 0.0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                lsm_accumulate_centered<NB>(mc, lane + 64 * q < n && payoff_of(call, s_j[q], K) > 1e-14, s_j[q], V[q], invK, mu,
+                                            disc);
+#pragma unroll
+            for (int t = 0; t < NM; ++t) mc[t] = wave_sum(mc[t]);
+            double* ws_coef = ws + lsm_ws_doubles(NB);
+            if (lane == 0) lsm_solve_centered(mc, NB, mu, K, ws_coef, ws);
+            // one wave: its LDS operations execute in program order, so the reads below see lane 0's result
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int t = 0; t < LSM_COEF_DOUBLES; ++t) coef[t] = ws_coef[t];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // read out before the next refined date overwrites it
+        }
+        const double n_itm = coef[LSM_C_COUNT], center = coef[LSM_C_CENTER];
+        double c[NB];
+#pragma unroll
+        for (int t = 0; t < NB; ++t) c[t] = coef[t];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const double pay = payoff_of(call, s_j[q], K);
             const double vn = V[q] * disc;
             double v;
             if (pay > 1e-14 && n_itm > 0.0) {
-                const double x = fma(s_j[q], invK, -1.0);
-                double cont = coef[NB - 1];
-#pragma unroll
-                for (int t = NB - 2; t >= 0; --t) cont = fma(cont, x, coef[t]);
-                v = fmax(pay, cont);
+                v = fmax(pay, lsm_continuation<NB>(c, center, fma(s_j[q], invK, -1.0)));
             } else if (pay < 1e-14) {
                 v = vn;
             } else {

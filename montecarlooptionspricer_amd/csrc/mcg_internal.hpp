@@ -95,7 +95,7 @@ constexpr int SCALARS_DOUBLES = 256;
 // layout of ctx->scalars (doubles)
 constexpr int SC_SUMS = 0;     // [0..3)  sum, sumsq, n
 constexpr int SC_MOMENTS = 8;  // [8..8+26) LSM moments (<= 3*8+2)
-constexpr int SC_COEF = 40;    // [40..40+9) LSM coefficients, [49] = regress flag
+constexpr int SC_COEF = 40;    // [40..53) the LSM coefficient block of the current date (lsm_device.hpp: LSM_C_*)
 constexpr int SC_FINAL = 64;   // [64..67) LSM final sums
 constexpr int SC_BARRIER = 72; // [72] 32-bit timeout flag of k_lsm_coop's hand-shake
 
@@ -127,7 +127,10 @@ int finish_sums(mcg_ctx* ctx, int64_t n_blocks, int64_t n_local, double out3[3])
 int run_lsm(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double maturity, double dt, int is_call,
             int poly_order, double* mean, double* std_err);
 
-int lsm_reduce_allreduce_solve(mcg_ctx* ctx, int grid, int nm, int nb, double min_count);
+// refine_row == nullptr: the caller's moments are never re-fitted (MartingaleOptimization's refit)
+int lsm_reduce_allreduce_solve(mcg_ctx* ctx, int grid, int nm, int nb, double min_count, const double* refine_row = nullptr,
+                               const double* refine_v = nullptr, int64_t refine_n = 0, double K = 0.0, double disc = 1.0,
+                               int is_call = 0);
 int run_martingale(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double maturity, double dt, int is_call,
                    int poly_order, int max_iterations, double* price, double* lower, double* upper);
 int run_branching(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double maturity, double dt, int is_call,

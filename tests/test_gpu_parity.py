@@ -340,6 +340,104 @@ def test_lsm_edge_cases_match_oracle(eng, orc):
         eng.price_lsm(P, 0.04, 100.0, 1.0, 0.1, False, 9)
 
 
+def _near_degenerate_matrix(rs, n_total, n_itm, base, spread, K=100.0):
+    """[n_total][3] price matrix (path-major): at the middle date exactly n_itm paths are in the money for a put, within
+    a relative spread `spread` of `base`; everything else stays out of the money there.  Column 0 is out of the money
+    too (no regression at j = 0), the last column gives every path its own terminal payoff."""
+    m = np.empty((n_total, 3))
+    m[:, 0] = 1.05 * K
+    m[:, 1] = K * (1.02 + 0.2 * rs.rand(n_total))
+    m[:, 2] = K * (0.7 + 0.5 * rs.rand(n_total))
+    idx = rs.choice(n_total, n_itm, replace=False)
+    m[idx, 1] = base * (1.0 + spread * rs.uniform(-1.0, 1.0, n_itm))
+    return m
+
+
+@pytest.mark.parametrize("n_total", [40, 600, 5000])
+def test_lsm_near_degenerate_itm_sets_follow_the_reference_rank_rule(eng, orc, n_total):
+    """The reference solves every date by Eigen's bdcSvd on raw monomials of S with its default rank threshold
+    min(rows, cols) eps sigma_max (LSMPricer.cpp:76).  Dates whose in-the-money prices nearly coincide sit where that rule
+    decides the fit: full rank down to a relative spread of about 1e-5 (the interpolating / least-squares quadratic),
+    rank 2 below it.  The device has to follow it through every execution shape: one wavefront (<= 256 paths), one
+    workgroup (<= 1024), the one-launch sweep, and -- with a collective installed -- the per-date kernels, which re-fit
+    such a date inside the solve kernel.  Tolerance 1e-6 relative on the price: the reference-side solve itself is only
+    defined to eps x cond(A) ~ 1e-16 x 1e10 there (oracle vs 60-digit arithmetic: tests/test_oracle_models.py)."""
+    rs = np.random.RandomState(11)
+    worst = 0.0
+    for base in (90.0, 99.9, 60.0):
+        for n_itm in (2, 3, 4, 5):
+            for spread in (1e-3, 1e-4, 1e-5, 1e-6, 1e-7):
+                m = _near_degenerate_matrix(rs, n_total, n_itm, base, spread)
+                P = eng.from_host(m)
+                got, _ = eng.price_lsm(P, 0.04, 100.0, 1.0, 0.5, False, 2)
+                P.free()
+                want = orc.lsm_price(m, 0.04, 100.0, 1.0, 0.5, False, 2, step_major=False)
+                err = abs(got - want) / abs(want)
+                worst = max(worst, err)
+                assert err <= 1e-6, (n_total, base, n_itm, spread, got, want)
+    # the same through the per-date kernels (a collective, here the identity, selects them)
+    other = mc.PathEngine(0)
+    try:
+        other.set_allreduce(lambda ptr, count, stream: None)
+        m = _near_degenerate_matrix(rs, n_total, 3, 90.0, 1e-4)
+        P = eng.from_host(m)
+        Q = other.from_host(m)
+        a = eng.price_lsm(P, 0.04, 100.0, 1.0, 0.5, False, 2)[0]
+        b = other.price_lsm(Q, 0.04, 100.0, 1.0, 0.5, False, 2)[0]
+        P.free()
+        Q.free()
+        # sharded runs do not refine (documented in lsm_device.hpp): only finite and close to the discounted payoffs
+        assert math.isfinite(b) and abs(a - b) <= 0.05 * abs(a)
+    finally:
+        other.close()
+
+
+def test_lsm_near_degenerate_large_shards(eng, orc):
+    """The same rank rule in the one-launch sweeps for big shards (16 and 32-64 paths per thread) and in the per-date
+    kernels WITHOUT a collective (forced by switching the one-launch sweep off), on 2.2M paths."""
+    rs = np.random.RandomState(12)
+    n_total = 2_200_000
+    for base, n_itm, spread in ((90.0, 3, 1e-4), (99.9, 5, 1e-6), (60.0, 4, 1e-3)):
+        m = _near_degenerate_matrix(rs, n_total, n_itm, base, spread)
+        want = orc.lsm_price(m, 0.04, 100.0, 1.0, 0.5, False, 2, step_major=False)
+        P = eng.from_host(m)
+        got = eng.price_lsm(P, 0.04, 100.0, 1.0, 0.5, False, 2)[0]
+        P.free()
+        assert abs(got - want) <= 1e-6 * abs(want), ("one launch", base, n_itm, spread, got, want)
+    big = _near_degenerate_matrix(rs, 5_000_000, 4, 90.0, 1e-5)          # 64 paths per thread
+    want_big = orc.lsm_price(big, 0.04, 100.0, 1.0, 0.5, False, 2, step_major=False)
+    P = eng.from_host(big)
+    got = eng.price_lsm(P, 0.04, 100.0, 1.0, 0.5, False, 2)[0]
+    P.free()
+    assert abs(got - want_big) <= 1e-6 * abs(want_big), ("one launch, 5M", got, want_big)
+    import os
+    e = mc.PathEngine(0)
+    os.environ["MCG_LSM_SPIN_LIMIT"] = "0"                    # first call times out -> per-date kernels from then on
+    try:
+        P = e.from_host(m)
+        got = e.price_lsm(P, 0.04, 100.0, 1.0, 0.5, False, 2)[0]
+        assert not e.lsm_one_launch_enabled()
+        assert abs(got - want) <= 1e-6 * abs(want), ("per-date", got, want)
+        P.free()
+    finally:
+        del os.environ["MCG_LSM_SPIN_LIMIT"]
+        e.close()
+
+
+@pytest.mark.parametrize("poly", [4, 5, 6, 8])
+def test_lsm_high_orders_follow_the_reference_rank_rule(eng, orc, poly):
+    """Raw monomials up to S^8 at S ~ 100 span sixteen orders of magnitude: Eigen's threshold truncates them on EVERY date
+    (the fitted polynomial is not the degree-p least-squares fit any more but its projection on the leading singular
+    directions).  The device recognises these dates (lsm_solve_nb's estimate) and reproduces the truncated solve."""
+    n, steps, dt = 3000, 12, 1.0 / 12
+    P = eng.gbm(SEED + 5, 100.0, 0.04, 0.3, dt, steps, n)
+    host = P.to_host_step_major()
+    got, _ = eng.price_lsm(P, 0.04, 100.0, 1.0, dt, False, poly)
+    P.free()
+    want = orc.lsm_price(host, 0.04, 100.0, 1.0, dt, False, poly)
+    assert abs(got - want) <= 2e-6 * abs(want), (poly, got, want)
+
+
 def test_from_host_roundtrip_is_exact(eng):
     rs = np.random.RandomState(0)
     a = rs.rand(777, 13) * 100

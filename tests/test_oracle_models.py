@@ -240,6 +240,45 @@ def lsm_numpy(paths_pm, r, K, maturity, dt, is_call, poly):
     return V.mean()
 
 
+def _exact_eigen_rule_fit(S, b, p):
+    """Eigen's bdcSvd().solve(b) on raw monomials of S (LSMPricer.cpp:61-76) in 60-digit arithmetic: minimum-norm least
+    squares with singular values <= min(rows, cols) eps sigma_max dropped.  Returns the fitted values at the data."""
+    import mpmath as mp
+    mp.mp.dps = 60
+    n = len(S)
+    A = mp.matrix(n, p + 1)
+    for i in range(n):
+        for k in range(p + 1):
+            A[i, k] = mp.mpf(float(S[i])) ** k
+    U, sv, V = mp.svd_r(A, full_matrices=False, compute_uv=True)
+    thr = min(n, p + 1) * mp.mpf(np.finfo(float).eps) * sv[0]
+    coef = mp.matrix(p + 1, 1)
+    for j in range(len(sv)):
+        if sv[j] > thr:
+            proj = sum(U[i, j] * mp.mpf(float(b[i])) for i in range(n)) / sv[j]
+            for t in range(p + 1):
+                coef[t] += proj * V[j, t]
+    fit = A * coef
+    return np.array([float(fit[i]) for i in range(n)])
+
+
+def test_lsm_oracle_rank_rule_on_near_degenerate_dates_vs_exact_arithmetic(orc):
+    """The oracle's least-squares solve (one-sided Jacobi SVD, Eigen's default threshold) on dates whose in-the-money
+    prices nearly coincide, against the same rule evaluated in 60-digit arithmetic: two-date matrices whose single
+    regression is the system under test (r = 0, terminal payoff K - S_1 chosen to be the right-hand side b)."""
+    rs = np.random.RandomState(1)
+    K = 100.0
+    for base in (90.0, 99.0, 60.0):
+        for n in (2, 3, 4, 5):
+            for spread in (1e-3, 1e-4, 1e-5, 1e-6, 1e-7):
+                S = base * (1 + spread * rs.uniform(-1, 1, n))
+                b = rs.uniform(45.0, 60.0, n)                      # above every immediate payoff: V_0 = fitted value
+                fit = _exact_eigen_rule_fit(S, b, 2)
+                _, v0 = orc.lsm_price(np.stack([S, K - b]), 0.0, K, 1.0, 1.0, False, 2, want_v0=True)
+                want = np.maximum(K - S, fit)
+                assert np.max(np.abs(v0 - want) / np.abs(want)) <= 2e-5, (base, n, spread, v0, want)
+
+
 @pytest.mark.parametrize("is_call,poly", [(False, 2), (True, 2), (False, 3), (False, 0)])
 def test_lsm_oracle_vs_lapack(orc, is_call, poly):
     n, steps, dt = 4000, 50, 0.02
