@@ -99,6 +99,63 @@ __device__ __forceinline__ double exp_full(double a) {
     return __builtin_ldexp(1.0 + em1, (int)kd);
 }
 
+// ---- two arguments at a time ---------------------------------------------------------------------------------
+// The rBergomi kernels run at two to three waves per SIMD, where a chain of dependent fp64 FMAs (issue 4 cycles,
+// result later) leaves issue slots empty, and hipcc schedules an asm FMA as an opaque unit: it neither interleaves two
+// such chains nor drops the s_nop it puts behind each.  The kernels handle two paths per lane, so every polynomial
+// exists twice: one asm block advances both chains by a step.
+__device__ __forceinline__ void horner2(double& qa, double& qb, double ra, double rb, double C) {
+    asm("v_fma_f64 %0, %0, %2, %4\n\tv_fma_f64 %1, %1, %3, %4" : "+v"(qa), "+v"(qb) : "v"(ra), "v"(rb), "s"(C));
+}
+
+// e^a, e^b (exp_full twice, interleaved)
+__device__ __forceinline__ void exp_full2(double a, double b, double& ea, double& eb) {
+    const double ka = __builtin_rint(a * 0x1.71547652b82fep+0), kb = __builtin_rint(b * 0x1.71547652b82fep+0);
+    double ra = __builtin_fma(ka, -0x1.62e42fee00000p-1, a), rb = __builtin_fma(kb, -0x1.62e42fee00000p-1, b);
+    ra = __builtin_fma(ka, -0x1.a39ef35793c76p-33, ra);
+    rb = __builtin_fma(kb, -0x1.a39ef35793c76p-33, rb);
+    double qa = 0x1.af38a9b0ec855p-26, qb = 0x1.af38a9b0ec855p-26;
+    horner2(qa, qb, ra, rb, 0x1.289185613a3d6p-22);
+    horner2(qa, qb, ra, rb, 0x1.71de0dae63bb3p-19);
+    horner2(qa, qb, ra, rb, 0x1.a019b90d2ae7ap-16);
+    horner2(qa, qb, ra, rb, 0x1.a01a01a7c41d5p-13);
+    horner2(qa, qb, ra, rb, 0x1.6c16c1788bd90p-10);
+    horner2(qa, qb, ra, rb, 0x1.11111111109b3p-7);
+    horner2(qa, qb, ra, rb, 0x1.5555555553d63p-5);
+    horner2(qa, qb, ra, rb, 0x1.5555555555556p-3);
+    horner2(qa, qb, ra, rb, 0x1.0000000000001p-1);
+    ea = __builtin_ldexp(1.0 + __builtin_fma(ra * ra, qa, ra), (int)ka);
+    eb = __builtin_ldexp(1.0 + __builtin_fma(rb * rb, qb, rb), (int)kb);
+}
+
+// e^a - 1, e^b - 1 for |a|, |b| <= 0.1 (the polynomial of scaled_exp_small6) and for <= 0.34 (that of scaled_exp
+// without its range reduction): a price step's exponent, whose size the caller has tested for the whole wave.
+__device__ __forceinline__ void expm1_small6_2(double a, double b, double& ea, double& eb) {
+    double qa = 0x1.a02eb88e6a6ffp-16, qb = 0x1.a02eb88e6a6ffp-16;
+    horner2(qa, qb, a, b, 0x1.a033e66a22569p-13);
+    horner2(qa, qb, a, b, 0x1.6c16c10206fa6p-10);
+    horner2(qa, qb, a, b, 0x1.1111108c7c825p-7);
+    horner2(qa, qb, a, b, 0x1.555555555664ep-5);
+    horner2(qa, qb, a, b, 0x1.5555555557fc2p-3);
+    horner2(qa, qb, a, b, 0x1.0000000000000p-1);
+    ea = __builtin_fma(a * a, qa, a);
+    eb = __builtin_fma(b * b, qb, b);
+}
+__device__ __forceinline__ void expm1_small9_2(double a, double b, double& ea, double& eb) {
+    double qa = 0x1.af38a9b0ec855p-26, qb = 0x1.af38a9b0ec855p-26;
+    horner2(qa, qb, a, b, 0x1.289185613a3d6p-22);
+    horner2(qa, qb, a, b, 0x1.71de0dae63bb3p-19);
+    horner2(qa, qb, a, b, 0x1.a019b90d2ae7ap-16);
+    horner2(qa, qb, a, b, 0x1.a01a01a7c41d5p-13);
+    horner2(qa, qb, a, b, 0x1.6c16c1788bd90p-10);
+    horner2(qa, qb, a, b, 0x1.11111111109b3p-7);
+    horner2(qa, qb, a, b, 0x1.5555555553d63p-5);
+    horner2(qa, qb, a, b, 0x1.5555555555556p-3);
+    horner2(qa, qb, a, b, 0x1.0000000000001p-1);
+    ea = __builtin_fma(a * a, qa, a);
+    eb = __builtin_fma(b * b, qb, b);
+}
+
 // S * e^a for |a| <= 0.125, guaranteed by the caller from the step's parameters (a GBM step has
 // |a| <= |drift| + vol * 7.55: the 40-bit radius uniform caps |z| at sqrt(2*41*ln2) = 7.54).  No range
 // reduction, no branch; e^a = 1 + a + a^2 q(a) with q of degree 7 (max rel err 2^-58.7 on the interval).

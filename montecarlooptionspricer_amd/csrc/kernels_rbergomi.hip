@@ -11,13 +11,13 @@
 namespace mcg {
 
 template <bool PAYOFF>
-__device__ __forceinline__ void rb_finish(const RbArgs& a, double log_a, double log_b, bool live_a, bool live_b,
+__device__ __forceinline__ void rb_finish(const RbArgs& a, double end_a, double end_b, bool live_a, bool live_b,
                                           bool lead) {
     if (PAYOFF) {
         __shared__ double red[2 * 4];
         const bool call = a.is_call != 0;
-        const double pay_a = (lead && live_a) ? payoff_of(call, fm::scaled_exp(1.0, log_a), a.K) : 0.0;
-        const double pay_b = (lead && live_b) ? payoff_of(call, fm::scaled_exp(1.0, log_b), a.K) : 0.0;
+        const double pay_a = (lead && live_a) ? payoff_of(call, end_a, a.K) : 0.0;
+        const double pay_b = (lead && live_b) ? payoff_of(call, end_b, a.K) : 0.0;
         double v[2] = {pay_a + pay_b, pay_a * pay_a + pay_b * pay_b};
         block_sum<2, 4>(v, red);
         if (threadIdx.x == 0) {
@@ -30,6 +30,8 @@ __device__ __forceinline__ void rb_finish(const RbArgs& a, double log_a, double 
 #ifndef RB_WAVES
 #define RB_WAVES 2
 #endif
+// Two waves per SIMD: the kernel wants ~230 VGPRs (64 of them the transform); held to the 168 of three waves -- which
+// LDS would admit up to Mz = 256 -- it spills ~60 of them into its loops and is slower (-DRB_WAVES=3 to try).
 template <int LG, int LT, bool PAYOFF>
 __global__ __launch_bounds__(256, RB_WAVES) void k_rbergomi_fft(RbArgs a) {
     extern __shared__ double smem[];

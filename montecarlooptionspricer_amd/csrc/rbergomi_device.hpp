@@ -10,17 +10,17 @@
 // amplitudes a_k of host/volterra.cpp and Y_k = a_k (g_k + i h_k),
 //   x_n = sum_{k<Mz} Y_k e^{+2 pi i k n/Mz},   X(path 2q) = Re x,  X(path 2q+1) = Im x
 // (two independent copies of the reference's X).  The transform is an in-register radix-2
-// decimation-in-time FFT of length Mz = 32 G spread over G lanes (32 complex points per lane): the
-// spectrum is drawn directly in bit-reversed order (each lane's 32 inputs are four runs of 8 consecutive k,
-// i.e. 16 Philox blocks with no draw wasted), the 2 lowest and 3 highest index bits are butterflies between
-// registers, the log2(G) middle bits are butterflies between lanes (wavefront shuffles), twiddles come
-// from an LDS table.  O(Mz log Mz) instead of the O(Mz steps) contraction of the Volterra form (which ran at the
+// decimation-in-time FFT of length Mz = 16 G spread over G lanes (16 complex points per lane; 32 only at
+// Mz = 2048): the spectrum is drawn directly in bit-reversed order (each lane's 16 inputs are four runs of 4
+// consecutive k, i.e. 8 Philox blocks with no draw wasted), the 2 lowest and 2 (3) highest index bits are
+// butterflies between registers, the log2(G) middle bits are butterflies between lanes (DPP moves and
+// v_permlane16/32_swap, no LDS), twiddles come from an LDS table.  O(Mz log Mz) instead of the O(Mz steps) contraction of the Volterra form (which ran at the
 // fp64-FMA roofline on MFMA in an earlier version of this file: 64 cycles per v_mfma_f64_16x16x4_f64 and no
 // overlap with fp64 VALU work on gfx950, tools/ubench_mfma_f64.hip).
-// The natural-order output leaves lane g of a pair with steps n = 4(tG + g) + v (t = 0..7, v = 0..3): four
-// CONSECUTIVE steps per 4G-step tile.  The price then advances in log space: in-lane 4-prefix, wavefront-
-// shuffle scan over the G lanes, S = exp(.), and each lane stores {S(path 2q), S(path 2q+1)} as one 16-byte
-// store (lanes of equal g cover 64/G pairs = a contiguous (64/G)*16-byte run of the step-major row).
+// The natural-order output leaves lane g of a pair with steps n = 4(tG + g) + v (t = 0..3, v = 0..3): four
+// CONSECUTIVE steps per 4G-step tile.  The price then advances as a product: step factors from a short
+// polynomial, in-lane running products, an exclusive product scan over the G lanes, and the tile's rows are
+// staged through LDS so that they leave as (pairs x 16)-byte runs of the step-major row.
 #pragma once
 #include <type_traits>
 #include "devmath.hpp"
@@ -181,11 +181,11 @@ __device__ __forceinline__ constexpr int rb_rev(int t) {
 }
 
 // One workgroup's share: 4 waves x (64 >> LG) path pairs, 4 * 2^LT transform points per lane
-// (Mz = 2^(2 + LG + LT)).  Returns through log_a/log_b the final log-prices of this lane's pair;
+// (Mz = 2^(2 + LG + LT)).  Returns through end_a/end_b the final prices S_T of this lane's pair (the stored values);
 // lead = this lane is the one lane (g == 0) that reports the pair's payoff.
 template <int LG, int LT>
 __device__ __forceinline__ void rb_generate_fft(const RbArgs& a, int64_t block_index, double* smem, fm::Tables* tabs,
-                                                double& log_a, double& log_b, bool& live_a, bool& live_b, bool& lead) {
+                                                double& end_a, double& end_b, bool& live_a, bool& live_b, bool& lead) {
     constexpr int G = 1 << LG;   // lanes per pair
     constexpr int P = 64 >> LG;  // pairs per wave
     constexpr int NT = 1 << LT;  // 4-step tiles per lane
@@ -327,10 +327,19 @@ __device__ __forceinline__ void rb_generate_fft(const RbArgs& a, int64_t block_i
     // now xr/xi[t*4+v] = Re/Im x_n, n = 4(tG + g) + v
 
     // ---- price stepping, two paths per lane ----
+    // S advances as a product.  A lane holds four consecutive steps of its two paths: the step factors e^inc come from
+    // a short polynomial without range reduction (|inc| is tested for the whole wave: a price step's exponent is a few
+    // per cent), their running products p_v are formed in the lane, an exclusive product scan over the G lanes of the
+    // pair gives the lane's lead, and S = (S_tile * lead) * p_v.  The next tile starts from the STORED value of this
+    // tile's last step (broadcast from the last lane), so the sequence of stored prices is exactly a chain of
+    // multiplications like the reference's S_j = S_{j-1} exp(.) (:363), only associated differently within a tile.
     lead = g == 0;
     double* col = a.out + col_a;
-    if (lead) rb_store_pair(col, a.S0, a.S0, live_a, live_b);
-    double ls_a = a.logS0, ls_b = a.logS0;
+    if (lead) rb_store_pair(col, a.S0, a.S0, true, true);
+    double S_a = a.S0, S_b = a.S0;  // price at the start of the tile (the same bits in every lane of the pair)
+    // this thread's part of every tile's write-out: rows wr_row + i G (i < 4) of the tile, pair wr_pc of the workgroup
+    const int wr_row = (int)threadIdx.x / PW, wr_pc = (int)threadIdx.x % PW;
+    double* wr_out = a.out + 2 * (block_index * PW + wr_pc) + (int64_t)(wr_row + 1) * a.ld;
     const double sq_xi_dt = sqrt(a.xi) * a.sqdt;  // sqrt(xi dt)
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -340,65 +349,113 @@ __device__ __forceinline__ void rb_generate_fft(const RbArgs& a, int64_t block_i
             double za[4], zb[4];  // steps nl..nl+3 are Philox block nl/4 of each path's price stream
             fm::normal_quad_fast(a.k0, a.k1, id_a, (uint32_t)(nl >> 2), STREAM_PRICE, tabs, za);
             fm::normal_quad_fast(a.k0, a.k1, id_b, (uint32_t)(nl >> 2), STREAM_PRICE, tabs, zb);
-            double pa[4], pb[4], run_a = 0.0, run_b = 0.0;
+            double ia[4], ib[4], big = 0.0;
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 const int n = nl + v;
                 const bool valid = n < a.n_steps;
                 const double cmp = valid ? L.comp[n] : 0.0;
                 // sqrt(v) = sqrt(xi) e^{(X + comp)/2}: one exponential gives both v and sqrt(v dt)
-                const double ea = fm::exp_full(0.5 * (xr[t * 4 + v] + cmp)), eb = fm::exp_full(0.5 * (xi[t * 4 + v] + cmp));
+                double ea, eb;
+                fm::exp_full2(0.5 * (xr[t * 4 + v] + cmp), 0.5 * (xi[t * 4 + v] + cmp), ea, eb);
                 const double var_a = a.xi * (ea * ea), var_b = a.xi * (eb * eb);
                 const double inc_a = fma(sq_xi_dt * ea, za[v], (a.r - 0.5 * var_a) * a.dt);
                 const double inc_b = fma(sq_xi_dt * eb, zb[v], (a.r - 0.5 * var_b) * a.dt);
-                run_a += valid ? inc_a : 0.0;
-                run_b += valid ? inc_b : 0.0;
-                pa[v] = run_a;
-                pb[v] = run_b;
+                ia[v] = valid ? inc_a : 0.0;  // a step beyond the grid multiplies by exactly 1
+                ib[v] = valid ? inc_b : 0.0;
+                big = fmax(big, fmax(fabs(ia[v]), fabs(ib[v])));
+                __builtin_amdgcn_sched_barrier(0);  // one step's pair of chains at a time: more of them cost registers, not time
             }
-            // inclusive scan of the lane totals over g = 0..G-1 (lanes c, c+P, c+2P, ...)
-            double inc_a = run_a, inc_b = run_b;
+            // e^inc - 1 by the shortest polynomial the wave's largest exponent allows, then the running products
+            // p_v = prod_{u <= v} e^{inc_u} (in place: ia/ib end up holding them)
+            if (__builtin_amdgcn_ballot_w64(big > fm::SMALL6_EXP_BOUND) == 0ull) {
 #pragma unroll
-            for (int b = 0; b < LG; ++b) {
-                const double ua = __shfl_up(inc_a, P << b, 64), ub = __shfl_up(inc_b, P << b, 64);
-                if (g >= (1 << b)) {
-                    inc_a += ua;
-                    inc_b += ub;
+                for (int v = 0; v < 4; ++v) {
+                    fm::expm1_small6_2(ia[v], ib[v], ia[v], ib[v]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else if (__builtin_amdgcn_ballot_w64(big > 0.34) == 0ull) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    fm::expm1_small9_2(ia[v], ib[v], ia[v], ib[v]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    double ea, eb;
+                    fm::exp_full2(ia[v], ib[v], ea, eb);
+                    ia[v] = ea - 1.0;  // (absolute error 1e-16: what the product below needs)
+                    ib[v] = eb - 1.0;
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            const double lead_a = ls_a + (inc_a - run_a), lead_b = ls_b + (inc_b - run_b);
-            const double tot_a = __shfl(inc_a, (G - 1) * P + c, 64), tot_b = __shfl(inc_b, (G - 1) * P + c, 64);
+            double (&pa)[4] = ia, (&pb)[4] = ib;
+            pa[0] = 1.0 + ia[0];
+            pb[0] = 1.0 + ib[0];
+#pragma unroll
+            for (int v = 1; v < 4; ++v) {
+                pa[v] = fma(pa[v - 1], ia[v], pa[v - 1]);
+                pb[v] = fma(pb[v - 1], ib[v], pb[v - 1]);
+            }
+            // exclusive product scan of the lane totals over g = 0..G-1 (lanes c, c+P, c+2P, ...)
+            double la = __shfl_up(pa[3], P, 64), lb = __shfl_up(pb[3], P, 64);
+            if (g == 0) {
+                la = 1.0;
+                lb = 1.0;
+            }
+#pragma unroll
+            for (int b = 0; b < LG; ++b) {
+                const double ua = __shfl_up(la, P << b, 64), ub = __shfl_up(lb, P << b, 64);
+                if (g > (1 << b)) {  // (lane g = 2^b would multiply by lane 0's lead, which is 1)
+                    la *= ua;
+                    lb *= ub;
+                }
+            }
+            const double base_a = S_a * la, base_b = S_b * lb;
+            double last_a = 0.0, last_b = 0.0;
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
-                const double sa = fm::exp_full(lead_a + pa[v]);
-                const double sb = fm::exp_full(lead_b + pb[v]);
-                stage[(4 * g + v) * RS + wave * P + c] = make_double2(sa, sb);
+                last_a = base_a * pa[v];
+                last_b = base_b * pb[v];
+                stage[(4 * g + v) * RS + wave * P + c] = make_double2(last_a, last_b);
             }
-            ls_a += tot_a;
-            ls_b += tot_b;
+            S_a = __shfl(last_a, (G - 1) * P + c, 64);
+            S_b = __shfl(last_b, (G - 1) * P + c, 64);
             __syncthreads();
-            // write-out: the tile is 4G rows x PW pairs = 1024 16-byte units, four per thread; a wavefront store
-            // covers 64 / PW complete rows of PW * 16 contiguous bytes
+            // write-out: the tile is 4G rows x PW pairs = 1024 16-byte units, four per thread (rows wr_row + i G); a
+            // wavefront store covers 64 / PW complete rows of PW * 16 contiguous bytes.  Columns are never masked: rows
+            // are padded to 256 columns and a workgroup's 2 PW columns divide that, so the columns behind n_paths
+            // exist (scratch, never read back) -- like the GBM generator's unconditional stores.
+            {
+                const double2* sbuf = static_cast<const double2*>(__builtin_assume_aligned(stage, 16));
+                double* tile_out = wr_out + (int64_t)t * (4 * G) * a.ld;
+                double2 sv[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int u = i * 256 + (int)threadIdx.x;
-                const int row = u / PW, pc = u % PW;
-                const int n = ((t * G) << 2) + row;
-                const int64_t colp = 2 * (block_index * PW + pc);
-                const double2 sv = stage[row * RS + pc];
-                if (n < a.n_steps)
-                    rb_store_pair(a.out + colp + (int64_t)(n + 1) * a.ld, sv.x, sv.y, colp < a.n_paths, colp + 1 < a.n_paths);
+                for (int i = 0; i < 4; ++i) {  // all four LDS reads in flight before the first store waits for one
+                    sv[i] = sbuf[(wr_row + i * G) * RS + wr_pc];
+                    asm volatile("" : "+v"(sv[i].x), "+v"(sv[i].y));
+                }
+                if ((((t + 1) * G) << 2) <= a.n_steps) {  // wave-uniform: every row of the tile is a step of the grid
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) rb_store_pair(tile_out + (int64_t)(i * G) * a.ld, sv[i].x, sv[i].y, true, true);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (((t * G) << 2) + wr_row + i * G < a.n_steps)
+                            rb_store_pair(tile_out + (int64_t)(i * G) * a.ld, sv[i].x, sv[i].y, true, true);
+                }
             }
             if (NBUF == 1) __syncthreads();
         }
     }
-    log_a = ls_a;
-    log_b = ls_b;
+    end_a = S_a;
+    end_b = S_b;
 }
 
 // Mz < 32 (at most 16 steps): one pair per lane, the transform evaluated directly.
 __device__ __forceinline__ void rb_generate_small(const RbArgs& a, int64_t block_index, double* smem, fm::Tables* tabs,
-                                                  double& log_a, double& log_b, bool& live_a, bool& live_b, bool& lead) {
+                                                  double& end_a, double& end_b, bool& live_a, bool& live_b, bool& lead) {
     const RbLds L = rb_stage_lds(a, smem, tabs);
     const int M = a.M;  // 1, 2, 4, 8 or 16
     const int64_t q = block_index * (int64_t)blockDim.x + threadIdx.x;
@@ -445,10 +502,10 @@ __device__ __forceinline__ void rb_generate_small(const RbArgs& a, int64_t block
         const double var_a = fm::scaled_exp(a.xi, re + L.comp[n]), var_b = fm::scaled_exp(a.xi, im + L.comp[n]);
         ls_a += fma(fm::sqrt_pos(fmax(var_a, 1e-300)) * a.sqdt, za[n & 3], (a.r - 0.5 * var_a) * a.dt);
         ls_b += fma(fm::sqrt_pos(fmax(var_b, 1e-300)) * a.sqdt, zb[n & 3], (a.r - 0.5 * var_b) * a.dt);
-        rb_store_pair(col + (int64_t)(n + 1) * a.ld, fm::scaled_exp(1.0, ls_a), fm::scaled_exp(1.0, ls_b), live_a, live_b);
+        end_a = fm::scaled_exp(1.0, ls_a);
+        end_b = fm::scaled_exp(1.0, ls_b);
+        rb_store_pair(col + (int64_t)(n + 1) * a.ld, end_a, end_b, live_a, live_b);
     }
-    log_a = ls_a;
-    log_b = ls_b;
 }
 
 }  // namespace mcg
