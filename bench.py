@@ -177,15 +177,15 @@ def extra_configs(eng, N) -> list:
         P.free()
         return r
 
-    # (name, pass, paths, dominant kernel id, algorithmic bytes of ALL launches of that kernel in one pass, valu profile key)
+    # (name, pass, paths, time steps / exercise dates, {kernel: SURVEY 8(d) algorithmic bytes of all its launches in one pass})
     specs = [
-        ("C3: American put, LSM order 2, GBM, 1M paths x 50 exercise dates", c3, 1_000_000, N.K_LSM_SWEEP,
-         40.0 * 50 * 1_000_000, None),
-        ("C4: rBergomi European call (H=0.1), 4M paths x 512 steps", c4, 4_000_000, N.K_RBERGOMI, 8.0 * 513 * 4_000_000, "c4"),
-        ("C5 shard: rBergomi American put LSM order 2, 8M paths x 252 steps (1/8 of the 64M job)", c5, 8_000_000,
-         N.K_LSM_SWEEP, 40.0 * 252 * 8_000_000, None),
+        ("C3: American put, LSM order 2, GBM, 1M paths x 50 exercise dates", c3, 1_000_000, 50,
+         {"gbm": 8.0 * 51 * 1_000_000, "lsm_sweep": 40.0 * 50 * 1_000_000}),
+        ("C4: rBergomi European call (H=0.1), 4M paths x 512 steps", c4, 4_000_000, 512, {"rbergomi": 8.0 * 513 * 4_000_000}),
+        ("C5 shard: rBergomi American put LSM order 2, 8M paths x 252 steps (1/8 of the 64M job)", c5, 8_000_000, 252,
+         {"rbergomi": 8.0 * 253 * 8_000_000, "lsm_sweep": 40.0 * 252 * 8_000_000}),
     ]
-    for name, fn, paths, kid, alg_bytes, vkey in specs:
+    for name, fn, paths, steps, alg in specs:
         fn()
         eng.synchronize()
         eng.timing_reset()
@@ -199,18 +199,24 @@ def extra_configs(eng, N) -> list:
             tot, cnt = eng.timing_get(k)
             if cnt:
                 kernels[kname] = {"ms_per_pass": tot / reps, "launches_per_pass": cnt // reps}
-        dom = kernels[N.KERNEL_NAMES[kid]]
+        for kname, b in alg.items():  # against the HBM roofline, by SURVEY 8(d)'s algorithmic bytes
+            if kname in kernels:
+                kernels[kname]["algorithmic_bytes_per_pass"] = b
+                kernels[kname]["hbm_frac"] = b / (kernels[kname]["ms_per_pass"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+        if "lsm_sweep" in kernels:
+            # what the one-launch sweeps are designed to move: 8 B per path and date with the row kept in registers
+            # (<= 1.8M paths), 16 B when it streams through the LDS ring (k_lsm_big); V never touches memory
+            moved = (8.0 if paths <= 1_800_000 else 16.0) * steps * paths
+            kernels["lsm_sweep"]["design_bytes_per_pass"] = moved
+            kernels["lsm_sweep"]["hbm_frac_of_design_bytes"] = moved / (kernels["lsm_sweep"]["ms_per_pass"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+        dom = max(alg, key=lambda k: kernels.get(k, {}).get("ms_per_pass", 0.0))
         row = {"config": name, "paths": paths, "ms_per_pass": ms, "Mpaths_per_s": paths / ms / 1e3,
-               "price": res[0], "std_err": res[1], "kernels": kernels, "dominant_kernel": N.KERNEL_NAMES[kid],
-               "dominant_kernel_ms_per_pass": dom["ms_per_pass"],
-               "algorithmic_bytes_per_pass": alg_bytes,
-               "hbm_frac": alg_bytes / (dom["ms_per_pass"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
-        if "rbergomi" in kernels:  # the generation half, against the HBM-write roofline of its own matrix
-            steps = 512 if name.startswith("C4") else 252
-            g = kernels["rbergomi"]["ms_per_pass"]
-            row["generation_hbm_frac"] = 8.0 * (steps + 1) * paths / (g * 1e-3) / 1e9 / HBM_PEAK_GBS
+               "price": res[0], "std_err": res[1], "kernels": kernels, "dominant_kernel": dom,
+               "dominant_kernel_ms_per_pass": kernels[dom]["ms_per_pass"], "hbm_frac": kernels[dom].get("hbm_frac")}
+        if "rbergomi" in kernels:  # the generator is issue-bound: VALU instructions x 4 cycles against SIMD-cycles available
             vp = valu_profile("c4" if steps == 512 else "c5gen")
             if vp and vp.get("paths"):
+                g = kernels["rbergomi"]["ms_per_pass"]
                 insts = vp["insts"] * paths / vp["paths"]
                 row["generation_valu_issue_frac"] = insts * 4.0 / (N_SIMDS * vp["clock_GHz"] * 1e9 * g * 1e-3)
                 row["valu_source"] = (f"{vp['source']}: SQ_INSTS_VALU per launch scaled to {paths} paths x 4 cycles / "
@@ -407,11 +413,28 @@ def main() -> None:
         }
         if args.config == "c5":
             per_pass = max(args.steps, 1)
+            one_launch = sweep_n // per_pass <= 2
+            design = (16.0 if one_launch else 32.0) * n_steps * count
             out["roofline"]["lsm"] = {
                 "sweep_ms_per_pass": sweep_ms / per_pass, "sweep_launches_per_pass": sweep_n // per_pass,
                 "solve_ms_per_pass": solve_ms / per_pass, "solve_launches_per_pass": solve_n // per_pass,
                 "algorithmic_bytes_per_pass": 40.0 * n_steps * count,   # 40 B per path and date
-                "hbm_frac": 40.0 * n_steps * count / max(sweep_ms / per_pass * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS}
+                "hbm_frac": 40.0 * n_steps * count / max(sweep_ms / per_pass * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS,
+                "design_bytes_per_pass": design,   # what this execution shape moves: 16 B one-launch (k_lsm_big), 32 B per-date kernels
+                "hbm_frac_of_design_bytes": design / max(sweep_ms / per_pass * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS,
+                "shape": "one launch (k_lsm_big: V in registers, matrix through an LDS-DMA ring)" if one_launch
+                         else "per-date kernels (one all-reduce of 8 moments per exercise date)"}
+            pmc5 = os.path.join(ROOT, "profiles", "r02_c5_pmc_traffic.json")
+            if os.path.exists(pmc5) and count == 8_000_000 and n_steps == 252:
+                try:
+                    j5 = json.load(open(pmc5))
+                    out["roofline"]["traffic"] = j5["generator"]["hbm_bytes_per_launch"]
+                    out["roofline"]["traffic_source"] = ("profiles/r02_c5_pmc_traffic.json (committed: rocprofv3 --pmc WRITE_SIZE / "
+                                                         "FETCH_SIZE passes of this command, tools/profile_r02.sh; not re-measured here)")
+                    if one_launch:
+                        out["roofline"]["lsm"]["traffic"] = j5["lsm_one_launch"]["hbm_bytes_per_launch"]
+                except Exception:
+                    pass
         if world == 1 and not args.no_cpu_baseline:
             try:
                 cb = cpu_baseline(n_steps)
