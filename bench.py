@@ -242,6 +242,12 @@ def main() -> None:
     if args.paths <= 0:
         args.paths = 10_000_000 if args.config == "c2" else 8_000_000
 
+    # ONE JSON line on stdout, nothing else: libraries write banners there from C (RCCL prints its version block when a
+    # communicator is created), so the process's stdout is pointed at stderr and the line goes to the saved descriptor.
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -451,7 +457,7 @@ def main() -> None:
                 out["extra"] = {"configs": extra_configs(eng, N)}
             except Exception as e:
                 out["extra"] = {"configs": [], "error": str(e)}
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=json_out, flush=True)
     eng.timing_enable(False)
     eng.close()
     if dist is not None:

@@ -11,10 +11,14 @@
 //   * path generation: the reference is unseeded (std::random_device per call), so parity is
 //     statistical; "mt" mode below reproduces the reference's RNG consumption order with an explicit
 //     seed, "philox" mode mirrors the device algorithm draw-for-draw.
+//     In the rough regime (H = 0.1, eta = 1.9), which the reference's public entry point cannot reach, both modes
+//     are compared with a committed sample drawn through the compiled reference's own private members
+//     (ref_harness.cpp: ref_explicit_stats_omp; tests/golden/rough_regime_reference.json).
 //   * LSM and MartingaleOptimization: PARITY UNPINNED at the Eigen boundary -- Eigen3 is not in this image and
 //     the reference has no tests; `orc_lsm_price` / `orc_martingale_price` restate the two pricers with an
 //     independent one-sided Jacobi SVD (min-norm least squares, Eigen's rank threshold) and are cross-checked
-//     against LAPACK gelsd (numpy.linalg.lstsq) in tests/.
+//     against LAPACK gelsd (numpy.linalg.lstsq) and, on near-degenerate dates, against Eigen's rule evaluated in
+//     60-digit arithmetic (mpmath) in tests/.
 //   * BranchingProcesses upper bound: the reference resamples with an unseeded mt19937; compared statistically.
 //
 // Every function cites the reference lines it follows (paths relative to /root/reference).

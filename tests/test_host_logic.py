@@ -102,14 +102,14 @@ def test_device_math_tables_and_coefficients_come_from_the_generator(tmp_path):
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    """profiles/r01_bench_n1.json is the line bench.py printed on the GPU box: the driver's contract fields plus the
+    """profiles/r02_bench_n1.json is the line bench.py printed on the GPU box: the driver's contract fields plus the
     roofline and cpu_baseline objects must all be there, and be mutually consistent."""
     import json
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    j = json.load(open(os.path.join(root, "profiles", "r01_bench_n1.json")))
+    j = json.load(open(os.path.join(root, "profiles", "r02_bench_n1.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
-              "dtype", "data", "config", "roofline", "cpu_baseline", "parity"):
+              "dtype", "data", "config", "roofline", "cpu_baseline", "parity", "extra"):
         assert k in j, k
     assert j["metric"] == "Mpaths/sec at 252 steps" and j["unit"] == "Mpaths/s" and j["dtype"] == "f64"
     assert j["scaling"] == "weak" and j["higher_is_better"] is True and j["vs_baseline"] is None
@@ -121,11 +121,38 @@ def test_committed_bench_line_has_the_contract_fields():
     assert r["algorithmic_bytes_per_launch"] == alg
     assert abs(r["achieved"] - alg / (r["kernel_avg_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
     assert r["traffic"] is None or 0.99 * alg < r["traffic"] < 1.05 * alg          # PMC bytes ~ algorithmic bytes
+    assert r["traffic"] is None or "profiles/pmc_traffic.json" in r["traffic_source"]   # says where the number is from
     # whole-job throughput = paths of all ranks / time
     assert abs(j["value"] - j["config"]["global_paths"] / (j["ms_per_step"] * 1e-3) / 1e6) < 1e-6 * j["value"]
     c = j["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["unit"] == "Mpaths/s" and "sample" in c
     assert j["parity"]["abs_err_over_std_err"] <= 2.0
+    # north-star bar in the rough regime: every price within 2 combined standard errors of the compiled reference's sample
+    for name, v in j["parity"]["rough_regime_vs_reference_sample"].items():
+        assert v["abs_diff_over_combined_std_err"] <= 2.0, name
+    # the other configurations, timed in the same run
+    rows = {row["config"][:2]: row for row in j["extra"]["configs"]}
+    assert set(rows) == {"C3", "C4", "C5"}
+    for row in rows.values():
+        assert row["ms_per_pass"] > 0 and row["dominant_kernel"] in row["kernels"]
+        assert abs(row["Mpaths_per_s"] - row["paths"] / row["ms_per_pass"] / 1e3) < 1e-6 * row["Mpaths_per_s"]
+    assert rows["C5"]["kernels"]["lsm_sweep"]["launches_per_pass"] == 1          # the 8M shard runs the one-launch sweep
+
+
+def test_committed_c5_bench_lines():
+    """The C5 lines (bench.py --config c5): one launch of the LSM sweep without a collective, the per-date kernels with
+    one all-reduce of 8 moments per exercise date when the built-in RCCL communicator is installed; same price."""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    a = json.load(open(os.path.join(root, "profiles", "r02_bench_c5_n1.json")))
+    b = json.load(open(os.path.join(root, "profiles", "r02_bench_c5_rccl_n1.json")))
+    assert a["config"]["collective"] == "none" and b["config"]["collective"] == "rccl"
+    assert a["roofline"]["lsm"]["sweep_launches_per_pass"] == 1 and b["roofline"]["lsm"]["sweep_launches_per_pass"] == 254
+    assert abs(a["parity"]["price"] - b["parity"]["price"]) <= 1e-9 * a["parity"]["price"]
+    for j in (a, b):
+        assert j["config"]["paths_per_gpu"] == 8_000_000 and j["config"]["time_steps"] == 252
+        assert abs(j["value"] - j["config"]["global_paths"] / (j["ms_per_step"] * 1e-3) / 1e6) < 1e-6 * j["value"]
 
 
 def test_close_frees_live_matrices_before_the_ctx_and_late_free_is_a_no_op():
