@@ -235,7 +235,8 @@ def main() -> None:
     ap.add_argument("--time-steps", type=int, default=252)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the C3/C4/C5-shard timings after the headline loop")
-    ap.add_argument("--collective", default=os.environ.get("MCG_COLLECTIVE", "rccl"), choices=["rccl", "torch"])
+    ap.add_argument("--collective", default=os.environ.get("MCG_COLLECTIVE", "auto"), choices=["auto", "shm", "rccl", "torch"],
+                    help="auto: shm (node-local shared memory; the LSM sweeps exchange inside the kernel) for c5, rccl for c2")
     ap.add_argument("--backend", default=os.environ.get("MCG_DIST_BACKEND", "nccl"), choices=["nccl", "gloo"],
                     help="torch.distributed backend; gloo lets several ranks share one GPU (rehearsal only)")
     args = ap.parse_args()
@@ -284,7 +285,23 @@ def main() -> None:
     collective = "none"
     if dist is not None:
         collective = args.collective
-        if collective == "rccl":
+        if collective == "auto":
+            collective = "shm" if args.config == "c5" else "rccl"
+        if collective == "shm":
+            box = [f"/mcg_bench_{os.getpid()}_{int(time.time())}" if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            try:
+                eng.init_shm(box[0], rank, world)
+            except mc.McgError as e:
+                print(f"bench: shared-memory communicator unavailable ({e}); using RCCL", file=sys.stderr)
+                collective = "rccl (shm init failed)"
+            ok = torch.tensor([1 if collective == "shm" else 0], device="cuda")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0 and collective == "shm":
+                collective = "rccl (shm init failed on a peer)"
+            if collective != "shm":
+                eng.set_allreduce(None)
+        if collective.startswith("rccl"):
             def bcast(uid):
                 box = [uid]
                 dist.broadcast_object_list(box, src=0)
@@ -294,12 +311,12 @@ def main() -> None:
             except mc.McgError as e:           # communicator set-up failed on this node: use torch's, and say so
                 print(f"bench: built-in RCCL communicator unavailable ({e}); using torch.distributed", file=sys.stderr)
                 collective = "torch (built-in RCCL init failed)"
-            ok = torch.tensor([1 if collective == "rccl" else 0], device="cuda")
+            ok = torch.tensor([0 if collective.startswith("torch") else 1], device="cuda")
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)    # all ranks take the same route
             if int(ok.item()) == 0:
-                collective = collective if collective != "rccl" else "torch (built-in RCCL init failed on a peer)"
+                collective = collective if collective.startswith("torch") else "torch (built-in RCCL init failed on a peer)"
                 eng.use_torch_distributed()
-        else:
+        elif collective == "torch":
             eng.use_torch_distributed()
 
     if args.config == "c2":
@@ -397,8 +414,9 @@ def main() -> None:
         else:
             workload = ("C5: rBergomi (H=0.1, eta=1.9) American put, Longstaff-Schwartz order 2, 8M paths x 252 steps per GPU "
                         "(8 GPUs: the 64M-path job), fp64 matrix written then swept backwards")
-            sharding = (f"contiguous even-aligned path ids over {world} rank(s); per exercise date one all-reduce of 8 "
-                        "regression moments, then 3 doubles of final sums")
+            sharding = (f"contiguous even-aligned path ids over {world} rank(s); per exercise date 8 regression moments are "
+                        "summed over the ranks (shm: inside the one-launch sweep through the node mailbox; rccl/torch: "
+                        "one all-reduce between the per-date kernels), then 3 doubles of final sums")
             parity = {"price": price, "std_err": se}
             kernel_name = "k_rbergomi_fft"
         out = {
@@ -428,7 +446,7 @@ def main() -> None:
                 "hbm_frac": 40.0 * n_steps * count / max(sweep_ms / per_pass * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS,
                 "design_bytes_per_pass": design,   # what this execution shape moves: 16 B one-launch (k_lsm_big), 32 B per-date kernels
                 "hbm_frac_of_design_bytes": design / max(sweep_ms / per_pass * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS,
-                "shape": "one launch (k_lsm_big: V in registers, matrix through an LDS-DMA ring)" if one_launch
+                "shape": "one launch (V in registers; beyond 1.8M paths the matrix streams through an LDS-DMA ring)" if one_launch
                          else "per-date kernels (one all-reduce of 8 moments per exercise date)"}
             pmc5 = os.path.join(ROOT, "profiles", "r02_c5_pmc_traffic.json")
             if os.path.exists(pmc5) and count == 8_000_000 and n_steps == 252:

@@ -85,6 +85,14 @@ int mcg_set_allreduce(mcg_ctx* ctx, mcg_allreduce_fn fn, void* user);
 int mcg_comm_unique_id(unsigned char id[128]);
 int mcg_comm_init_rank(mcg_ctx* ctx, const unsigned char id[128], int n_ranks, int rank);
 
+/* Node-local collective over POSIX shared memory (one process per GPU, all on one host): `name` is a segment name
+ * starting with '/', the same on every rank and unique to the job (rank 0 creates it, mcg_finalize removes it).
+ * Installs a host all-reduce for the payoff sums AND lets the one-launch LSM sweeps exchange their per-date
+ * regression moments between the GPUs INSIDE the kernel, through a device-mapped mailbox in the segment: a sharded
+ * American price then costs one launch per GPU instead of three launches and one collective per exercise date.
+ * At most 16 ranks. */
+int mcg_comm_init_shm(mcg_ctx* ctx, const char* name, int n_ranks, int rank);
+
 /* ---- path generation (replaces RoughVolatility.cpp:346-365, device side) ---------------- */
 /* GBM: the stepping loop of RoughVolatility.cpp:354-364 with v == sigma^2.
  * Paths [path_begin, path_begin + n_paths) of the global Philox stream `seed`. */

@@ -69,6 +69,7 @@ def load_library():
     L.mcg_set_allreduce.argtypes = [vp, ALLREDUCE_FN, vp]
     L.mcg_comm_unique_id.argtypes = [C.c_char_p]
     L.mcg_comm_init_rank.argtypes = [vp, C.c_char_p, C.c_int, C.c_int]
+    L.mcg_comm_init_shm.argtypes = [vp, C.c_char_p, C.c_int, C.c_int]
     L.mcg_paths_gbm.argtypes = [vp, C.c_uint64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int,
                                 C.c_uint64, C.c_int64, C.POINTER(vp)]
     L.mcg_paths_gbm_payoff.argtypes = [vp, C.c_uint64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int,

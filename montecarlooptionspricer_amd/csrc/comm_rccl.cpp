@@ -117,6 +117,7 @@ int mcg_comm_init_rank(mcg_ctx* ctx, const unsigned char id[128], int n_ranks, i
     NcclId nid;
     std::memcpy(nid.internal, id, 128);
     mcg::comm_release(ctx);  // a second init on the same ctx replaces the communicator
+    mcg::shm_release(ctx);   // ... and the node-local one, mailbox included
     comm_t comm = nullptr;
     int rc = g_rccl.CommInitRank(&comm, n_ranks, nid, rank);
     if (rc != 0) return mcg::fail(MCG_ERR_COMM, "ncclCommInitRank failed: %s", nccl_err(rc));

@@ -273,6 +273,10 @@ struct LsmCoopArgs {
     unsigned spin_limit; // polling rounds before a spin gives up (LSM_SPIN_LIMIT; MCG_LSM_SPIN_LIMIT in tests)
     int u_full;          // k_lsm_big: units 0 .. u_full-1 lie inside the shard for EVERY thread (no masking needed)
     double* out;       // [2 * gridDim.x]: per-block {sum V, sum V^2}
+    // node-level exchange (mcg_comm_init_shm): mailbox[round][rank][SHM_ROW_DOUBLES] in device-mapped host memory,
+    // nullptr on a single GPU
+    double* mbox;
+    int mb_ranks, mb_rank;
 };
 
 __device__ __forceinline__ bool lsm_is_sentinel(double v) {
@@ -309,11 +313,55 @@ __device__ __forceinline__ void lsm_publish_partials(const LsmCoopArgs& a, doubl
 // sm_coef for its own threads).  The same fixed-order reduction as k_lsm_reduce_solve: wave w sums moments w, w+4, ...;
 // lane l the workgroups l, l+64, ...  Two of the wave's moments per round: all their slots are polled together, so the
 // usual date costs one round trip to the coherence point, not one per moment.
+// System-scope access to the node mailbox (host memory mapped into every GPU of the node: each access crosses PCIe).
+__device__ __forceinline__ void lsm_st_node(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ double lsm_ld_node(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+
+// Sum the local moments sm_mom[0..NM) over the GPUs of the node, inside the kernel: lane t of wave 0 publishes moment t in
+// this rank's row of the round's mailbox slot and polls the same entry of every rank's row (all loads of a poll in
+// flight together: one PCIe round trip) until none holds the reserved NaN; the sum runs in rank order, so every GPU
+// obtains the same bits.  Rows are written once per sweep; the host re-armed them before the launch (shm_arm_mailbox).
+template <int NM>
+__device__ __forceinline__ void lsm_node_allreduce(const LsmCoopArgs& a, int round, bool& gave_up, double* sm_mom) {
+    static_assert(NM <= SHM_ROW_DOUBLES, "a rank's mailbox row holds the moments of orders <= 4");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();  // sm_mom is complete
+    if (wave == 0 && lane < NM) {
+        double* slot = a.mbox + (size_t)round * SHM_MAX_RANKS * SHM_ROW_DOUBLES;
+        lsm_st_node(slot + a.mb_rank * SHM_ROW_DOUBLES + lane, sm_mom[lane]);
+        double v[SHM_MAX_RANKS];
+        unsigned spins = 0;
+        bool missing = !gave_up;
+        do {
+#pragma unroll
+            for (int r = 0; r < SHM_MAX_RANKS; ++r) v[r] = r < a.mb_ranks ? lsm_ld_node(slot + r * SHM_ROW_DOUBLES + lane) : 0.0;
+            if (!missing) break;
+            missing = false;
+#pragma unroll
+            for (int r = 0; r < SHM_MAX_RANKS; ++r) missing = missing || lsm_is_sentinel(v[r]);
+            if (missing) {
+                __builtin_amdgcn_s_sleep(4);
+                if (++spins > a.spin_limit) {
+                    __hip_atomic_store(a.timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    gave_up = true;
+                    break;
+                }
+            }
+        } while (missing);
+        double tot = 0.0;
+#pragma unroll
+        for (int r = 0; r < SHM_MAX_RANKS; ++r) tot += v[r];  // (entries beyond the communicator are +0)
+        sm_mom[lane] = tot;
+    }
+    __syncthreads();
+}
+
 // centered: this round carries the moments of a refinement pass about `mu` (lsm_solve_nb asked for it on the previous
-// round of the same date); ws = LDS workspace of lsm_solve_centered.
+// round of the same date); ws = LDS workspace of lsm_solve_centered; round = exchange counter of this sweep (the slot
+// of the node mailbox when the sweep is sharded over the GPUs of a node).
 template <int NB>
 __device__ __forceinline__ void lsm_reduce_solve_publish(const LsmCoopArgs& a, unsigned G, int parity, bool& gave_up, double* sm_mom,
-                                                         double* sm_coef, bool centered, double mu, double* ws) {
+                                                         double* sm_coef, bool centered, double mu, double* ws, int round) {
     constexpr int NM = 3 * NB - 1;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double* part = a.partials + (int64_t)parity * NM * G;
@@ -366,6 +414,7 @@ __device__ __forceinline__ void lsm_reduce_solve_publish(const LsmCoopArgs& a, u
     }
     // all partials of this date are in: every workgroup is past the previous date's coefficients
     if (threadIdx.x < LSM_COEF_DOUBLES) lsm_st_shared(a.coef + 16 * (parity ^ 1) + threadIdx.x, lsm_sentinel());
+    if (a.mbox) lsm_node_allreduce<NM>(a, round, gave_up, sm_mom);  // (uniform) local -> node-wide moments
     __syncthreads();
     if (threadIdx.x == 0) {
         if (centered) lsm_solve_centered(sm_mom, NB, mu, a.K, sm_coef, ws);
@@ -401,10 +450,10 @@ __device__ __forceinline__ void lsm_poll_coefficients(const LsmCoopArgs& a, int 
 template <int NB, class F>
 __device__ __forceinline__ void lsm_exchange(const LsmCoopArgs& a, double (&m)[3 * NB - 1], int parity, bool& gave_up,
                                              double* red, double* sm_mom, double* sm_coef, bool centered, double mu, double* ws,
-                                             F&& after_publish) {
+                                             int round, F&& after_publish) {
     lsm_publish_partials<NB>(a, m, gridDim.x, blockIdx.x, parity, red);
     after_publish();
-    if (blockIdx.x == 0) lsm_reduce_solve_publish<NB>(a, gridDim.x, parity, gave_up, sm_mom, sm_coef, centered, mu, ws);
+    if (blockIdx.x == 0) lsm_reduce_solve_publish<NB>(a, gridDim.x, parity, gave_up, sm_mom, sm_coef, centered, mu, ws, round);
     else lsm_poll_coefficients(a, parity, gave_up, sm_coef);
 }
 
@@ -425,7 +474,7 @@ __global__ __launch_bounds__(256, (PPT >= 16 ? 2 : 3)) void k_lsm_coop(LsmCoopAr
     int64_t stride = (int64_t)G * 256;
     // columns first + q * stride exist for q < n_live (one per-lane integer instead of PPT lane masks)
     const int n_live = (int64_t)first < a.n ? (int)std::min<int64_t>(PPT, (a.n - 1 - first) / stride + 1) : 0;
-    int parity = 0;
+    int parity = 0, round = 0;         // round: exchanges so far (every workgroup counts alike; only workgroup 0 uses it)
     bool gave_up = a.spin_limit == 0;  // this thread has hit the spin limit once (limit 0, tests: from the start)
     if (gave_up && blockIdx.x == 0 && threadIdx.x == 0)
         __hip_atomic_store(a.timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -479,7 +528,7 @@ __global__ __launch_bounds__(256, (PPT >= 16 ? 2 : 3)) void k_lsm_coop(LsmCoopAr
                 }
             }
         }
-        lsm_exchange<NB>(a, m, parity, gave_up, red, sm_mom, sm_coef, false, 0.0, sm_ws, [&]() {
+        lsm_exchange<NB>(a, m, parity, gave_up, red, sm_mom, sm_coef, false, 0.0, sm_ws, round++, [&]() {
             if constexpr (PREFETCH) {
                 if (j >= 1) load_row(j - 1, s_nxt);
             }
@@ -495,7 +544,7 @@ __global__ __launch_bounds__(256, (PPT >= 16 ? 2 : 3)) void k_lsm_coop(LsmCoopAr
             for (int q = 0; q < PPT; ++q)
                 lsm_accumulate_centered<NB>(m, q < n_live && payoff_of(call, s_j[q], a.K) > 1e-14, s_j[q], V[q], a.invK, mu, a.disc);
             parity ^= 1;
-            lsm_exchange<NB>(a, m, parity, gave_up, red, sm_mom, sm_coef, true, mu, sm_ws, []() {});
+            lsm_exchange<NB>(a, m, parity, gave_up, red, sm_mom, sm_coef, true, mu, sm_ws, round++, []() {});
         }
         double c[NB];
 #pragma unroll
@@ -627,16 +676,16 @@ __device__ __forceinline__ void lsm_reduce_loop(const LsmCoopArgs& a, unsigned G
     int j = a.n_cols - 2;
     for (; j >= 0 && j * a.dt > a.maturity; --j) {
     }
-    int parity = 0;
+    int parity = 0, round = 0;
     for (; j >= 0; --j) {
-        lsm_reduce_solve_publish<NB>(a, G, parity, gave_up, sm_mom, sm_coef, false, 0.0, ws);
+        lsm_reduce_solve_publish<NB>(a, G, parity, gave_up, sm_mom, sm_coef, false, 0.0, ws, round++);
         __syncthreads();
         const bool refine = __builtin_amdgcn_readfirstlane(sm_coef[LSM_C_REFINE] != 0.0 ? 1 : 0) != 0;
         const double mu = sm_coef[LSM_C_HINT];
         __syncthreads();  // sm_mom / sm_coef are rewritten on the next round
         parity ^= 1;
         if (refine) {  // the workers answer a refinement request with one more round for the same date
-            lsm_reduce_solve_publish<NB>(a, G, parity, gave_up, sm_mom, sm_coef, true, mu, ws);
+            lsm_reduce_solve_publish<NB>(a, G, parity, gave_up, sm_mom, sm_coef, true, mu, ws, round++);
             __syncthreads();
             parity ^= 1;
         }
@@ -867,16 +916,22 @@ static int run_lsm_coop(mcg_ctx* ctx, const mcg_paths* P, double r, double K, do
                         int nb, double* sums3, bool* done) {
     *done = false;
     const CoopVariant* vars = coop_variants_for(nb);
-    if (!vars || !ctx->coop_launch) return MCG_OK;  // coop_launch: cleared after a hand-shake time-out
     const int64_t N = P->n_paths;
+    // Sharded over the GPUs of a node (mcg_comm_init_shm): the reducing workgroups exchange through the node mailbox.
+    // The ranks' shards differ by at most a pair of paths, so they all come here, pick a variant (possibly different
+    // ones: irrelevant) and run the same number of exchange rounds.
+    double* mbox = shm_mailbox_device(ctx);
+    const int rounds_needed = 2 * (P->n_steps + 1);
     const int nm = 3 * nb - 1;
+    // coop_launch: cleared after a hand-shake time-out
+    bool eligible = vars && ctx->coop_launch && N > 1024 && !(mbox && (rounds_needed > SHM_MAX_ROUNDS || nm > SHM_ROW_DOUBLES));
     // Few paths per thread keep each workgroup's serial work per date short, a small grid keeps the reduction in
     // workgroup 0 short: take the fewest paths per thread that need at most two workgroups per CU, else the most.
     const CoopVariant* use = nullptr;
     int grid = 0, workers = 0;
     static const int min_ppt = std::getenv("MCG_LSM_COOP_MIN_PPT") ? std::atoi(std::getenv("MCG_LSM_COOP_MIN_PPT")) : 0;  // experiments
     static std::atomic<int> occ_cache[10][LSM_N_VARIANTS];  // workgroups per CU of each variant (0 = not asked yet); same on every device
-    for (int k = 0; k < LSM_N_VARIANTS; ++k) {
+    for (int k = 0; eligible && k < LSM_N_VARIANTS; ++k) {
         if (vars[k].ppt < min_ppt) continue;
         int occ = occ_cache[nb][k].load(std::memory_order_relaxed);
         if (occ == 0) {
@@ -906,6 +961,12 @@ static int run_lsm_coop(mcg_ctx* ctx, const mcg_paths* P, double r, double K, do
         grid = workers + (int)extra;
         if (grid <= 2 * ctx->n_cus) break;
     }
+    if (mbox) {  // every rank of the node takes the one-launch sweep, or none does
+        int all = 0;
+        int rc0 = shm_sum_flag(ctx, use ? 1 : 0, &all);
+        if (rc0) return rc0;
+        if (all != shm_n_ranks(ctx)) return MCG_OK;
+    }
     if (!use) return MCG_OK;
     // buffer: {sum, sum^2} per contributing workgroup | [2][nm][workers] moment slots | [2][16] coefficient slots
     const size_t n_slots = 2 * (size_t)nm * workers + 32;
@@ -929,10 +990,17 @@ static int run_lsm_coop(mcg_ctx* ctx, const mcg_paths* P, double r, double K, do
     // test hook: MCG_LSM_SPIN_LIMIT=0 makes every wait give up at once and raises the time-out flag, which drives
     // the time-out -> per-date fall-back branch below on a healthy device (read on every call: tests flip it)
     a.u_full = (int)(N / ((int64_t)workers * 512));  // (k_lsm_big: units per thread that every thread has in full)
+    a.mbox = mbox;
+    a.mb_ranks = shm_n_ranks(ctx);
+    a.mb_rank = shm_rank(ctx);
     a.spin_limit = LSM_SPIN_LIMIT;
     if (const char* e = std::getenv("MCG_LSM_SPIN_LIMIT")) a.spin_limit = (unsigned)std::strtoul(e, nullptr, 10);
     MCG_HIP(hipMemsetD32Async((hipDeviceptr_t)a.partials, (int)LSM_SENTINEL32, 2 * n_slots, ctx->stream));
     MCG_HIP(hipMemsetAsync(a.timeout, 0, sizeof(unsigned), ctx->stream));
+    if (mbox) {  // this rank's mailbox rows hold the reserved NaN again, and so do everybody else's, before anyone launches
+        rc = shm_arm_mailbox(ctx, rounds_needed, ((uint64_t)LSM_SENTINEL32 << 32) | LSM_SENTINEL32);
+        if (rc) return rc;
+    }
     void* params[] = {&a};
     {
         // One such kernel at a time per process: two grids of spinning workgroups that are each only partly resident
@@ -949,7 +1017,12 @@ static int run_lsm_coop(mcg_ctx* ctx, const mcg_paths* P, double r, double K, do
         rc = finish_sums(ctx, workers, N, sums3);  // synchronises the stream
     }
     if (rc) return rc;
-    if (reinterpret_cast<const unsigned*>(ctx->h_scalars + SC_BARRIER)[0] != 0) {
+    int timed_out = reinterpret_cast<const unsigned*>(ctx->h_scalars + SC_BARRIER)[0] != 0 ? 1 : 0;
+    if (mbox) {  // the ranks agree: one time-out anywhere voids the sweep everywhere (they fall back together)
+        rc = shm_sum_flag(ctx, timed_out, &timed_out);
+        if (rc) return rc;
+    }
+    if (timed_out) {
         // A spin gave up: the grid was not co-resident after all.  The result is discarded, this context stops using
         // the one-launch sweep, and the caller runs the per-date kernels.
         ctx->coop_launch = false;
@@ -1046,7 +1119,7 @@ int run_lsm(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double maturit
         return MCG_OK;
     }
     int rc;
-    if (N > 1024 && !ctx->allreduce) {
+    if ((N > 1024 && !ctx->allreduce) || shm_mailbox_device(ctx)) {  // (with the node mailbox every rank asks: they agree inside)
         bool done = false;
         double s3[3];
         rc = run_lsm_coop(ctx, P, r, K, maturity, dt, is_call, nb, s3, &done);

@@ -272,6 +272,7 @@ int mcg_finalize(mcg_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     comm_release(ctx);
+    shm_release(ctx);
     for (mcg_paths* P : ctx->live_paths) {  // handles the caller still holds: orphan them (see mcg_paths_free)
         if (P->data) (void)hipFree(P->data);
         P->data = nullptr;
@@ -315,6 +316,7 @@ int mcg_trim(mcg_ctx* ctx) {
 
 int mcg_set_allreduce(mcg_ctx* ctx, mcg_allreduce_fn fn, void* user) {
     if (!ctx) return fail(MCG_ERR_INVALID, "ctx is NULL");
+    shm_release(ctx);  // a collective installed from outside replaces the node-local one, mailbox included
     ctx->allreduce = fn;
     ctx->allreduce_user = user;
     return MCG_OK;

@@ -35,6 +35,11 @@ struct EventPair {
     hipEvent_t a, b;
 };
 
+struct ShmComm;  // comm_shm.cpp: node-local collective over POSIX shared memory
+constexpr int SHM_MAX_RANKS = 16;     // processes (GPUs) sharing one segment
+constexpr int SHM_MAX_ROUNDS = 4096;  // exchange rounds of one LSM sweep the device mailbox holds (2 per exercise date at most)
+constexpr int SHM_ROW_DOUBLES = 16;   // one rank's row of a round: up to 14 moments (orders <= 4)
+
 }  // namespace mcg
 
 struct mcg_ctx {
@@ -64,6 +69,7 @@ struct mcg_ctx {
     mcg_allreduce_fn allreduce = nullptr;
     void* allreduce_user = nullptr;
     void* rccl_comm = nullptr;
+    mcg::ShmComm* shm = nullptr;  // mcg_comm_init_shm
     int n_ranks = 1, rank = 0;
 
     // timing
@@ -114,6 +120,13 @@ struct TimedLaunch {
 };
 
 void comm_release(mcg_ctx* ctx);  // comm_rccl.cpp
+// comm_shm.cpp
+void shm_release(mcg_ctx* ctx);
+int shm_arm_mailbox(mcg_ctx* ctx, int rounds, uint64_t sentinel_bits);
+int shm_sum_flag(mcg_ctx* ctx, int flag, int* total);
+double* shm_mailbox_device(mcg_ctx* ctx);
+int shm_rank(mcg_ctx* ctx);
+int shm_n_ranks(mcg_ctx* ctx);
 
 int paths_new(mcg_ctx* ctx, int64_t n_paths, int n_steps, uint64_t path_begin, mcg_paths** out);
 

@@ -163,6 +163,12 @@ class PathEngine:
         uid = broadcast_bytes(uid)
         check(self._L.mcg_comm_init_rank(self._ctx, uid, int(world), int(rank)))
 
+    def init_shm(self, name: str, rank: int, world: int) -> None:
+        """Node-local shared-memory collective (mcg_comm_init_shm): `name` starts with '/', is the same on every rank
+        and unique to the job.  Host all-reduce for the sums; the one-launch LSM sweeps exchange their per-date moments
+        between the GPUs inside the kernel."""
+        check(self._L.mcg_comm_init_shm(self._ctx, name.encode(), int(world), int(rank)))
+
     # -- generation -----------------------------------------------------------------------------
     def gbm(self, seed: int, S0: float, r: float, sigma: float, dt: float, n_steps: int, n_paths: int,
             path_begin: int = 0, payoff: Optional[Tuple[float, bool]] = None) -> PathMatrix:

@@ -1,12 +1,15 @@
 """One rank of a sharded pricing job on the PRODUCT path (libmcgpu through the C ABI): started as a fresh child
 process by tests/test_gpu_multirank.py, once per rank, all ranks on GPU 0.
 
-    python tests/mp_rank_worker.py <rank> <world> <port> <out.json>
+    python tests/mp_rank_worker.py <rank> <world> <port> <out.json> [gloo|shm]
 
-The collective is gloo (two ranks cannot share one device under RCCL): the callback installed with
-mcg_set_allreduce copies the handful of doubles to the host, all-reduces there and copies back, stream-ordered
-on the ctx's stream (= torch's current stream).  Everything else -- shard ranges, kernels, the per-date
-reduce / all-reduce / solve sequence of csrc/kernels_lsm.hip -- is exactly what an N-GPU run executes.
+gloo (two ranks cannot share one device under RCCL): the callback installed with mcg_set_allreduce copies the handful
+of doubles to the host, all-reduces there and copies back, stream-ordered on the ctx's stream (= torch's current
+stream).  Everything else -- shard ranges, kernels, the per-date reduce / all-reduce / solve sequence of
+csrc/kernels_lsm.hip -- is exactly what an N-GPU run executes.
+shm: the library's node-local shared-memory communicator (mcg_comm_init_shm; no torch.distributed at all): host
+all-reduce of the sums, and the LSM sweeps run as ONE launch per rank whose reducing workgroups exchange the per-date
+moments through the device-mapped mailbox -- here with both ranks' persistent kernels resident on the same GPU.
 """
 import json
 import os
@@ -22,28 +25,36 @@ JOBS = dict(euro_paths=300_001, lsm_paths=200_001, lsm_steps=50, rb_paths=100_00
 
 def main() -> None:
     rank, world, port, out_path = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+    mode = sys.argv[5] if len(sys.argv) > 5 else "gloo"
     import torch
-    import torch.distributed as dist
 
     import montecarlooptionspricer_amd as mc
+    from montecarlooptionspricer_amd import _native as N
     from montecarlooptionspricer_amd.engine import _DevView
     from montecarlooptionspricer_amd.sharding import shard_range
 
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    torch.cuda.set_device(0)
-    eng = mc.PathEngine(0, stream=torch.cuda.current_stream().cuda_stream)
     calls = []
+    dist = None
+    if mode == "gloo":
+        import torch.distributed as dist
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        torch.cuda.set_device(0)
+        eng = mc.PathEngine(0, stream=torch.cuda.current_stream().cuda_stream)
 
-    def allreduce(ptr, count, _stream):
-        t = torch.as_tensor(_DevView(ptr, count), device="cuda:0")
-        h = t.cpu()                      # waits for the producing kernel on the shared stream
-        dist.all_reduce(h)
-        t.copy_(h)
-        calls.append(count)
+        def allreduce(ptr, count, _stream):
+            t = torch.as_tensor(_DevView(ptr, count), device="cuda:0")
+            h = t.cpu()                      # waits for the producing kernel on the shared stream
+            dist.all_reduce(h)
+            t.copy_(h)
+            calls.append(count)
 
-    eng.set_allreduce(allreduce)
+        eng.set_allreduce(allreduce)
+    else:
+        eng = mc.PathEngine(0)
+        eng.init_shm(f"/mcg_test_{port}", rank, world)
+    eng.timing_enable(True)
     res = {}
 
     b, c = shard_range(JOBS["euro_paths"], rank, world)
@@ -53,13 +64,18 @@ def main() -> None:
 
     b, c = shard_range(JOBS["lsm_paths"], rank, world)
     P = eng.gbm(SEED, 100.0, 0.04, 0.2, 0.02, JOBS["lsm_steps"], c, path_begin=b)
+    eng.timing_reset()
     res["gbm_lsm"] = eng.price_lsm(P, 0.04, 100.0, 1.0, 0.02, False, 2)
+    res["gbm_lsm_sweep_launches"] = eng.timing_get(N.K_LSM_SWEEP)[1]
     P.free()
 
     b, c = shard_range(JOBS["rb_paths"], rank, world, align=2)
     T = JOBS["rb_steps"] * DT
     P = eng.rbergomi(SEED, RB["S0"], RB["r"], RB["xi"], RB["H"], RB["eta"], RB["rho"], DT, JOBS["rb_steps"], c, path_begin=b)
+    eng.timing_reset()
     res["rb_lsm"] = eng.price_lsm(P, RB["r"], 100.0, T, DT, False, 2)
+    res["rb_lsm_sweep_launches"] = eng.timing_get(N.K_LSM_SWEEP)[1]
+    res["one_launch_enabled"] = eng.lsm_one_launch_enabled()
     res["rb_euro_put"] = eng.price_european(P, 100.0, RB["r"], T, False)
     P.free()
 
@@ -68,8 +84,9 @@ def main() -> None:
     eng.close()
     with open(f"{out_path}.{rank}", "w") as f:
         json.dump(res, f)
-    dist.barrier()
-    dist.destroy_process_group()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

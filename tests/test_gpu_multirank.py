@@ -61,13 +61,17 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def test_two_rank_processes_equal_single_rank(tmp_path):
+@pytest.mark.parametrize("mode", ["gloo", "shm"])
+def test_two_rank_processes_equal_single_rank(tmp_path, mode):
+    """mode "gloo": a host all-reduce callback, the per-date LSM kernels (what RCCL runs use).  mode "shm": the
+    library's node-local shared-memory communicator -- each rank's LSM sweep is ONE launch, and the two persistent
+    kernels exchange their per-date moments through the device-mapped mailbox while both are resident on the GPU."""
     sys.path.insert(0, HERE)
     from mp_rank_worker import JOBS
 
     world, port, out = 2, _free_port(), str(tmp_path / "res.json")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "mp_rank_worker.py"), str(r), str(world), str(port), out],
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "mp_rank_worker.py"), str(r), str(world), str(port), out, mode],
                               env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     logs = []
     for p in procs:
@@ -100,6 +104,11 @@ def test_two_rank_processes_equal_single_rank(tmp_path):
                                (res["gbm_lsm"], want_lsm, 1e-9), (res["rb_lsm"], want_rb, 1e-9)):
             assert abs(got[0] - want[0]) <= tol * abs(want[0]), (r, got, want)
             assert abs(got[1] - want[1]) <= max(tol, 1e-9) * abs(want[1]), (r, got, want)
-        assert res["allreduce_calls"] == {"3": 4, "8": JOBS["lsm_steps"] + JOBS["rb_steps"]}
+        if mode == "gloo":
+            assert res["allreduce_calls"] == {"3": 4, "8": JOBS["lsm_steps"] + JOBS["rb_steps"]}
+            assert res["gbm_lsm_sweep_launches"] == JOBS["lsm_steps"] + 2          # one per date + terminal + final sums
+        else:
+            assert res["one_launch_enabled"], "\n".join(logs)                       # no hand-shake ever timed out
+            assert res["gbm_lsm_sweep_launches"] == 1 and res["rb_lsm_sweep_launches"] == 1
     assert ranks[0]["shard"][0] == 0 and ranks[1]["shard"][0] % 2 == 0
     assert ranks[0]["shard"][1] + ranks[1]["shard"][1] == JOBS["rb_paths"]
