@@ -1,7 +1,7 @@
 """One rank of a sharded pricing job on the PRODUCT path (libmcgpu through the C ABI): started as a fresh child
 process by tests/test_gpu_multirank.py, once per rank, all ranks on GPU 0.
 
-    python tests/mp_rank_worker.py <rank> <world> <port> <out.json> [gloo|shm]
+    python tests/mp_rank_worker.py <rank> <world> <port> <out.json> [gloo|shm|shm_timeout]
 
 gloo (two ranks cannot share one device under RCCL): the callback installed with mcg_set_allreduce copies the handful
 of doubles to the host, all-reduces there and copies back, stream-ordered on the ctx's stream (= torch's current
@@ -52,6 +52,8 @@ def main() -> None:
 
         eng.set_allreduce(allreduce)
     else:
+        if mode == "shm_timeout":       # every hand-shake gives up at once: the ranks must agree to fall back together
+            os.environ["MCG_LSM_SPIN_LIMIT"] = "0"
         eng = mc.PathEngine(0)
         eng.init_shm(f"/mcg_test_{port}", rank, world)
     eng.timing_enable(True)

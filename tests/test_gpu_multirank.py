@@ -61,11 +61,13 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("mode", ["gloo", "shm"])
+@pytest.mark.parametrize("mode", ["gloo", "shm", "shm_timeout"])
 def test_two_rank_processes_equal_single_rank(tmp_path, mode):
     """mode "gloo": a host all-reduce callback, the per-date LSM kernels (what RCCL runs use).  mode "shm": the
     library's node-local shared-memory communicator -- each rank's LSM sweep is ONE launch, and the two persistent
-    kernels exchange their per-date moments through the device-mapped mailbox while both are resident on the GPU."""
+    kernels exchange their per-date moments through the device-mapped mailbox while both are resident on the GPU.
+    mode "shm_timeout": the same with every hand-shake forced to give up: the ranks agree (sum of their time-out flags)
+    to discard the sweep and answer from the per-date kernels over the segment's host all-reduce."""
     sys.path.insert(0, HERE)
     from mp_rank_worker import JOBS
 
@@ -107,8 +109,12 @@ def test_two_rank_processes_equal_single_rank(tmp_path, mode):
         if mode == "gloo":
             assert res["allreduce_calls"] == {"3": 4, "8": JOBS["lsm_steps"] + JOBS["rb_steps"]}
             assert res["gbm_lsm_sweep_launches"] == JOBS["lsm_steps"] + 2          # one per date + terminal + final sums
-        else:
+        elif mode == "shm":
             assert res["one_launch_enabled"], "\n".join(logs)                       # no hand-shake ever timed out
             assert res["gbm_lsm_sweep_launches"] == 1 and res["rb_lsm_sweep_launches"] == 1
+        else:   # forced time-out: the void sweep (1 launch) is discarded on BOTH ranks, the per-date kernels answer
+            assert not res["one_launch_enabled"]
+            assert res["gbm_lsm_sweep_launches"] == 1 + JOBS["lsm_steps"] + 2
+            assert res["rb_lsm_sweep_launches"] == JOBS["rb_steps"] + 2              # sticky: no second attempt
     assert ranks[0]["shard"][0] == 0 and ranks[1]["shard"][0] % 2 == 0
     assert ranks[0]["shard"][1] + ranks[1]["shard"][1] == JOBS["rb_paths"]
