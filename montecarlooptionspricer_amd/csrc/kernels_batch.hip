@@ -271,7 +271,8 @@ __global__ __launch_bounds__(256) void k_batch_martingale(BatchArgs a) {
     __shared__ double red[(NM + 1) * 4];
     __shared__ double sm_mom[32];
     __shared__ double sm_coef[16];
-    __shared__ double sm_off;
+    __shared__ double sm_off, sm_primal;
+    __shared__ double sm_ws[lsm_ws_doubles(NB)];
     const BatchRow row = a.rows[blockIdx.x];
     if (!row.valid) return;
     const int n_cols = row.n_steps + 1;
@@ -290,6 +291,7 @@ __global__ __launch_bounds__(256) void k_batch_martingale(BatchArgs a) {
     const bool live = p < a.n_paths;
     const double* col = a.S + (int64_t)blockIdx.x * 256 + p;
     double m[NM + 1];
+    double xs[2] = {0.0, 0.0}, ys[2] = {0.0, 0.0};  // this path's two regression samples (kept for a re-fit)
 #pragma unroll
     for (int q = 0; q <= NM; ++q) m[q] = 0.0;
     if (live) {
@@ -304,9 +306,10 @@ __global__ __launch_bounds__(256) void k_batch_martingale(BatchArgs a) {
         }
         m[NM] = best;
         const int other = (stop + n_cols / 2) % n_cols;
-        const double xs[2] = {col[(int64_t)stop * a.ld], col[(int64_t)other * a.ld]};
-        const double ys[2] = {0.5 * (payoff_of(call, xs[0], row.strike) * dsc[stop]),
-                              0.2 * (payoff_of(call, xs[1], row.strike) * dsc[other])};
+        xs[0] = col[(int64_t)stop * a.ld];
+        xs[1] = col[(int64_t)other * a.ld];
+        ys[0] = 0.5 * (payoff_of(call, xs[0], row.strike) * dsc[stop]);
+        ys[1] = 0.2 * (payoff_of(call, xs[1], row.strike) * dsc[other]);
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const double x = fma(xs[s], invK, -1.0);
@@ -323,20 +326,33 @@ __global__ __launch_bounds__(256) void k_batch_martingale(BatchArgs a) {
     if (threadIdx.x == 0) {
 #pragma unroll
         for (int q = 0; q <= NM; ++q) sm_mom[q] = m[q];
-        lsm_solve_nb<NB>(sm_mom, (double)NB, 0.0, sm_coef);  // (K = 0: the refit of M is not refined, see lsm_solve_nb)
+        sm_primal = m[NM];
+        lsm_solve_nb<NB>(sm_mom, (double)NB, row.strike, sm_coef);
     }
     __syncthreads();
-    const double primal = sm_mom[NM] / (double)a.n_paths;
+    if (sm_coef[LSM_C_REFINE] != 0.0) {  // workgroup-uniform: re-fit about the samples' mean (lsm_solve_nb; MartingaleOptimizationPricer.cpp:166)
+        const double mu = sm_coef[LSM_C_HINT];
+        double mc[NM];
+#pragma unroll
+        for (int q = 0; q < NM; ++q) mc[q] = 0.0;
+        if (live) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) lsm_accumulate_centered<NB>(mc, true, xs[s], ys[s], invK, mu, 1.0);
+        }
+        block_sum<NM, 4>(mc, red);
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int q = 0; q < NM; ++q) sm_mom[q] = mc[q];
+            lsm_solve_centered(sm_mom, NB, mu, row.strike, sm_coef, sm_ws);
+        }
+        __syncthreads();
+    }
+    const double primal = sm_primal / (double)a.n_paths;
     double c[NB];
 #pragma unroll
     for (int q = 0; q < NB; ++q) c[q] = sm_coef[q];
-    auto poly = [&](double S) {
-        const double x = fma(S, invK, -1.0);
-        double v = c[NB - 1];
-#pragma unroll
-        for (int q = NB - 2; q >= 0; --q) v = fma(v, x, c[q]);
-        return v;
-    };
+    const double center = sm_coef[LSM_C_CENTER];
+    auto poly = [&](double S) { return lsm_continuation<NB>(c, center, fma(S, invK, -1.0)); };
     double o[2] = {live ? poly(col[0]) : 0.0, 0.0};
     __syncthreads();  // red is reused
     block_sum<2, 4>(o, red);

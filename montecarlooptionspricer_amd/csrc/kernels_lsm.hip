@@ -113,6 +113,11 @@ struct LsmRefine {
     int64_t n;
     double K, disc;
     int is_call;
+    // MartingaleOptimization's refit (its samples are not a row of the matrix, its driver is on the host anyway):
+    //   request_only: solve the first pass with the refinement test on and leave the request in the coefficient block;
+    //   centered:     the moments are already about `mu`: solve them with lsm_solve_centered.
+    int request_only, centered;
+    double mu;
 };
 
 template <int NB>
@@ -161,12 +166,26 @@ __global__ __launch_bounds__(256) void k_lsm_reduce_solve(const double* partials
         __syncthreads();
     }
     if (!do_solve) return;
+    if (rf.centered) {
+        if (threadIdx.x == 0) {
+            const double* mc = do_reduce ? sm : moments;
+            if (mc[0] >= min_count) {
+                lsm_solve_centered(mc, nb, rf.mu, rf.K, sm_c, sm_ws);
+            } else {  // too few samples: coefficients stay 0 (as in lsm_solve_nb)
+                for (int t = 0; t < LSM_COEF_DOUBLES; ++t) sm_c[t] = 0.0;
+                sm_c[LSM_C_COUNT] = mc[0];
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < LSM_COEF_DOUBLES) coef[threadIdx.x] = sm_c[threadIdx.x];
+        return;
+    }
     if (threadIdx.x == 0) {
-        lsm_solve_one(do_reduce ? sm : moments, nb, min_count, rf.S ? rf.K : 0.0, sm_c);
-        if (!rf.S) sm_c[LSM_C_REFINE] = 0.0;
+        lsm_solve_one(do_reduce ? sm : moments, nb, min_count, (rf.S || rf.request_only) ? rf.K : 0.0, sm_c);
+        if (!rf.S && !rf.request_only) sm_c[LSM_C_REFINE] = 0.0;
     }
     __syncthreads();
-    if (sm_c[LSM_C_REFINE] != 0.0) {  // uniform
+    if (rf.S && sm_c[LSM_C_REFINE] != 0.0) {  // uniform
         const double mu = sm_c[LSM_C_HINT];
         switch (nb) {
             case 1: lsm_refine_block<1>(rf, mu, red, sm); break;
@@ -1036,11 +1055,12 @@ static int run_lsm_coop(mcg_ctx* ctx, const mcg_paths* P, double r, double K, do
 // partials[grid][nm] -> moments (fixed order) -> optional all-reduce -> coefficients in ctx->scalars.
 // Shared by the LSM sweep and the MartingaleOptimization refit.
 int lsm_reduce_allreduce_solve(mcg_ctx* ctx, int grid, int nm, int nb, double min_count, const double* refine_row,
-                               const double* refine_v, int64_t refine_n, double K, double disc, int is_call) {
+                               const double* refine_v, int64_t refine_n, double K, double disc, int is_call, int mo_mode,
+                               double mo_mu) {
     double* moments = ctx->scalars + SC_MOMENTS;
     double* coef = ctx->scalars + SC_COEF;
-    // refinement of an ill-conditioned date (lsm_solve_nb) is single-GPU only: see LsmRefine
-    LsmRefine rf{ctx->allreduce ? nullptr : refine_row, refine_v, refine_n, K, disc, is_call};
+    // refinement of an ill-conditioned date (lsm_solve_nb) inside the solve kernel is single-GPU only: see LsmRefine
+    LsmRefine rf{ctx->allreduce ? nullptr : refine_row, refine_v, refine_n, K, disc, is_call, mo_mode == 1, mo_mode == 2, mo_mu};
     if (ctx->allreduce) {
         {
             TimedLaunch t(ctx, MCG_K_LSM_SOLVE);

@@ -12,6 +12,7 @@
 // the offset, one dual stream.  Two HBM-read streams of the matrix (16 B per path per date); no MFMA.
 // Sharded use: the moments (+ primal sum), the offset sum and the dual sum go through ctx->allreduce.
 #include "devmath.hpp"
+#include "lsm_device.hpp"
 #include "mcg_internal.hpp"
 
 namespace mcg {
@@ -25,8 +26,9 @@ struct MoArgs {
     const double* disc;  // [n_cols] exp(-r min(j dt, maturity))  (PathDiscountFactor, header :46-51)
     double K, invK;
     int is_call;
-    const double* coef;  // device: coef[0..NB) in x = S/K - 1; coef[10] = offset
+    const double* coef;  // device: the coefficient block of the refit (lsm_device.hpp: LSM_C_*): M in y = (S/K - 1) - centre
     double* partials;
+    double center;       // k_mo_primal: the regressor's centre (0 on the first pass, the samples' mean when re-fitted)
 };
 
 // primal scan + regression moments.  partials[NM + 1][grid] (moment-major): NM moments, then the primal sum.
@@ -57,7 +59,7 @@ __global__ __launch_bounds__(256) void k_mo_primal(MoArgs a) {
                               0.2 * (payoff_of(call, xs[1], a.K) * a.disc[other])};
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            const double x = fma(xs[s], a.invK, -1.0);
+            const double x = fma(xs[s], a.invK, -1.0) - a.center;
             double pw = 1.0;
 #pragma unroll
             for (int q = 0; q < 2 * NB - 1; ++q) {
@@ -75,12 +77,8 @@ __global__ __launch_bounds__(256) void k_mo_primal(MoArgs a) {
 }
 
 template <int NB>
-__device__ __forceinline__ double mo_poly(const double (&c)[NB], double S, double invK) {
-    const double x = fma(S, invK, -1.0);
-    double v = c[NB - 1];
-#pragma unroll
-    for (int q = NB - 2; q >= 0; --q) v = fma(v, x, c[q]);
-    return v;
+__device__ __forceinline__ double mo_poly(const double (&c)[NB], double center, double S, double invK) {
+    return lsm_continuation<NB>(c, center, fma(S, invK, -1.0));
 }
 
 // sum_i M(S_i0) -> partials[block][2] (second column unused), :178-183
@@ -90,9 +88,10 @@ __global__ __launch_bounds__(256) void k_mo_offset(MoArgs a) {
     double c[NB];
 #pragma unroll
     for (int q = 0; q < NB; ++q) c[q] = a.coef[q];
+    const double center = a.coef[LSM_C_CENTER];
     double v[2] = {0.0, 0.0};
     for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < a.n; p += (int64_t)gridDim.x * 256)
-        v[0] += mo_poly<NB>(c, a.data[p], a.invK);
+        v[0] += mo_poly<NB>(c, center, a.data[p], a.invK);
     block_sum<2, 4>(v, red);
     if (threadIdx.x == 0) {
         a.partials[2 * (int64_t)blockIdx.x] = v[0];
@@ -108,13 +107,14 @@ __global__ __launch_bounds__(256) void k_mo_dual(MoArgs a, double offset) {
     double c[NB];
 #pragma unroll
     for (int q = 0; q < NB; ++q) c[q] = a.coef[q];
+    const double center = a.coef[LSM_C_CENTER];
     double v[2] = {0.0, 0.0};
     for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < a.n; p += (int64_t)gridDim.x * 256) {
         const double* col = a.data + p;
         double best = 0.0;
         for (int j = 0; j < a.n_dates; ++j) {
             const double S = col[(int64_t)j * a.ld];
-            const double cand = payoff_of(call, S, a.K) * a.disc[j] - (mo_poly<NB>(c, S, a.invK) - offset);
+            const double cand = payoff_of(call, S, a.K) * a.disc[j] - (mo_poly<NB>(c, center, S, a.invK) - offset);
             if (cand > best) best = cand;
         }
         v[0] += best;
@@ -137,9 +137,25 @@ static int run_mo_nb(mcg_ctx* ctx, const MoArgs& a0, int grid, int64_t n_local, 
         TimedLaunch t(ctx, MCG_K_MARTINGALE);
         hipLaunchKernelGGL(k_mo_primal<NB>, dim3(grid), dim3(256), 0, ctx->stream, a);
     }
-    // reduce (+ all-reduce) + solve; fewer than p+1 samples leave M = 0 (:150-153)
-    int rc = lsm_reduce_allreduce_solve(ctx, grid, NM + 1, NB, (double)NB);
+    // reduce (+ all-reduce) + solve; fewer than p+1 samples leave M = 0 (:150-153).  The refit is Eigen's bdcSvd on raw
+    // monomials like LSM's (:166): when the first pass asks for it (lsm_solve_nb: ill-conditioned samples, or an order
+    // whose raw monomials Eigen truncates) the samples are re-accumulated about their mean and solved by
+    // lsm_solve_centered.  The request is read on the host -- this driver synchronises below anyway -- so sharded runs
+    // refine too (every rank sees the same all-reduced moments, hence the same request).
+    int rc = lsm_reduce_allreduce_solve(ctx, grid, NM + 1, NB, (double)NB, nullptr, nullptr, 0, a.K, 1.0, a.is_call, 1, 0.0);
     if (rc) return rc;
+    MCG_HIP(hipMemcpyAsync(ctx->h_scalars + SC_COEF, coef, LSM_COEF_DOUBLES * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    MCG_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->h_scalars[SC_COEF + LSM_C_REFINE] != 0.0) {
+        // (the primal sum of the first pass, behind the moments, is overwritten by an identical one)
+        a.center = ctx->h_scalars[SC_COEF + LSM_C_HINT];
+        {
+            TimedLaunch t(ctx, MCG_K_MARTINGALE);
+            hipLaunchKernelGGL(k_mo_primal<NB>, dim3(grid), dim3(256), 0, ctx->stream, a);
+        }
+        rc = lsm_reduce_allreduce_solve(ctx, grid, NM + 1, NB, (double)NB, nullptr, nullptr, 0, a.K, 1.0, a.is_call, 2, a.center);
+        if (rc) return rc;
+    }
     double s[3];
     {
         TimedLaunch t(ctx, MCG_K_MARTINGALE);
@@ -205,6 +221,7 @@ int run_martingale(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double 
     a.is_call = is_call;
     a.coef = ctx->scalars + SC_COEF;
     a.partials = ctx->partials;
+    a.center = 0.0;
     switch (poly_order + 1) {
         case 1: return run_mo_nb<1>(ctx, a, grid, P->n_paths, max_iterations, price, lower, upper);
         case 2: return run_mo_nb<2>(ctx, a, grid, P->n_paths, max_iterations, price, lower, upper);

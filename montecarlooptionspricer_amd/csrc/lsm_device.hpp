@@ -33,7 +33,7 @@ __host__ __device__ constexpr int lsm_ws_doubles(int nb) { return 7 * nb * nb + 
 // coefficients written here are then the fall-back for callers that cannot refine (sharded runs: a second,
 // data-dependent all-reduce per date cannot be scheduled from the host): cyclic Jacobi eigen-decomposition and a
 // pseudo-inverse with relative eigenvalue cut 1e-12, the projection on the numerical range of the scaled basis.
-// K <= 0 switches the refinement request off (MartingaleOptimization's refit).
+// K <= 0 switches the refinement request off.
 // NB is a template parameter so that every loop unrolls and G, Q live in registers: with a run-time size the
 // arrays go to scratch memory and the (serial, one-thread) solve takes ~20 us instead of ~2.
 template <int NB>

@@ -140,10 +140,12 @@ int finish_sums(mcg_ctx* ctx, int64_t n_blocks, int64_t n_local, double out3[3])
 int run_lsm(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double maturity, double dt, int is_call,
             int poly_order, double* mean, double* std_err);
 
-// refine_row == nullptr: the caller's moments are never re-fitted (MartingaleOptimization's refit)
+// refine_row: the row the moments came from (LSM: a date that asks for it is re-fitted inside the solve kernel).
+// mo_mode (MartingaleOptimization, whose driver re-accumulates on request): 1 = first pass, leave the refinement
+// request in the coefficient block; 2 = the moments are about mo_mu, solve them with lsm_solve_centered.
 int lsm_reduce_allreduce_solve(mcg_ctx* ctx, int grid, int nm, int nb, double min_count, const double* refine_row = nullptr,
                                const double* refine_v = nullptr, int64_t refine_n = 0, double K = 0.0, double disc = 1.0,
-                               int is_call = 0);
+                               int is_call = 0, int mo_mode = 0, double mo_mu = 0.0);
 int run_martingale(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double maturity, double dt, int is_call,
                    int poly_order, int max_iterations, double* price, double* lower, double* upper);
 int run_branching(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double maturity, double dt, int is_call,
