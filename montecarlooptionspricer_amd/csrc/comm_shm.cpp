@@ -82,7 +82,7 @@ bool shm_barrier(ShmComm* c) {
 int shm_allreduce(void* user, double* buf, int count, void* stream) {
     mcg_ctx* ctx = (mcg_ctx*)user;
     ShmComm* c = ctx->shm;
-    if (!c || count < 0 || count > 32) {
+    if (!c || count < 0 || count > 31) {  // (entry 31 of a rank's slot row carries shm_sum_flag's integer)
         set_error("shared-memory all-reduce: bad count %d", count);
         return 1;
     }
