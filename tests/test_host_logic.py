@@ -150,7 +150,11 @@ def test_committed_c5_bench_lines():
     assert a["config"]["collective"] == "none" and b["config"]["collective"] == "rccl"
     assert a["roofline"]["lsm"]["sweep_launches_per_pass"] == 1 and b["roofline"]["lsm"]["sweep_launches_per_pass"] == 254
     assert abs(a["parity"]["price"] - b["parity"]["price"]) <= 1e-9 * a["parity"]["price"]
-    for j in (a, b):
+    c = json.load(open(os.path.join(root, "profiles", "r02_bench_c5_shm_n1.json")))   # shared-memory communicator, world size 1
+    assert c["config"]["collective"] == "shm" and c["roofline"]["lsm"]["sweep_launches_per_pass"] == 1
+    assert abs(c["parity"]["price"] - a["parity"]["price"]) <= 1e-9 * a["parity"]["price"]
+    assert a["ms_per_step"] <= c["ms_per_step"] < b["ms_per_step"]        # the in-kernel exchange costs little, the per-date path a lot
+    for j in (a, b, c):
         assert j["config"]["paths_per_gpu"] == 8_000_000 and j["config"]["time_steps"] == 252
         assert abs(j["value"] - j["config"]["global_paths"] / (j["ms_per_step"] * 1e-3) / 1e6) < 1e-6 * j["value"]
 
