@@ -1,5 +1,6 @@
 #!/bin/bash
-# GPU box: tests, default bench, C5 bench (1 rank with the built-in RCCL communicator), 2-rank gloo rehearsal of C5.
+# GPU box (gpurun): the GPU tests, the default bench line, the C5 lines (no collective, RCCL and shared memory at world size 1)
+# and a two-rank rehearsal of C5 on the one GPU.  Output in gpurun_out/r2a_*.
 set -o pipefail
 export TMPDIR=/tmp
 mkdir -p gpurun_out
