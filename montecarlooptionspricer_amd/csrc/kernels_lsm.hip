@@ -296,6 +296,10 @@ struct LsmCoopArgs {
     // nullptr on a single GPU
     double* mbox;
     int mb_ranks, mb_rank;
+    // k_lsm_coop, small grids on one GPU: every workgroup gathers ALL partial moments itself and solves redundantly
+    // (one trip through the coherence point per date instead of two): gather[round][NM][gridDim.x], sentinel-filled,
+    // every slot written once per sweep.  nullptr: workgroup 0 reduces, solves and publishes (above).
+    double* gather;
 };
 
 __device__ __forceinline__ bool lsm_is_sentinel(double v) {
@@ -378,12 +382,14 @@ __device__ __forceinline__ void lsm_node_allreduce(const LsmCoopArgs& a, int rou
 // centered: this round carries the moments of a refinement pass about `mu` (lsm_solve_nb asked for it on the previous
 // round of the same date); ws = LDS workspace of lsm_solve_centered; round = exchange counter of this sweep (the slot
 // of the node mailbox when the sweep is sharded over the GPUs of a node).
-template <int NB>
+// GATHER: called by EVERY workgroup on the round's own slots of a.gather: nothing is recycled and nothing published --
+// each workgroup ends with the same coefficient block in its own sm_coef (same values, same summation order).
+template <int NB, bool GATHER = false>
 __device__ __forceinline__ void lsm_reduce_solve_publish(const LsmCoopArgs& a, unsigned G, int parity, bool& gave_up, double* sm_mom,
                                                          double* sm_coef, bool centered, double mu, double* ws, int round) {
     constexpr int NM = 3 * NB - 1;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    double* part = a.partials + (int64_t)parity * NM * G;
+    double* part = GATHER ? a.gather + (int64_t)round * NM * G : a.partials + (int64_t)parity * NM * G;
     double* coef_now = a.coef + 16 * parity;
     for (int t0 = wave; t0 < NM; t0 += 8) {
         const int t1 = t0 + 4;
@@ -420,8 +426,10 @@ __device__ __forceinline__ void lsm_reduce_solve_publish(const LsmCoopArgs& a, u
             if (b < G) {
                 sum0 += v0[k];
                 sum1 += v1[k];
-                lsm_st_shared(slot0 + b, lsm_sentinel());  // recycled two dates from now
-                if (two) lsm_st_shared(slot1 + b, lsm_sentinel());
+                if (!GATHER) {
+                    lsm_st_shared(slot0 + b, lsm_sentinel());  // recycled two dates from now
+                    if (two) lsm_st_shared(slot1 + b, lsm_sentinel());
+                }
             }
         }
         sum0 = wave_sum(sum0);
@@ -430,6 +438,15 @@ __device__ __forceinline__ void lsm_reduce_solve_publish(const LsmCoopArgs& a, u
             sm_mom[t0] = sum0;
             if (two) sm_mom[t1] = sum1;
         }
+    }
+    if (GATHER) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            if (centered) lsm_solve_centered(sm_mom, NB, mu, a.K, sm_coef, ws);
+            else lsm_solve_nb<NB>(sm_mom, 1.0, a.K, sm_coef);
+        }
+        __syncthreads();
+        return;
     }
     // all partials of this date are in: every workgroup is past the previous date's coefficients
     if (threadIdx.x < LSM_COEF_DOUBLES) lsm_st_shared(a.coef + 16 * (parity ^ 1) + threadIdx.x, lsm_sentinel());
@@ -470,6 +487,18 @@ template <int NB, class F>
 __device__ __forceinline__ void lsm_exchange(const LsmCoopArgs& a, double (&m)[3 * NB - 1], int parity, bool& gave_up,
                                              double* red, double* sm_mom, double* sm_coef, bool centered, double mu, double* ws,
                                              int round, F&& after_publish) {
+    if (a.gather) {  // (uniform) every workgroup gathers, reduces and solves by itself
+        constexpr int NM = 3 * NB - 1;
+        block_sum<NM, 4>(m, red);
+        if (threadIdx.x == 0) {
+            double* slot = a.gather + (int64_t)round * NM * gridDim.x;
+#pragma unroll
+            for (int t = 0; t < NM; ++t) lsm_st_shared(slot + (int64_t)t * gridDim.x + blockIdx.x, m[t]);
+        }
+        after_publish();
+        lsm_reduce_solve_publish<NB, true>(a, gridDim.x, parity, gave_up, sm_mom, sm_coef, centered, mu, ws, round);
+        return;
+    }
     lsm_publish_partials<NB>(a, m, gridDim.x, blockIdx.x, parity, red);
     after_publish();
     if (blockIdx.x == 0) lsm_reduce_solve_publish<NB>(a, gridDim.x, parity, gave_up, sm_mom, sm_coef, centered, mu, ws, round);
@@ -988,8 +1017,15 @@ static int run_lsm_coop(mcg_ctx* ctx, const mcg_paths* P, double r, double K, do
     }
     if (!use) return MCG_OK;
     // buffer: {sum, sum^2} per contributing workgroup | [2][nm][workers] moment slots | [2][16] coefficient slots
+    //         | (gather mode) [rounds][nm][grid] moment slots, written once each
+    // Gather mode: k_lsm_coop<NB, 16> on one GPU.  Measured on the 50-date sweep (ms, reducer / gather): 600k paths
+    // 0.535 / 0.430, 1M 0.592 / 0.455, 1.8M 0.780 / 0.696 -- one trip through the coherence point per date instead of two;
+    // with 4 paths per thread (three workgroups per CU, <= 0.5M paths) the reducer is the faster one (250k: 0.380 / 0.486).
+    static const bool gather_off = std::getenv("MCG_LSM_NO_GATHER") != nullptr;  // experiments
+    const bool gather = !use->exact && use->ppt == 16 && !mbox && !gather_off;
     const size_t n_slots = 2 * (size_t)nm * workers + 32;
-    int rc = ensure_cap(ctx, &ctx->partials, &ctx->partials_cap, 2 * (size_t)workers + n_slots);
+    const size_t n_gather = gather ? (size_t)rounds_needed * nm * grid : 0;
+    int rc = ensure_cap(ctx, &ctx->partials, &ctx->partials_cap, 2 * (size_t)workers + n_slots + n_gather);
     if (rc) return rc;
     LsmCoopArgs a;
     a.data = P->data;
@@ -1012,9 +1048,10 @@ static int run_lsm_coop(mcg_ctx* ctx, const mcg_paths* P, double r, double K, do
     a.mbox = mbox;
     a.mb_ranks = shm_n_ranks(ctx);
     a.mb_rank = shm_rank(ctx);
+    a.gather = gather ? a.coef + 32 : nullptr;
     a.spin_limit = LSM_SPIN_LIMIT;
     if (const char* e = std::getenv("MCG_LSM_SPIN_LIMIT")) a.spin_limit = (unsigned)std::strtoul(e, nullptr, 10);
-    MCG_HIP(hipMemsetD32Async((hipDeviceptr_t)a.partials, (int)LSM_SENTINEL32, 2 * n_slots, ctx->stream));
+    MCG_HIP(hipMemsetD32Async((hipDeviceptr_t)a.partials, (int)LSM_SENTINEL32, 2 * (n_slots + n_gather), ctx->stream));
     MCG_HIP(hipMemsetAsync(a.timeout, 0, sizeof(unsigned), ctx->stream));
     if (mbox) {  // this rank's mailbox rows hold the reserved NaN again, and so do everybody else's, before anyone launches
         rc = shm_arm_mailbox(ctx, rounds_needed, ((uint64_t)LSM_SENTINEL32 << 32) | LSM_SENTINEL32);
