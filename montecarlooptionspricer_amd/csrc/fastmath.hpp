@@ -206,9 +206,8 @@ __device__ __forceinline__ LogSplit log_split(double u) {
     return s;
 }
 
-__device__ __forceinline__ double neg2log(double u, const double2* tab) {
-    const LogSplit sp = log_split(u);
-    const double2 e = tab[sp.idx];
+// (split, table entry) -> -2 ln u
+__device__ __forceinline__ double neg2log_entry(const LogSplit& sp, const double2 e) {
     const double r = __builtin_fma(sp.z, e.x, -1.0);
     double q = 0x1.24940e22d9958p-3;
     q = fma_sc(q, r, -0x1.555752f357b5cp-3);
@@ -220,6 +219,10 @@ __device__ __forceinline__ double neg2log(double u, const double2* tab) {
     // -2 ln u = -2 k ln2 + (-2 ln c) - 2 log1p(r)
     const double base = __builtin_fma((double)sp.k, -0x1.62e42fefa39efp+0, e.y);
     return __builtin_fma(-2.0, l1p, base);
+}
+__device__ __forceinline__ double neg2log(double u, const double2* tab) {
+    const LogSplit sp = log_split(u);
+    return neg2log_entry(sp, tab[sp.idx]);
 }
 
 // vol^2 * (-2 ln u): the same evaluation with the scale folded into its constants -- the table's second column is
@@ -256,8 +259,17 @@ __device__ __forceinline__ double sqrt_pos(double x) {
 // (0, 0.01228).  (cos, sin)(2 pi i/512) come from a 512-entry LDS table (correctly rounded),
 // sin/cos(delta) from 3-term series (truncation 8e-18 / 1e-20), combined by the angle-addition
 // formulas: 13 fp64 instructions and no octant logic.
-__device__ __forceinline__ void sincos_table(uint32_t wb, const double2* sc_tab, double& c_out, double& s_out) {
-    const double2 e = sc_tab[wb >> 23];
+// the table-independent half: (cos, sin)(delta)
+__device__ __forceinline__ void sincos_small(uint32_t wb, double& cd_out, double& sd_out) {
+    const double delta = __builtin_fma((double)((wb >> 8) & 0x7FFFu), 0x1.921fb54442d18p-22, 0x1.921fb54442d18p-23);
+    const double d2 = delta * delta;
+    const double ts = __builtin_fma(d2, 0x1.1111111111111p-7, -0x1.5555555555555p-3);  // 1/120, -1/6
+    sd_out = __builtin_fma(delta * d2, ts, delta);
+    double tc = __builtin_fma(d2, -0x1.6c16c16c16c17p-10, 0x1.5555555555555p-5);        // -1/720, 1/24
+    tc = __builtin_fma(tc, d2, -0.5);
+    cd_out = __builtin_fma(tc, d2, 1.0);
+}
+__device__ __forceinline__ void sincos_entry(uint32_t wb, const double2 e, double& c_out, double& s_out) {
     const double delta = __builtin_fma((double)((wb >> 8) & 0x7FFFu), 0x1.921fb54442d18p-22, 0x1.921fb54442d18p-23);
     const double d2 = delta * delta;
     const double ts = __builtin_fma(d2, 0x1.1111111111111p-7, -0x1.5555555555555p-3);  // 1/120, -1/6
@@ -267,6 +279,9 @@ __device__ __forceinline__ void sincos_table(uint32_t wb, const double2* sc_tab,
     const double cd = __builtin_fma(tc, d2, 1.0);
     c_out = __builtin_fma(e.x, cd, -(e.y * sd));
     s_out = __builtin_fma(e.y, cd, e.x * sd);
+}
+__device__ __forceinline__ void sincos_table(uint32_t wb, const double2* sc_tab, double& c_out, double& s_out) {
+    sincos_entry(wb, sc_tab[wb >> 23], c_out, s_out);
 }
 
 // One Box-Muller pair from 64 Philox bits (philox.hpp contract).
@@ -301,11 +316,29 @@ __device__ __forceinline__ void box_muller_pair_affine_scaled(uint32_t wa, uint3
 }
 
 // One Philox block -> four N(0,1) deviates.
+// EAGER: request all four table entries before any is used (costs ~12 registers for the time of the lookups).
+template <bool EAGER = false>
 __device__ __forceinline__ void normal_quad_fast(uint32_t k0, uint32_t k1, uint64_t path, uint32_t block,
                                                  uint32_t stream, const Tables* tab, double (&z)[4]) {
     const Philox4 w = philox4x32_10((uint32_t)path, (uint32_t)(path >> 32), block, stream, k0, k1);
-    box_muller_pair(w.w0, w.w1, tab, z[0], z[1]);
-    box_muller_pair(w.w2, w.w3, tab, z[2], z[3]);
+    if constexpr (!EAGER) {
+        box_muller_pair(w.w0, w.w1, tab, z[0], z[1]);
+        box_muller_pair(w.w2, w.w3, tab, z[2], z[3]);
+        return;
+    }
+    // All four table entries are requested before any of them is used: a lookup is ~100 cycles of LDS latency, and a
+    // kernel at two waves per SIMD has little else to issue meanwhile (requested one by one, each was waited for).
+    const LogSplit s0 = log_split(radius_u01(w.w0, w.w1)), s1 = log_split(radius_u01(w.w2, w.w3));
+    double2 a0 = tab->sincos[w.w1 >> 23], a1 = tab->sincos[w.w3 >> 23], l0 = tab->log[s0.idx], l1 = tab->log[s1.idx];
+    double cd0, sd0, cd1, sd1;  // meanwhile: the halves that need no table
+    sincos_small(w.w1, cd0, sd0);
+    sincos_small(w.w3, cd1, sd1);
+    __builtin_amdgcn_sched_barrier(0);
+    const double r0 = sqrt_pos(neg2log_entry(s0, l0)), r1 = sqrt_pos(neg2log_entry(s1, l1));
+    z[0] = r0 * __builtin_fma(a0.x, cd0, -(a0.y * sd0));
+    z[1] = r0 * __builtin_fma(a0.y, cd0, a0.x * sd0);
+    z[2] = r1 * __builtin_fma(a1.x, cd1, -(a1.y * sd1));
+    z[3] = r1 * __builtin_fma(a1.y, cd1, a1.x * sd1);
 }
 
 // Cooperative copy of both tables (global, 10 KiB) into LDS; call before the first normal and

@@ -117,6 +117,8 @@ __global__ __launch_bounds__(256) void k_batch_paths(BatchArgs a, int blocks_per
     g.K = 0.0;
     g.is_call = 0;
     g.partials = nullptr;
+    g.n_blocks = 0;
+    g.ticket = nullptr;
     double la, lb;
     bool va, vb, lead;
     switch (row.M) {  // wave-uniform

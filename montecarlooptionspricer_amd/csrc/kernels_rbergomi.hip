@@ -5,20 +5,31 @@
 // Roofline: like the GBM kernel it is issue-bound on fp64 VALU work (per path and step: one volatility
 // normal, one price normal, two exponentials, log2(Mz) half-butterflies) while writing 8 (n_steps+1)
 // bytes per path; DESIGN.md section 5 has the instruction budget and the measurements.
+#include <algorithm>
+#include <cstdlib>
+
 #include "mcg_internal.hpp"
 #include "rbergomi_device.hpp"
 
 namespace mcg {
 
+// this lane's payoff sums {sum, sum of squares} over the shares its workgroup worked through
 template <bool PAYOFF>
-__device__ __forceinline__ void rb_finish(const RbArgs& a, double end_a, double end_b, bool live_a, bool live_b,
-                                          bool lead) {
+__device__ __forceinline__ void rb_add_payoff(const RbArgs& a, double end_a, double end_b, bool live_a, bool live_b,
+                                              bool lead, double (&v)[2]) {
     if (PAYOFF) {
-        __shared__ double red[2 * 4];
         const bool call = a.is_call != 0;
         const double pay_a = (lead && live_a) ? payoff_of(call, end_a, a.K) : 0.0;
         const double pay_b = (lead && live_b) ? payoff_of(call, end_b, a.K) : 0.0;
-        double v[2] = {pay_a + pay_b, pay_a * pay_a + pay_b * pay_b};
+        v[0] += pay_a + pay_b;
+        v[1] += pay_a * pay_a + pay_b * pay_b;
+    }
+}
+
+template <bool PAYOFF>
+__device__ __forceinline__ void rb_finish(const RbArgs& a, double (&v)[2]) {
+    if (PAYOFF) {
+        __shared__ double red[2 * 4];
         block_sum<2, 4>(v, red);
         if (threadIdx.x == 0) {
             a.partials[2 * (int64_t)blockIdx.x] = v[0];
@@ -36,10 +47,34 @@ template <int LG, int LT, bool PAYOFF>
 __global__ __launch_bounds__(256, RB_WAVES) void k_rbergomi_fft(RbArgs a) {
     extern __shared__ double smem[];
     __shared__ fm::Tables tabs;
-    double la, lb;
-    bool va, vb, lead;
-    rb_generate_fft<LG, LT>(a, (int64_t)blockIdx.x, smem, &tabs, la, lb, va, vb, lead);
-    rb_finish<PAYOFF>(a, la, lb, va, vb, lead);
+    // Persistent workgroups: the LDS tables (amplitudes, compensator, twiddles, the normal generator's tables) are
+    // staged once, then the workgroup takes every gridDim.x-th share of 4 x 64/G pairs.
+    const RbLds L = rb_stage_lds(a, smem, &tabs);
+    // Shares are handed out dynamically (the first gridDim.x by blockIdx, the rest from a ticket counter): workgroups
+    // do not all run at the same speed, and a fixed stride leaves the fast ones idle at the end.  Thread 0 draws a
+    // ticket one trip before it publishes it (so the atomic's latency is never waited for) into one of two alternating
+    // LDS slots; the barriers inside a share order a slot's write against the reads of the trip before.
+    __shared__ long long next_share[2];
+    double v[2] = {0.0, 0.0};
+    long long share = blockIdx.x;
+    unsigned long long drawn = 0;  // thread 0: the ticket of the trip after the current one
+    if (threadIdx.x == 0) drawn = atomicAdd(a.ticket, 1ull);
+    for (int trip = 0; share < a.n_blocks; ++trip) {
+        if (threadIdx.x == 0) {
+            next_share[trip & 1] = (long long)(drawn + gridDim.x);
+            drawn = atomicAdd(a.ticket, 1ull);
+        }
+        double la, lb;
+        bool va, vb, lead;
+        // (opaque per trip: hoisting the ~40 lane-derived indices and addresses out of the loop costs registers this
+        // kernel does not have -- it spilled)
+        int tid = (int)threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        rb_fft_block<LG, LT>(a, L, share, tid, &tabs, la, lb, va, vb, lead);
+        rb_add_payoff<PAYOFF>(a, la, lb, va, vb, lead, v);
+        share = next_share[trip & 1];  // written before this trip's first barrier
+    }
+    rb_finish<PAYOFF>(a, v);
 }
 
 template <bool PAYOFF>
@@ -49,7 +84,9 @@ __global__ __launch_bounds__(256) void k_rbergomi_small(RbArgs a) {
     double la, lb;
     bool va, vb, lead;
     rb_generate_small(a, (int64_t)blockIdx.x, smem, &tabs, la, lb, va, vb, lead);
-    rb_finish<PAYOFF>(a, la, lb, va, vb, lead);
+    double v[2] = {0.0, 0.0};
+    rb_add_payoff<PAYOFF>(a, la, lb, va, vb, lead, v);
+    rb_finish<PAYOFF>(a, v);
 }
 
 // gfx950 allows a workgroup up to 160 KB of LDS, but beyond 64 KB of dynamic LDS the kernel has to opt in
@@ -75,6 +112,16 @@ static void launch_fft(mcg_ctx* ctx, const RbArgs& a, dim3 g, dim3 b, size_t sme
 }
 #undef MCG_RB_LAUNCH
 
+// workgroups per CU of the persistent FFT kernels (MCG_RB_GRID_PER_CU overrides, for timing studies)
+static int rb_grid_per_cu() {
+    static const int v = [] {
+        const char* e = std::getenv("MCG_RB_GRID_PER_CU");
+        const int n = e ? std::atoi(e) : 0;
+        return n > 0 ? n : RB_WAVES;
+    }();
+    return v;
+}
+
 template <bool PAYOFF>
 static void launch_variant(mcg_ctx* ctx, const RbArgs& a, unsigned grid, size_t smem) {
     const dim3 g(grid), b(256);
@@ -99,11 +146,13 @@ int launch_rbergomi(mcg_ctx* ctx, mcg_paths* P, uint64_t seed, double S0, double
     const int ppb = rb_pairs_per_block(M);
     const int64_t n_blocks = (n_pairs + ppb - 1) / ppb;
     if (n_blocks > 0x7fffffffLL) return fail(MCG_ERR_INVALID, "n_paths too large for one launch");
+    // FFT variants: persistent workgroups, RB_WAVES per CU (what their registers admit), each striding over the shares
+    const int64_t grid = M < 32 ? n_blocks : std::min<int64_t>(n_blocks, (int64_t)ctx->n_cus * rb_grid_per_cu());
 
     rc = ensure_cap(ctx, &ctx->weights, &ctx->weights_cap, (size_t)M + (size_t)P->n_steps);
     if (rc) return rc;
     if (want_payoff) {
-        rc = ensure_cap(ctx, &ctx->partials, &ctx->partials_cap, (size_t)(2 * n_blocks));
+        rc = ensure_cap(ctx, &ctx->partials, &ctx->partials_cap, (size_t)(2 * grid));
         if (rc) return rc;
     }
     MCG_HIP(hipMemcpyAsync(ctx->weights, amp.data(), (size_t)M * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
@@ -133,15 +182,18 @@ int launch_rbergomi(mcg_ctx* ctx, mcg_paths* P, uint64_t seed, double S0, double
     a.K = K;
     a.is_call = is_call;
     a.partials = ctx->partials;
+    a.n_blocks = n_blocks;
+    a.ticket = reinterpret_cast<unsigned long long*>(ctx->scalars + SC_TICKET);
+    if (M >= 32) MCG_HIP(hipMemsetAsync(a.ticket, 0, sizeof(unsigned long long), ctx->stream));
     const size_t smem = rb_smem_bytes(M, P->n_steps);
     {
         TimedLaunch t(ctx, MCG_K_RBERGOMI);
-        if (want_payoff) launch_variant<true>(ctx, a, (unsigned)n_blocks, smem);
-        else launch_variant<false>(ctx, a, (unsigned)n_blocks, smem);
+        if (want_payoff) launch_variant<true>(ctx, a, (unsigned)grid, smem);
+        else launch_variant<false>(ctx, a, (unsigned)grid, smem);
     }
     MCG_HIP(hipGetLastError());
     if (want_payoff) {
-        rc = finish_sums(ctx, n_blocks, P->n_paths, P->sums);
+        rc = finish_sums(ctx, grid, P->n_paths, P->sums);
         if (rc) return rc;
         P->has_sums = true;
         P->sums_K = K;

@@ -104,6 +104,7 @@ constexpr int SC_MOMENTS = 8;  // [8..8+26) LSM moments (<= 3*8+2)
 constexpr int SC_COEF = 40;    // [40..53) the LSM coefficient block of the current date (lsm_device.hpp: LSM_C_*)
 constexpr int SC_FINAL = 64;   // [64..67) LSM final sums
 constexpr int SC_BARRIER = 72; // [72] 32-bit timeout flag of k_lsm_coop's hand-shake
+constexpr int SC_TICKET = 80;  // [80] 64-bit share ticket of the persistent rBergomi generator (zeroed before each launch)
 
 int pool_alloc(mcg_ctx* ctx, size_t bytes, void** out);
 void pool_release(mcg_ctx* ctx, void* ptr, size_t bytes);

@@ -43,6 +43,8 @@ struct RbArgs {
     double K;
     int is_call;
     double* partials;
+    unsigned long long* ticket;  // shares handed out beyond the first gridDim.x (zero at launch)
+    int64_t n_blocks;  // workgroup shares of the launch (rb_pairs_per_block pairs each); a workgroup takes every gridDim.x-th
 };
 
 // Transform points per lane = 4 * 2^LT.  16 points (64 data VGPRs) keep the kernel at 2 waves/SIMD with no
@@ -59,6 +61,10 @@ __host__ __device__ inline int rb_pairs_per_block(int M) { return M < 32 ? 256 :
 // instead of one 16-byte piece per lane.
 #ifndef RB_NBUF
 #define RB_NBUF 2
+#endif
+// the spectrum's normals request their table entries four at a time (registers are not short in that phase)
+#ifndef RB_EAGER_SPECTRUM
+#define RB_EAGER_SPECTRUM true
 #endif
 __host__ __device__ inline int rb_stage_bufs(int M) { return rb_log_tiles(M) == 2 ? RB_NBUF : 1; }
 __host__ __device__ inline size_t rb_stage_units(int M) {  // double2 units per buffer
@@ -183,17 +189,18 @@ __device__ __forceinline__ constexpr int rb_rev(int t) {
 // One workgroup's share: 4 waves x (64 >> LG) path pairs, 4 * 2^LT transform points per lane
 // (Mz = 2^(2 + LG + LT)).  Returns through end_a/end_b the final prices S_T of this lane's pair (the stored values);
 // lead = this lane is the one lane (g == 0) that reports the pair's payoff.
+// The LDS tables (L, tabs) are staged by the caller: once per workgroup, however many shares it works through.
+// tid = threadIdx.x (a parameter so that a looping caller can keep the lane-derived indices out of its loop-invariant set).
 template <int LG, int LT>
-__device__ __forceinline__ void rb_generate_fft(const RbArgs& a, int64_t block_index, double* smem, fm::Tables* tabs,
-                                                double& end_a, double& end_b, bool& live_a, bool& live_b, bool& lead) {
+__device__ __forceinline__ void rb_fft_block(const RbArgs& a, const RbLds& L, int64_t block_index, int tid,
+                                             fm::Tables* tabs, double& end_a, double& end_b, bool& live_a, bool& live_b, bool& lead) {
     constexpr int G = 1 << LG;   // lanes per pair
     constexpr int P = 64 >> LG;  // pairs per wave
     constexpr int NT = 1 << LT;  // 4-step tiles per lane
     constexpr int PW = 4 * P;    // pairs per workgroup
     constexpr int RS = PW + 1;   // staging row stride in 16-byte units (one unit of padding)
     constexpr int NBUF = LT == 2 ? RB_NBUF : 1;
-    const RbLds L = rb_stage_lds(a, smem, tabs);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = tid & 63, wave = tid >> 6;
     const int g = lane >> (6 - LG), c = lane & (P - 1);
     const int64_t q = block_index * (4 * P) + wave * P + c;  // pair index within the launch
     const int64_t col_a = 2 * q;
@@ -212,7 +219,7 @@ __device__ __forceinline__ void rb_generate_fft(const RbArgs& a, int64_t block_i
 #pragma unroll
         for (int bq = 0; bq < NT / 2; ++bq) {
             double z[4];
-            fm::normal_quad_fast(a.k0, a.k1, pair_id, (uint32_t)((k_base >> 1) + bq), STREAM_VOL, tabs, z);
+            fm::normal_quad_fast<RB_EAGER_SPECTRUM>(a.k0, a.k1, pair_id, (uint32_t)((k_base >> 1) + bq), STREAM_VOL, tabs, z);
             const double a0 = L.amp[k_base + 2 * bq], a1 = L.amp[k_base + 2 * bq + 1];
             const int t0 = rb_rev<LT>(2 * bq), t1 = rb_rev<LT>(2 * bq + 1);
             xr[t0 * 4 + v] = a0 * z[0];
@@ -338,7 +345,7 @@ __device__ __forceinline__ void rb_generate_fft(const RbArgs& a, int64_t block_i
     if (lead) rb_store_pair(col, a.S0, a.S0, true, true);
     double S_a = a.S0, S_b = a.S0;  // price at the start of the tile (the same bits in every lane of the pair)
     // this thread's part of every tile's write-out: rows wr_row + i G (i < 4) of the tile, pair wr_pc of the workgroup
-    const int wr_row = (int)threadIdx.x / PW, wr_pc = (int)threadIdx.x % PW;
+    const int wr_row = tid / PW, wr_pc = tid % PW;
     double* wr_out = a.out + 2 * (block_index * PW + wr_pc) + (int64_t)(wr_row + 1) * a.ld;
     const double sq_xi_dt = sqrt(a.xi) * a.sqdt;  // sqrt(xi dt)
 #pragma unroll
@@ -451,6 +458,15 @@ __device__ __forceinline__ void rb_generate_fft(const RbArgs& a, int64_t block_i
     }
     end_a = S_a;
     end_b = S_b;
+    // an odd number of live tiles leaves the last tile's reads and the next share's first writes on the same buffer
+    if (NBUF == 2 && (((a.n_steps + 4 * G - 1) / (4 * G)) & 1)) __syncthreads();
+}
+
+template <int LG, int LT>
+__device__ __forceinline__ void rb_generate_fft(const RbArgs& a, int64_t block_index, double* smem, fm::Tables* tabs,
+                                                double& end_a, double& end_b, bool& live_a, bool& live_b, bool& lead) {
+    const RbLds L = rb_stage_lds(a, smem, tabs);
+    rb_fft_block<LG, LT>(a, L, block_index, (int)threadIdx.x, tabs, end_a, end_b, live_a, live_b, lead);
 }
 
 // Mz < 32 (at most 16 steps): one pair per lane, the transform evaluated directly.
