@@ -70,7 +70,11 @@ __global__ __launch_bounds__(256, RB_WAVES) void k_rbergomi_fft(RbArgs a) {
         // kernel does not have -- it spilled)
         int tid = (int)threadIdx.x;
         asm volatile("" : "+v"(tid));
-        rb_fft_block<LG, LT>(a, L, share, tid, &tabs, la, lb, va, vb, lead);
+        // (likewise the two dozen wave-uniform conditions and strides derived from n_steps and ld: hoisted, they overflow
+        // the scalar registers and come back through v_readlane on every trip; recomputed, they are a few s_cmp each)
+        RbArgs b = a;
+        asm volatile("" : "+s"(b.n_steps), "+s"(b.ld));
+        rb_fft_block<LG, LT>(b, L, share, tid, &tabs, la, lb, va, vb, lead);
         rb_add_payoff<PAYOFF>(a, la, lb, va, vb, lead, v);
         share = next_share[trip & 1];  // written before this trip's first barrier
     }

@@ -62,18 +62,23 @@ __host__ __device__ inline int rb_pairs_per_block(int M) { return M < 32 ? 256 :
 #ifndef RB_NBUF
 #define RB_NBUF 2
 #endif
-// the spectrum's normals request their table entries four at a time (registers are not short in that phase)
+// the normals of a Philox block request their four table entries together, then compute (fm::normal_quad_fast<true>;
+// false = one lookup at a time, 12 registers fewer)
 #ifndef RB_EAGER_SPECTRUM
 #define RB_EAGER_SPECTRUM true
+#endif
+#ifndef RB_EAGER_PRICE
+#define RB_EAGER_PRICE true
 #endif
 __host__ __device__ inline int rb_stage_bufs(int M) { return rb_log_tiles(M) == 2 ? RB_NBUF : 1; }
 __host__ __device__ inline size_t rb_stage_units(int M) {  // double2 units per buffer
     return M < 32 ? 0 : (size_t)(M >> rb_log_tiles(M)) * (size_t)(rb_pairs_per_block(M) + 1);
 }
 
-// LDS carve-up shared by all variants: amp[M] | comp[n_steps] | twiddle (cos, sin)(2 pi q / M), q < max(M/2, 1) | staging
+// LDS carve-up shared by all variants: amp[M] | comp[max(M, n_steps)], zero beyond n_steps | twiddle (cos, sin)(2 pi q / M), q < max(M/2, 1) | staging
 __host__ __device__ inline size_t rb_smem_bytes(int M, int n_steps) {
-    const size_t head = (size_t)M + n_steps + ((M + n_steps) & 1);
+    const size_t nc = (size_t)(n_steps > M ? n_steps : M);
+    const size_t head = (size_t)M + nc + ((M + nc) & 1);
     return (head + 2 * (size_t)(M / 2 + 1) + 2 * rb_stage_bufs(M) * rb_stage_units(M)) * sizeof(double);
 }
 
@@ -88,9 +93,11 @@ __device__ __forceinline__ RbLds rb_stage_lds(const RbArgs& a, double* smem, fm:
     const int M = a.M;
     double* amp = smem;
     double* comp = smem + M;
-    double2* tw = reinterpret_cast<double2*>(smem + M + a.n_steps + ((M + a.n_steps) & 1));  // 16-B aligned
+    const int nc = a.n_steps > M ? a.n_steps : M;  // (n_steps <= M except in the direct variant, M < 32)
+    double2* tw = reinterpret_cast<double2*>(smem + M + nc + ((M + nc) & 1));  // 16-B aligned
     for (int i = threadIdx.x; i < M; i += blockDim.x) amp[i] = a.amp[i];
-    for (int i = threadIdx.x; i < a.n_steps; i += blockDim.x) comp[i] = a.comp[i];
+    // zero beyond the grid: the FFT variants step through whole tiles, and a step that does not exist must stay finite
+    for (int i = threadIdx.x; i < nc; i += blockDim.x) comp[i] = i < a.n_steps ? a.comp[i] : 0.0;
     for (int q = threadIdx.x; q < M / 2; q += blockDim.x) {
         double s, c;
         sincospi(2.0 * (double)q / (double)M, &s, &c);
@@ -348,31 +355,42 @@ __device__ __forceinline__ void rb_fft_block(const RbArgs& a, const RbLds& L, in
     const int wr_row = tid / PW, wr_pc = tid % PW;
     double* wr_out = a.out + 2 * (block_index * PW + wr_pc) + (int64_t)(wr_row + 1) * a.ld;
     const double sq_xi_dt = sqrt(a.xi) * a.sqdt;  // sqrt(xi dt)
+    const double neg_half_xi_dt = -0.5 * a.xi * a.dt, r_dt = a.r * a.dt;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         if (((t * G) << 2) < a.n_steps) {  // wave-uniform: the tile has at least one live step
             const int nl = ((t * G + g) << 2);
             double2* stage = L.stage + (NBUF == 2 ? (t & 1) * (4 * G * RS) : 0);
-            double za[4], zb[4];  // steps nl..nl+3 are Philox block nl/4 of each path's price stream
-            fm::normal_quad_fast(a.k0, a.k1, id_a, (uint32_t)(nl >> 2), STREAM_PRICE, tabs, za);
-            fm::normal_quad_fast(a.k0, a.k1, id_b, (uint32_t)(nl >> 2), STREAM_PRICE, tabs, zb);
-            double ia[4], ib[4], big = 0.0;
+            // Everything below works in place on the tile's eight transform values (xr = path A, xi = path B), so that the
+            // tile adds no long-lived registers to the 64 of the transform: first e^{(X + comp)/2} (sqrt(v) = sqrt(xi)
+            // times it: one exponential gives both v and sqrt(v dt)), then, one path at a time, the four normals of
+            // Philox block nl/4 of the path's price stream turn them into the exponents of the four price steps.
+            // Steps beyond the grid (last tile only) are computed like any other -- finite, never stored, never used.
+            double* const ia = xr + t * 4;
+            double* const ib = xi + t * 4;
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
-                const int n = nl + v;
-                const bool valid = n < a.n_steps;
-                const double cmp = valid ? L.comp[n] : 0.0;
-                // sqrt(v) = sqrt(xi) e^{(X + comp)/2}: one exponential gives both v and sqrt(v dt)
-                double ea, eb;
-                fm::exp_full2(0.5 * (xr[t * 4 + v] + cmp), 0.5 * (xi[t * 4 + v] + cmp), ea, eb);
-                const double var_a = a.xi * (ea * ea), var_b = a.xi * (eb * eb);
-                const double inc_a = fma(sq_xi_dt * ea, za[v], (a.r - 0.5 * var_a) * a.dt);
-                const double inc_b = fma(sq_xi_dt * eb, zb[v], (a.r - 0.5 * var_b) * a.dt);
-                ia[v] = valid ? inc_a : 0.0;  // a step beyond the grid multiplies by exactly 1
-                ib[v] = valid ? inc_b : 0.0;
-                big = fmax(big, fmax(fabs(ia[v]), fabs(ib[v])));
+                const double cmp = L.comp[nl + v];
+                fm::exp_full2(0.5 * (ia[v] + cmp), 0.5 * (ib[v] + cmp), ia[v], ib[v]);
                 __builtin_amdgcn_sched_barrier(0);  // one step's pair of chains at a time: more of them cost registers, not time
             }
+            {
+                double z[4];
+                fm::normal_quad_fast<RB_EAGER_PRICE>(a.k0, a.k1, id_a, (uint32_t)(nl >> 2), STREAM_PRICE, tabs, z);
+#pragma unroll
+                for (int v = 0; v < 4; ++v)  // (r - v/2) dt + sqrt(v dt) z,  v = xi e^2
+                    ia[v] = fma(sq_xi_dt * ia[v], z[v], fma(neg_half_xi_dt, ia[v] * ia[v], r_dt));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                double z[4];
+                fm::normal_quad_fast<RB_EAGER_PRICE>(a.k0, a.k1, id_b, (uint32_t)(nl >> 2), STREAM_PRICE, tabs, z);
+#pragma unroll
+                for (int v = 0; v < 4; ++v) ib[v] = fma(sq_xi_dt * ib[v], z[v], fma(neg_half_xi_dt, ib[v] * ib[v], r_dt));
+            }
+            double big = 0.0;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) big = fmax(big, fmax(fabs(ia[v]), fabs(ib[v])));
             // e^inc - 1 by the shortest polynomial the wave's largest exponent allows, then the running products
             // p_v = prod_{u <= v} e^{inc_u} (in place: ia/ib end up holding them)
             if (__builtin_amdgcn_ballot_w64(big > fm::SMALL6_EXP_BOUND) == 0ull) {
@@ -397,7 +415,8 @@ __device__ __forceinline__ void rb_fft_block(const RbArgs& a, const RbLds& L, in
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            double (&pa)[4] = ia, (&pb)[4] = ib;
+            double* const pa = ia;
+            double* const pb = ib;
             pa[0] = 1.0 + ia[0];
             pb[0] = 1.0 + ib[0];
 #pragma unroll
@@ -420,15 +439,27 @@ __device__ __forceinline__ void rb_fft_block(const RbArgs& a, const RbLds& L, in
                 }
             }
             const double base_a = S_a * la, base_b = S_b * lb;
-            double last_a = 0.0, last_b = 0.0;
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
-                last_a = base_a * pa[v];
-                last_b = base_b * pb[v];
-                stage[(4 * g + v) * RS + wave * P + c] = make_double2(last_a, last_b);
+                pa[v] *= base_a;
+                pb[v] *= base_b;
+                stage[(4 * g + v) * RS + wave * P + c] = make_double2(pa[v], pb[v]);
             }
-            S_a = __shfl(last_a, (G - 1) * P + c, 64);
-            S_b = __shfl(last_b, (G - 1) * P + c, 64);
+            // the tile's last step of the grid: lane G - 1, v = 3, except in a last tile that the grid leaves unfinished
+            double last_a = pa[3], last_b = pb[3];
+            int src_g = G - 1;
+            if ((((t + 1) * G) << 2) > a.n_steps) {  // wave-uniform
+                const int n_last = a.n_steps - 1 - ((t * G) << 2);
+                src_g = n_last >> 2;
+                switch (n_last & 3) {
+                    case 0: last_a = pa[0]; last_b = pb[0]; break;
+                    case 1: last_a = pa[1]; last_b = pb[1]; break;
+                    case 2: last_a = pa[2]; last_b = pb[2]; break;
+                    default: break;
+                }
+            }
+            S_a = __shfl(last_a, src_g * P + c, 64);
+            S_b = __shfl(last_b, src_g * P + c, 64);
             __syncthreads();
             // write-out: the tile is 4G rows x PW pairs = 1024 16-byte units, four per thread (rows wr_row + i G); a
             // wavefront store covers 64 / PW complete rows of PW * 16 contiguous bytes.  Columns are never masked: rows
