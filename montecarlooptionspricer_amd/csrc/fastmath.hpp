@@ -107,6 +107,29 @@ __device__ __forceinline__ double exp_full(double a) {
 __device__ __forceinline__ void horner2(double& qa, double& qb, double ra, double rb, double C) {
     asm("v_fma_f64 %0, %0, %2, %4\n\tv_fma_f64 %1, %1, %3, %4" : "+v"(qa), "+v"(qb) : "v"(ra), "v"(rb), "s"(C));
 }
+// Several steps of both chains in ONE asm statement: behind every asm statement whose result the next instruction
+// reads hipcc puts an `s_nop 0` (it cannot see that the statement is a plain FMA); inside a statement there is none,
+// and dependent VALU instructions need none.
+#define MCG_H2(n) "v_fma_f64 %0, %0, %2, %" #n "\n\tv_fma_f64 %1, %1, %3, %" #n "\n\t"
+__device__ __forceinline__ void horner2x5(double& qa, double& qb, double ra, double rb, double c1, double c2, double c3,
+                                          double c4, double c5) {
+    asm(MCG_H2(4) MCG_H2(5) MCG_H2(6) MCG_H2(7) MCG_H2(8)
+        : "+v"(qa), "+v"(qb)
+        : "v"(ra), "v"(rb), "s"(c1), "s"(c2), "s"(c3), "s"(c4), "s"(c5));
+}
+__device__ __forceinline__ void horner2x6(double& qa, double& qb, double ra, double rb, double c1, double c2, double c3,
+                                          double c4, double c5, double c6) {
+    asm(MCG_H2(4) MCG_H2(5) MCG_H2(6) MCG_H2(7) MCG_H2(8) MCG_H2(9)
+        : "+v"(qa), "+v"(qb)
+        : "v"(ra), "v"(rb), "s"(c1), "s"(c2), "s"(c3), "s"(c4), "s"(c5), "s"(c6));
+}
+__device__ __forceinline__ void horner2x9(double& qa, double& qb, double ra, double rb, double c1, double c2, double c3,
+                                          double c4, double c5, double c6, double c7, double c8, double c9) {
+    asm(MCG_H2(4) MCG_H2(5) MCG_H2(6) MCG_H2(7) MCG_H2(8) MCG_H2(9) MCG_H2(10) MCG_H2(11) MCG_H2(12)
+        : "+v"(qa), "+v"(qb)
+        : "v"(ra), "v"(rb), "s"(c1), "s"(c2), "s"(c3), "s"(c4), "s"(c5), "s"(c6), "s"(c7), "s"(c8), "s"(c9));
+}
+#undef MCG_H2
 
 // e^a, e^b (exp_full twice, interleaved)
 __device__ __forceinline__ void exp_full2(double a, double b, double& ea, double& eb) {
@@ -115,15 +138,9 @@ __device__ __forceinline__ void exp_full2(double a, double b, double& ea, double
     ra = __builtin_fma(ka, -0x1.a39ef35793c76p-33, ra);
     rb = __builtin_fma(kb, -0x1.a39ef35793c76p-33, rb);
     double qa = 0x1.af38a9b0ec855p-26, qb = 0x1.af38a9b0ec855p-26;
-    horner2(qa, qb, ra, rb, 0x1.289185613a3d6p-22);
-    horner2(qa, qb, ra, rb, 0x1.71de0dae63bb3p-19);
-    horner2(qa, qb, ra, rb, 0x1.a019b90d2ae7ap-16);
-    horner2(qa, qb, ra, rb, 0x1.a01a01a7c41d5p-13);
-    horner2(qa, qb, ra, rb, 0x1.6c16c1788bd90p-10);
-    horner2(qa, qb, ra, rb, 0x1.11111111109b3p-7);
-    horner2(qa, qb, ra, rb, 0x1.5555555553d63p-5);
-    horner2(qa, qb, ra, rb, 0x1.5555555555556p-3);
-    horner2(qa, qb, ra, rb, 0x1.0000000000001p-1);
+    horner2x9(qa, qb, ra, rb, 0x1.289185613a3d6p-22, 0x1.71de0dae63bb3p-19, 0x1.a019b90d2ae7ap-16, 0x1.a01a01a7c41d5p-13,
+              0x1.6c16c1788bd90p-10, 0x1.11111111109b3p-7, 0x1.5555555553d63p-5, 0x1.5555555555556p-3,
+              0x1.0000000000001p-1);
     ea = __builtin_ldexp(1.0 + __builtin_fma(ra * ra, qa, ra), (int)ka);
     eb = __builtin_ldexp(1.0 + __builtin_fma(rb * rb, qb, rb), (int)kb);
 }
@@ -132,26 +149,16 @@ __device__ __forceinline__ void exp_full2(double a, double b, double& ea, double
 // without its range reduction): a price step's exponent, whose size the caller has tested for the whole wave.
 __device__ __forceinline__ void expm1_small6_2(double a, double b, double& ea, double& eb) {
     double qa = 0x1.a02eb88e6a6ffp-16, qb = 0x1.a02eb88e6a6ffp-16;
-    horner2(qa, qb, a, b, 0x1.a033e66a22569p-13);
-    horner2(qa, qb, a, b, 0x1.6c16c10206fa6p-10);
-    horner2(qa, qb, a, b, 0x1.1111108c7c825p-7);
-    horner2(qa, qb, a, b, 0x1.555555555664ep-5);
-    horner2(qa, qb, a, b, 0x1.5555555557fc2p-3);
-    horner2(qa, qb, a, b, 0x1.0000000000000p-1);
+    horner2x6(qa, qb, a, b, 0x1.a033e66a22569p-13, 0x1.6c16c10206fa6p-10, 0x1.1111108c7c825p-7, 0x1.555555555664ep-5,
+              0x1.5555555557fc2p-3, 0x1.0000000000000p-1);
     ea = __builtin_fma(a * a, qa, a);
     eb = __builtin_fma(b * b, qb, b);
 }
 __device__ __forceinline__ void expm1_small9_2(double a, double b, double& ea, double& eb) {
     double qa = 0x1.af38a9b0ec855p-26, qb = 0x1.af38a9b0ec855p-26;
-    horner2(qa, qb, a, b, 0x1.289185613a3d6p-22);
-    horner2(qa, qb, a, b, 0x1.71de0dae63bb3p-19);
-    horner2(qa, qb, a, b, 0x1.a019b90d2ae7ap-16);
-    horner2(qa, qb, a, b, 0x1.a01a01a7c41d5p-13);
-    horner2(qa, qb, a, b, 0x1.6c16c1788bd90p-10);
-    horner2(qa, qb, a, b, 0x1.11111111109b3p-7);
-    horner2(qa, qb, a, b, 0x1.5555555553d63p-5);
-    horner2(qa, qb, a, b, 0x1.5555555555556p-3);
-    horner2(qa, qb, a, b, 0x1.0000000000001p-1);
+    horner2x9(qa, qb, a, b, 0x1.289185613a3d6p-22, 0x1.71de0dae63bb3p-19, 0x1.a019b90d2ae7ap-16, 0x1.a01a01a7c41d5p-13,
+              0x1.6c16c1788bd90p-10, 0x1.11111111109b3p-7, 0x1.5555555553d63p-5, 0x1.5555555555556p-3,
+              0x1.0000000000001p-1);
     ea = __builtin_fma(a * a, qa, a);
     eb = __builtin_fma(b * b, qb, b);
 }
@@ -219,6 +226,17 @@ __device__ __forceinline__ double neg2log_entry(const LogSplit& sp, const double
     // -2 ln u = -2 k ln2 + (-2 ln c) - 2 log1p(r)
     const double base = __builtin_fma((double)sp.k, -0x1.62e42fefa39efp+0, e.y);
     return __builtin_fma(-2.0, l1p, base);
+}
+// two of them, the polynomial chains interleaved (bit-identical to neg2log_entry twice)
+__device__ __forceinline__ void neg2log_entry2(const LogSplit& s0, const double2 e0, const LogSplit& s1, const double2 e1,
+                                               double& out0, double& out1) {
+    const double r0 = __builtin_fma(s0.z, e0.x, -1.0), r1 = __builtin_fma(s1.z, e1.x, -1.0);
+    double q0 = 0x1.24940e22d9958p-3, q1 = 0x1.24940e22d9958p-3;
+    horner2x5(q0, q1, r0, r1, -0x1.555752f357b5cp-3, 0x1.99999998b8291p-3, -0x1.ffffffff02617p-3, 0x1.5555555555556p-2,
+              -0x1.0000000000000p-1);
+    const double l0 = __builtin_fma(r0 * r0, q0, r0), l1 = __builtin_fma(r1 * r1, q1, r1);
+    out0 = __builtin_fma(-2.0, l0, __builtin_fma((double)s0.k, -0x1.62e42fefa39efp+0, e0.y));
+    out1 = __builtin_fma(-2.0, l1, __builtin_fma((double)s1.k, -0x1.62e42fefa39efp+0, e1.y));
 }
 __device__ __forceinline__ double neg2log(double u, const double2* tab) {
     const LogSplit sp = log_split(u);
@@ -334,7 +352,9 @@ __device__ __forceinline__ void normal_quad_fast(uint32_t k0, uint32_t k1, uint6
     sincos_small(w.w1, cd0, sd0);
     sincos_small(w.w3, cd1, sd1);
     __builtin_amdgcn_sched_barrier(0);
-    const double r0 = sqrt_pos(neg2log_entry(s0, l0)), r1 = sqrt_pos(neg2log_entry(s1, l1));
+    double n0, n1;
+    neg2log_entry2(s0, l0, s1, l1, n0, n1);
+    const double r0 = sqrt_pos(n0), r1 = sqrt_pos(n1);
     z[0] = r0 * __builtin_fma(a0.x, cd0, -(a0.y * sd0));
     z[1] = r0 * __builtin_fma(a0.y, cd0, a0.x * sd0);
     z[2] = r1 * __builtin_fma(a1.x, cd1, -(a1.y * sd1));

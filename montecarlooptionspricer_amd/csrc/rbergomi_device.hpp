@@ -187,6 +187,18 @@ __device__ __forceinline__ void lane_swap(double& a, double& b) {
     b = __hiloint2double((int)hi.y, (int)lo.y);
 }
 
+// (a, b) -> (a + w b, a - w b) in six FMAs: lo = a + w b as two chained FMAs per component, hi = 2a - lo.
+// (The textbook form -- w b, then a +- it -- is eight instructions.)  Outputs may alias the inputs.
+__device__ __forceinline__ void rb_butterfly(const double2 w, double ar, double ai, double br, double bi, double& lo_r,
+                                             double& lo_i, double& hi_r, double& hi_i) {
+    const double lr = fma(w.x, br, fma(-w.y, bi, ar));
+    const double li = fma(w.x, bi, fma(w.y, br, ai));
+    hi_r = fma(2.0, ar, -lr);
+    hi_i = fma(2.0, ai, -li);
+    lo_r = lr;
+    lo_i = li;
+}
+
 // bit reversal of the low LT bits of t (LT = 2 or 3)
 template <int LT>
 __device__ __forceinline__ constexpr int rb_rev(int t) {
@@ -280,8 +292,8 @@ __device__ __forceinline__ void rb_fft_block(const RbArgs& a, const RbLds& L, in
                     const int i0 = (2 * tp) * 4 + v, i1 = (2 * tp + 1) * 4 + v;
                     lane_swap<DELTA>(xr[i0], xr[i1]);  // now [i0] = lower end, [i1] = upper end of ONE butterfly
                     lane_swap<DELTA>(xi[i0], xi[i1]);
-                    const double wr = w.x * xr[i1] - w.y * xi[i1], wi = w.x * xi[i1] + w.y * xr[i1];
-                    double lo_r = xr[i0] + wr, lo_i = xi[i0] + wi, hi_r = xr[i0] - wr, hi_i = xi[i0] - wi;
+                    double lo_r, lo_i, hi_r, hi_i;
+                    rb_butterfly(w, xr[i0], xi[i0], xr[i1], xi[i1], lo_r, lo_i, hi_r, hi_i);
                     lane_swap<DELTA>(lo_r, hi_r);
                     lane_swap<DELTA>(lo_i, hi_i);
                     xr[i0] = lo_r;
@@ -327,13 +339,8 @@ __device__ __forceinline__ void rb_fft_block(const RbArgs& a, const RbLds& L, in
 #pragma unroll
                 for (int th = 0; th < (NT / 2 >> bt); ++th) {  // t bits above bt
                     const int t_lo = (th << (bt + 1)) | tl, t_up = t_lo | (1 << bt);
-                    const double ar = xr[t_lo * 4 + v], ai = xi[t_lo * 4 + v];
-                    const double br = xr[t_up * 4 + v], bi = xi[t_up * 4 + v];
-                    const double wr = w.x * br - w.y * bi, wi = w.x * bi + w.y * br;
-                    xr[t_lo * 4 + v] = ar + wr;
-                    xi[t_lo * 4 + v] = ai + wi;
-                    xr[t_up * 4 + v] = ar - wr;
-                    xi[t_up * 4 + v] = ai - wi;
+                    rb_butterfly(w, xr[t_lo * 4 + v], xi[t_lo * 4 + v], xr[t_up * 4 + v], xi[t_up * 4 + v], xr[t_lo * 4 + v],
+                                 xi[t_lo * 4 + v], xr[t_up * 4 + v], xi[t_up * 4 + v]);
                 }
             }
         }
