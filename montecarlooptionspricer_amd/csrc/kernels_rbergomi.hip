@@ -41,8 +41,8 @@ __device__ __forceinline__ void rb_finish(const RbArgs& a, double (&v)[2]) {
 #ifndef RB_WAVES
 #define RB_WAVES 2
 #endif
-// Two waves per SIMD: the kernel wants ~230 VGPRs (64 of them the transform); held to the 168 of three waves -- which
-// LDS would admit up to Mz = 256 -- it spills ~60 of them into its loops and is slower (-DRB_WAVES=3 to try).
+// Two waves per SIMD: the kernel uses ~205 VGPRs (64 of them the transform); held to the 168 of three waves it spills
+// 18-31 dwords and is slower, and at ~90 % VALU busy there is little left for a third wave to fill (-DRB_WAVES=3 to try).
 template <int LG, int LT, bool PAYOFF>
 __global__ __launch_bounds__(256, RB_WAVES) void k_rbergomi_fft(RbArgs a) {
     extern __shared__ double smem[];

@@ -169,6 +169,24 @@ def test_rbergomi_paths_match_oracle(eng, orc, n_paths, n_steps):
     P.free()
 
 
+@pytest.mark.parametrize("n_paths,n_steps", [(40_001, 150), (24_001, 300)])
+def test_rbergomi_persistent_shares_match_oracle(eng, orc, n_paths, n_steps):
+    """More shares than resident workgroups (each works through several, drawn from the ticket counter) AND an odd
+    number of live tiles per share (150 of 256 / 300 of 512 steps: three of four), so that the last tile of one share
+    and the first of the next use the same staging buffer; the last tile is also unfinished (S_T comes from a lane in the
+    middle of the tile).  Paths and the fused payoff sums against the oracle."""
+    T = n_steps * DT
+    P = eng.rbergomi(SEED, RB["S0"], RB["r"], RB["xi"], RB["H"], RB["eta"], RB["rho"], DT, n_steps, n_paths,
+                     path_begin=2, payoff=(95.0, False))
+    got = P.to_host_step_major()
+    want = orc.paths_rbergomi(SEED, RB["S0"], RB["r"], RB["xi"], RB["H"], RB["eta"], RB["rho"], DT, n_steps, 2, n_paths)
+    assert rel_err(got, want) < 1e-9
+    m, se = eng.price_european(P, 95.0, RB["r"], T, False)     # from the sums the generator left
+    om, ose = orc.price_european(want, 95.0, RB["r"], T, False)
+    assert abs(m - om) <= 1e-9 * om and abs(se - ose) <= 1e-8 * ose
+    P.free()
+
+
 def test_rbergomi_spectrum_matches_oracle(orc):
     from montecarlooptionspricer_amd.engine import rbergomi_spectrum
     for steps, H, eta in [(252, 0.1, 1.9), (512, 0.1, 1.9), (7, 0.57, 0.03), (1, 0.3, 1.0)]:
