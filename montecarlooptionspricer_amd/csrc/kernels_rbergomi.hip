@@ -13,27 +13,21 @@
 
 namespace mcg {
 
-// this lane's payoff sums {sum, sum of squares} over the shares its workgroup worked through
+// One share's payoff sums {sum, sum of squares} -> partials[2 share ..]: per SHARE, not per workgroup, because which
+// workgroup draws which share differs from run to run and the fixed-order sum over the partials (finish_sums) must not.
 template <bool PAYOFF>
-__device__ __forceinline__ void rb_add_payoff(const RbArgs& a, double end_a, double end_b, bool live_a, bool live_b,
-                                              bool lead, double (&v)[2]) {
+__device__ __forceinline__ void rb_finish(const RbArgs& a, int64_t share, double end_a, double end_b, bool live_a,
+                                          bool live_b, bool lead) {
     if (PAYOFF) {
+        __shared__ double red[2 * 4];  // (re-used share after share: the barriers inside a share separate the uses)
         const bool call = a.is_call != 0;
         const double pay_a = (lead && live_a) ? payoff_of(call, end_a, a.K) : 0.0;
         const double pay_b = (lead && live_b) ? payoff_of(call, end_b, a.K) : 0.0;
-        v[0] += pay_a + pay_b;
-        v[1] += pay_a * pay_a + pay_b * pay_b;
-    }
-}
-
-template <bool PAYOFF>
-__device__ __forceinline__ void rb_finish(const RbArgs& a, double (&v)[2]) {
-    if (PAYOFF) {
-        __shared__ double red[2 * 4];
+        double v[2] = {pay_a + pay_b, pay_a * pay_a + pay_b * pay_b};
         block_sum<2, 4>(v, red);
         if (threadIdx.x == 0) {
-            a.partials[2 * (int64_t)blockIdx.x] = v[0];
-            a.partials[2 * (int64_t)blockIdx.x + 1] = v[1];
+            a.partials[2 * share] = v[0];
+            a.partials[2 * share + 1] = v[1];
         }
     }
 }
@@ -55,7 +49,6 @@ __global__ __launch_bounds__(256, RB_WAVES) void k_rbergomi_fft(RbArgs a) {
     // ticket one trip before it publishes it (so the atomic's latency is never waited for) into one of two alternating
     // LDS slots; the barriers inside a share order a slot's write against the reads of the trip before.
     __shared__ long long next_share[2];
-    double v[2] = {0.0, 0.0};
     long long share = blockIdx.x;
     unsigned long long drawn = 0;  // thread 0: the ticket of the trip after the current one
     if (threadIdx.x == 0) drawn = atomicAdd(a.ticket, 1ull);
@@ -75,10 +68,9 @@ __global__ __launch_bounds__(256, RB_WAVES) void k_rbergomi_fft(RbArgs a) {
         RbArgs b = a;
         asm volatile("" : "+s"(b.n_steps), "+s"(b.ld));
         rb_fft_block<LG, LT>(b, L, share, tid, &tabs, la, lb, va, vb, lead);
-        rb_add_payoff<PAYOFF>(a, la, lb, va, vb, lead, v);
+        rb_finish<PAYOFF>(a, share, la, lb, va, vb, lead);
         share = next_share[trip & 1];  // written before this trip's first barrier
     }
-    rb_finish<PAYOFF>(a, v);
 }
 
 template <bool PAYOFF>
@@ -88,9 +80,7 @@ __global__ __launch_bounds__(256) void k_rbergomi_small(RbArgs a) {
     double la, lb;
     bool va, vb, lead;
     rb_generate_small(a, (int64_t)blockIdx.x, smem, &tabs, la, lb, va, vb, lead);
-    double v[2] = {0.0, 0.0};
-    rb_add_payoff<PAYOFF>(a, la, lb, va, vb, lead, v);
-    rb_finish<PAYOFF>(a, v);
+    rb_finish<PAYOFF>(a, (int64_t)blockIdx.x, la, lb, va, vb, lead);
 }
 
 // gfx950 allows a workgroup up to 160 KB of LDS, but beyond 64 KB of dynamic LDS the kernel has to opt in
@@ -156,7 +146,7 @@ int launch_rbergomi(mcg_ctx* ctx, mcg_paths* P, uint64_t seed, double S0, double
     rc = ensure_cap(ctx, &ctx->weights, &ctx->weights_cap, (size_t)M + (size_t)P->n_steps);
     if (rc) return rc;
     if (want_payoff) {
-        rc = ensure_cap(ctx, &ctx->partials, &ctx->partials_cap, (size_t)(2 * grid));
+        rc = ensure_cap(ctx, &ctx->partials, &ctx->partials_cap, (size_t)(2 * n_blocks));
         if (rc) return rc;
     }
     MCG_HIP(hipMemcpyAsync(ctx->weights, amp.data(), (size_t)M * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
@@ -197,7 +187,7 @@ int launch_rbergomi(mcg_ctx* ctx, mcg_paths* P, uint64_t seed, double S0, double
     }
     MCG_HIP(hipGetLastError());
     if (want_payoff) {
-        rc = finish_sums(ctx, grid, P->n_paths, P->sums);
+        rc = finish_sums(ctx, n_blocks, P->n_paths, P->sums);
         if (rc) return rc;
         P->has_sums = true;
         P->sums_K = K;

@@ -290,6 +290,7 @@ int mcg_finalize(mcg_ctx* ctx) {
         (void)hipEventDestroy(ev.b);
     }
     if (ctx->partials) (void)hipFree(ctx->partials);
+    if (ctx->fin_chunks) (void)hipFree(ctx->fin_chunks);
     if (ctx->scalars) (void)hipFree(ctx->scalars);
     if (ctx->h_scalars) (void)hipHostFree(ctx->h_scalars);
     if (ctx->weights) (void)hipFree(ctx->weights);

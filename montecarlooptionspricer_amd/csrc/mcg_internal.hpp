@@ -57,6 +57,8 @@ struct mcg_ctx {
     // small persistent workspace
     double* partials = nullptr;  // per-block partial sums
     size_t partials_cap = 0;     // in doubles
+    double* fin_chunks = nullptr;  // finish_sums: chunk sums of a long partials list
+    size_t fin_chunks_cap = 0;
     double* scalars = nullptr;   // device: sums, moments, coefficients
     double* h_scalars = nullptr; // pinned host mirror
     double* weights = nullptr;   // rBergomi spectral amplitudes + compensator
