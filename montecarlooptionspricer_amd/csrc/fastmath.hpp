@@ -129,6 +129,12 @@ __device__ __forceinline__ void horner2x9(double& qa, double& qb, double ra, dou
         : "+v"(qa), "+v"(qb)
         : "v"(ra), "v"(rb), "s"(c1), "s"(c2), "s"(c3), "s"(c4), "s"(c5), "s"(c6), "s"(c7), "s"(c8), "s"(c9));
 }
+__device__ __forceinline__ void horner2x10(double& qa, double& qb, double ra, double rb, double c1, double c2, double c3,
+                                           double c4, double c5, double c6, double c7, double c8, double c9, double c10) {
+    asm(MCG_H2(4) MCG_H2(5) MCG_H2(6) MCG_H2(7) MCG_H2(8) MCG_H2(9) MCG_H2(10) MCG_H2(11) MCG_H2(12) MCG_H2(13)
+        : "+v"(qa), "+v"(qb)
+        : "v"(ra), "v"(rb), "s"(c1), "s"(c2), "s"(c3), "s"(c4), "s"(c5), "s"(c6), "s"(c7), "s"(c8), "s"(c9), "s"(c10));
+}
 #undef MCG_H2
 
 // e^a, e^b (exp_full twice, interleaved)
@@ -143,6 +149,21 @@ __device__ __forceinline__ void exp_full2(double a, double b, double& ea, double
               0x1.0000000000001p-1);
     ea = __builtin_ldexp(1.0 + __builtin_fma(ra * ra, qa, ra), (int)ka);
     eb = __builtin_ldexp(1.0 + __builtin_fma(rb * rb, qb, rb), (int)kb);
+}
+
+// 2^ta, 2^tb for arguments that are ALREADY in units of ln 2 (the caller folds log2(e) into whatever produces them:
+// the rBergomi variance factor is 2^(c X + table)): k = rint(t), f = t - k exactly, 2^f = 1 + f g(f) with g of degree 10
+// on |f| <= 1/2 (max rel err 2^-55.5, tools/gen_coeffs.py), result = ldexp(., k).  16 instructions per value, against
+// the 20 of exp_full2: no multiply by log2(e), no two-step reduction by ln 2, no separate r^2.
+__device__ __forceinline__ void exp2_pair(double ta, double tb, double& ea, double& eb) {
+    const double ka = __builtin_rint(ta), kb = __builtin_rint(tb);
+    const double fa = ta - ka, fb = tb - kb;
+    double qa = 0x1.e9d419696e0e9p-32, qb = 0x1.e9d419696e0e9p-32;
+    horner2x10(qa, qb, fa, fb, 0x1.e6065f532c950p-28, 0x1.b524fad88ed30p-24, 0x1.62bfd46781ef6p-20, 0x1.ffcbfc6712438p-17,
+               0x1.4309130975155p-13, 0x1.5d87fe78a526dp-10, 0x1.3b2ab6fba1dc6p-7, 0x1.c6b08d704a0c2p-5,
+               0x1.ebfbdff82c598p-3, 0x1.62e42fefa39efp-1);
+    ea = __builtin_ldexp(__builtin_fma(qa, fa, 1.0), (int)ka);
+    eb = __builtin_ldexp(__builtin_fma(qb, fb, 1.0), (int)kb);
 }
 
 // e^a - 1, e^b - 1 for |a|, |b| <= 0.1 (the polynomial of scaled_exp_small6) and for <= 0.34 (that of scaled_exp
@@ -335,13 +356,16 @@ __device__ __forceinline__ void box_muller_pair_affine_scaled(uint32_t wa, uint3
 
 // One Philox block -> four N(0,1) deviates.
 // EAGER: request all four table entries before any is used (costs ~12 registers for the time of the lookups).
+// amp0, amp1: factors of the first and of the second pair (the rBergomi spectrum's amplitudes a_k: folded into the radius,
+// one multiply per pair instead of one per deviate); 1 for plain deviates.
 template <bool EAGER = false>
 __device__ __forceinline__ void normal_quad_fast(uint32_t k0, uint32_t k1, uint64_t path, uint32_t block,
-                                                 uint32_t stream, const Tables* tab, double (&z)[4]) {
+                                                 uint32_t stream, const Tables* tab, double (&z)[4], double amp0 = 1.0,
+                                                 double amp1 = 1.0) {
     const Philox4 w = philox4x32_10((uint32_t)path, (uint32_t)(path >> 32), block, stream, k0, k1);
     if constexpr (!EAGER) {
-        box_muller_pair(w.w0, w.w1, tab, z[0], z[1]);
-        box_muller_pair(w.w2, w.w3, tab, z[2], z[3]);
+        box_muller_pair_affine(w.w0, w.w1, tab, amp0, 0.0, z[0], z[1]);
+        box_muller_pair_affine(w.w2, w.w3, tab, amp1, 0.0, z[2], z[3]);
         return;
     }
     // All four table entries are requested before any of them is used: a lookup is ~100 cycles of LDS latency, and a
@@ -354,7 +378,7 @@ __device__ __forceinline__ void normal_quad_fast(uint32_t k0, uint32_t k1, uint6
     __builtin_amdgcn_sched_barrier(0);
     double n0, n1;
     neg2log_entry2(s0, l0, s1, l1, n0, n1);
-    const double r0 = sqrt_pos(n0), r1 = sqrt_pos(n1);
+    const double r0 = amp0 * sqrt_pos(n0), r1 = amp1 * sqrt_pos(n1);
     z[0] = r0 * __builtin_fma(a0.x, cd0, -(a0.y * sd0));
     z[1] = r0 * __builtin_fma(a0.y, cd0, a0.x * sd0);
     z[2] = r1 * __builtin_fma(a1.x, cd1, -(a1.y * sd1));

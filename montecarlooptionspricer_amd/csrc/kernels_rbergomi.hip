@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256, RB_WAVES) void k_rbergomi_fft(RbArgs a) {
     __shared__ fm::Tables tabs;
     // Persistent workgroups: the LDS tables (amplitudes, compensator, twiddles, the normal generator's tables) are
     // staged once, then the workgroup takes every gridDim.x-th share of 4 x 64/G pairs.
-    const RbLds L = rb_stage_lds(a, smem, &tabs);
+    const RbLds L = rb_stage_lds(a, smem, &tabs, RB_HALF_LOG2E);
     // Shares are handed out dynamically (the first gridDim.x by blockIdx, the rest from a ticket counter): workgroups
     // do not all run at the same speed, and a fixed stride leaves the fast ones idle at the end.  Thread 0 draws a
     // ticket one trip before it publishes it (so the atomic's latency is never waited for) into one of two alternating

@@ -89,7 +89,10 @@ struct RbLds {
     double2* stage;
 };
 
-__device__ __forceinline__ RbLds rb_stage_lds(const RbArgs& a, double* smem, fm::Tables* tabs) {
+// comp_scale: the FFT variants keep the compensator as (log2(e)/2) comp -- their variance factor is
+// e^{(X + comp)/2} = 2^{(log2(e)/2) X + table} (fm::exp2_pair) --, the direct variant as it is.
+constexpr double RB_HALF_LOG2E = 0x1.71547652b82fep-1;  // log2(e) / 2
+__device__ __forceinline__ RbLds rb_stage_lds(const RbArgs& a, double* smem, fm::Tables* tabs, double comp_scale) {
     const int M = a.M;
     double* amp = smem;
     double* comp = smem + M;
@@ -97,7 +100,7 @@ __device__ __forceinline__ RbLds rb_stage_lds(const RbArgs& a, double* smem, fm:
     double2* tw = reinterpret_cast<double2*>(smem + M + nc + ((M + nc) & 1));  // 16-B aligned
     for (int i = threadIdx.x; i < M; i += blockDim.x) amp[i] = a.amp[i];
     // zero beyond the grid: the FFT variants step through whole tiles, and a step that does not exist must stay finite
-    for (int i = threadIdx.x; i < nc; i += blockDim.x) comp[i] = i < a.n_steps ? a.comp[i] : 0.0;
+    for (int i = threadIdx.x; i < nc; i += blockDim.x) comp[i] = i < a.n_steps ? comp_scale * a.comp[i] : 0.0;
     for (int q = threadIdx.x; q < M / 2; q += blockDim.x) {
         double s, c;
         sincospi(2.0 * (double)q / (double)M, &s, &c);
@@ -238,13 +241,14 @@ __device__ __forceinline__ void rb_fft_block(const RbArgs& a, const RbLds& L, in
 #pragma unroll
         for (int bq = 0; bq < NT / 2; ++bq) {
             double z[4];
-            fm::normal_quad_fast<RB_EAGER_SPECTRUM>(a.k0, a.k1, pair_id, (uint32_t)((k_base >> 1) + bq), STREAM_VOL, tabs, z);
-            const double a0 = L.amp[k_base + 2 * bq], a1 = L.amp[k_base + 2 * bq + 1];
+            const double a0 = L.amp[k_base + 2 * bq], a1 = L.amp[k_base + 2 * bq + 1];  // folded into the pairs' radii
+            fm::normal_quad_fast<RB_EAGER_SPECTRUM>(a.k0, a.k1, pair_id, (uint32_t)((k_base >> 1) + bq), STREAM_VOL, tabs, z,
+                                                    a0, a1);
             const int t0 = rb_rev<LT>(2 * bq), t1 = rb_rev<LT>(2 * bq + 1);
-            xr[t0 * 4 + v] = a0 * z[0];
-            xi[t0 * 4 + v] = a0 * z[1];
-            xr[t1 * 4 + v] = a1 * z[2];
-            xi[t1 * 4 + v] = a1 * z[3];
+            xr[t0 * 4 + v] = z[0];
+            xi[t0 * 4 + v] = z[1];
+            xr[t1 * 4 + v] = z[2];
+            xi[t1 * 4 + v] = z[3];
         }
     }
 
@@ -377,8 +381,8 @@ __device__ __forceinline__ void rb_fft_block(const RbArgs& a, const RbLds& L, in
             double* const ib = xi + t * 4;
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
-                const double cmp = L.comp[nl + v];
-                fm::exp_full2(0.5 * (ia[v] + cmp), 0.5 * (ib[v] + cmp), ia[v], ib[v]);
+                const double cmp = L.comp[nl + v];  // (log2(e)/2) comp_n
+                fm::exp2_pair(fma(ia[v], RB_HALF_LOG2E, cmp), fma(ib[v], RB_HALF_LOG2E, cmp), ia[v], ib[v]);
                 __builtin_amdgcn_sched_barrier(0);  // one step's pair of chains at a time: more of them cost registers, not time
             }
             {
@@ -439,11 +443,10 @@ __device__ __forceinline__ void rb_fft_block(const RbArgs& a, const RbLds& L, in
             }
 #pragma unroll
             for (int b = 0; b < LG; ++b) {
-                const double ua = __shfl_up(la, P << b, 64), ub = __shfl_up(lb, P << b, 64);
-                if (g > (1 << b)) {  // (lane g = 2^b would multiply by lane 0's lead, which is 1)
-                    la *= ua;
-                    lb *= ub;
-                }
+                // lanes g <= 2^b read lane 0 of their pair, whose lead is 1 and stays 1: no select on the product
+                const int src = max(lane - (P << b), c);
+                la *= __shfl(la, src, 64);
+                lb *= __shfl(lb, src, 64);
             }
             const double base_a = S_a * la, base_b = S_b * lb;
 #pragma unroll
@@ -503,14 +506,14 @@ __device__ __forceinline__ void rb_fft_block(const RbArgs& a, const RbLds& L, in
 template <int LG, int LT>
 __device__ __forceinline__ void rb_generate_fft(const RbArgs& a, int64_t block_index, double* smem, fm::Tables* tabs,
                                                 double& end_a, double& end_b, bool& live_a, bool& live_b, bool& lead) {
-    const RbLds L = rb_stage_lds(a, smem, tabs);
+    const RbLds L = rb_stage_lds(a, smem, tabs, RB_HALF_LOG2E);
     rb_fft_block<LG, LT>(a, L, block_index, (int)threadIdx.x, tabs, end_a, end_b, live_a, live_b, lead);
 }
 
 // Mz < 32 (at most 16 steps): one pair per lane, the transform evaluated directly.
 __device__ __forceinline__ void rb_generate_small(const RbArgs& a, int64_t block_index, double* smem, fm::Tables* tabs,
                                                   double& end_a, double& end_b, bool& live_a, bool& live_b, bool& lead) {
-    const RbLds L = rb_stage_lds(a, smem, tabs);
+    const RbLds L = rb_stage_lds(a, smem, tabs, 1.0);
     const int M = a.M;  // 1, 2, 4, 8 or 16
     const int64_t q = block_index * (int64_t)blockDim.x + threadIdx.x;
     const int64_t col_a = 2 * q;
