@@ -25,9 +25,11 @@ __global__ __launch_bounds__(256) void k_debug_eval(int fn, const double* x, dou
         case 4: fm::normal_quad_fast(1u, 0u, (uint64_t)v, 0u, STREAM_PRICE, tab, z); break;
         case 6: a = fm::scaled_exp_small(1.0, v); break;
         case 7: a = fm::scaled_exp_small6(1.0, v); break;
+        case 8: fm::exp2_pair(v, v + 0.375, a, b); break;
+        case 9: fm::normal_quad_fast<true>(1u, 0u, (uint64_t)v, 0u, STREAM_PRICE, tab, z); break;
         default: normal_quad_ref(1u, 0u, (uint64_t)v, 0u, STREAM_PRICE, z); break;
     }
-    if (fn < 4 || fn > 5) {
+    if (fn < 4 || (fn > 5 && fn != 9)) {
         z[0] = a;
         z[1] = b;
     }
@@ -39,7 +41,7 @@ __global__ __launch_bounds__(256) void k_debug_eval(int fn, const double* x, dou
 
 extern "C" int mcg_debug_eval(mcg_ctx* ctx, int fn, const double* x, double* y, int64_t n) {
     using namespace mcg;
-    if (!ctx || !x || !y || n < 0 || fn < 0 || fn > 7) return fail(MCG_ERR_INVALID, "bad arguments");
+    if (!ctx || !x || !y || n < 0 || fn < 0 || fn > 9) return fail(MCG_ERR_INVALID, "bad arguments");
     if (n == 0) return MCG_OK;
     MCG_HIP(hipSetDevice(ctx->device));
     double *dx = nullptr, *dy = nullptr;

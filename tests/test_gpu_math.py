@@ -54,6 +54,19 @@ def test_scaled_exp_small_variants(eng):
         assert worst <= 2.0, (fn, worst)
 
 
+def test_exp2_pair(eng):
+    """2^t for arguments already in units of ln 2 (the rBergomi variance factor): both chains of the pair, <= 1.5 ulp."""
+    rs = np.random.RandomState(11)
+    t = np.concatenate([rs.uniform(-0.5, 0.5, 3000), rs.uniform(-30, 30, 2000), rs.normal(0, 1.5, 2000),
+                        [0.0, 0.5, -0.5, 1.5, 2.5, -1.5, 1e-300, 1000.0, -1070.0, 1100.0, -1200.0]])
+    y = eng.debug_eval(8, t)
+    worst = 0.0
+    for ti, (ya, yb) in zip(t[:-2], y[:-2, :2]):
+        worst = max(worst, ulp_err(ya, mp.mpf(2) ** mp.mpf(ti)), ulp_err(yb, mp.mpf(2) ** mp.mpf(float(ti + 0.375))))
+    assert worst <= 1.5, worst
+    assert y[-2, 0] == np.inf and y[-1, 0] == 0.0
+
+
 def test_neg2log(eng):
     rs = np.random.RandomState(1)
     u = np.concatenate([rs.uniform(0, 1, 4000), 1 - rs.uniform(0, 1, 1500) ** 8, rs.uniform(0, 1, 1500) ** 12,
@@ -99,6 +112,8 @@ def test_normal_quad_fast_matches_contract(eng):
     slow = eng.debug_eval(5, ids)
     want = np.array([orc.normal_quad(1, int(i), 0, 0) for i in ids])
     assert np.max(np.abs(fast - want)) < 1e-14
+    eager = eng.debug_eval(9, ids)          # the four table entries requested together: the same arithmetic, the same bits
+    assert np.array_equal(eager, fast)
     assert np.max(np.abs(slow - want)) < 1e-14
     # and in high precision for a few
     for i in range(0, 5000, 500):
