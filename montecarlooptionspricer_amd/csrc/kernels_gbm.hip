@@ -7,6 +7,8 @@
 // PayoffFunction (include/core/common.h:8-14) on the last column.
 //
 // Roofline: HBM write, 8*(n_steps+1) bytes per path, reads ~0.  No MFMA: the step is elementwise.
+#include <cstdlib>
+
 #include "devmath.hpp"
 #include "fastmath.hpp"
 #include "mcg_internal.hpp"
@@ -32,68 +34,99 @@ struct GbmArgs {
 // fits fm::scaled_exp_small (no range reduction, two fewer polynomial terms).  MODE 2: SMALL and vol > 0 folded into
 // the logarithm (fm::neg2log_scaled): one multiply less per pair.  MODE 3: MODE 2 with the bound at 0.1, where e^a needs
 // one polynomial term less (fm::scaled_exp_small6).
-template <bool PAYOFF, int MODE>
+// PPL: paths per lane.  1: a wavefront writes 512 B per step.  2: a lane carries two adjacent paths and writes them with
+// one 16-byte store (1 KB per wavefront and step; half the store instructions, half the loop and addressing overhead,
+// two independent chains per lane) -- tools/ubench_write.hip: with 40 FMAs of work per path-step the 16-byte pattern
+// runs 5.24 TB/s against 5.02.  A workgroup then covers 512 columns; rows are padded to 256, so the upper two waves of
+// the last workgroup may lie beyond the row and sit the generation out (wave-uniform).
+template <bool PAYOFF, int MODE, int PPL>
 __global__ __launch_bounds__(256) void k_gbm_paths(GbmArgs a) {
     constexpr bool SMALL = MODE >= 1;
+    typedef double v2d __attribute__((ext_vector_type(2)));
     __shared__ fm::Tables tabs;
     const fm::Tables* tab = &tabs;
     if (MODE >= 2) fm::load_tables_scaled(&tabs, a.log_tab, a.vol * a.vol);
     else fm::load_tables(&tabs, a.log_tab);
     __syncthreads();
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const bool live = i < a.n_paths;
-    const uint64_t id = a.path_begin + (uint64_t)i;
-    // The address of a store is (wave-uniform row pointer) + (lane offset): the row pointer advances on the scalar
-    // unit and the lane offset never changes, so a step spends no vector instruction on addressing.
-    double* row = a.out + (int64_t)blockIdx.x * 256;
-    const unsigned lane_bytes = threadIdx.x * 8u;
-    // (hipcc picks the scalar-base form for the first store only and rebuilds a 64-bit vector address inside the
-    // loop, hence the explicit instruction)
-    auto store_row = [&](double* r, double v) {
-        asm volatile("global_store_dwordx2 %0, %1, %2 nt" : : "v"(lane_bytes), "v"(v), "s"(r) : "memory");
-    };
-    double S = a.S0;
-    store_row(row, S);
-    // One Philox block feeds two Box-Muller pairs = four steps.  The main loop takes whole blocks (both pairs
-    // written out, so no register copies select a pair); the tail runs pair by pair over the last <= 3 steps.
-    const PhiloxLane lane_rng = philox_lane_setup(id, STREAM_PRICE, a.k1);
-    auto step = [&](double e) {
-        S = MODE == 3 ? fm::scaled_exp_small6(S, e) : SMALL ? fm::scaled_exp_small(S, e) : fm::scaled_exp(S, e);
-        row += a.ld;
-        store_row(row, S);
-    };
-    auto pair_exponents = [&](uint32_t wa, uint32_t wb, double& e0, double& e1) {  // drift + vol*z of two steps
-        if (MODE >= 2) fm::box_muller_pair_affine_scaled(wa, wb, tab, a.c_k, a.c_l, a.drift, e0, e1);
-        else fm::box_muller_pair_affine(wa, wb, tab, a.vol, a.drift, e0, e1);
-    };
-    const int n_blocks = a.n_steps >> 2;
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * PPL;  // first column of this lane
+    const bool in_row = PPL == 1 || i < a.ld;
+    double S[PPL];
+#pragma unroll
+    for (int p = 0; p < PPL; ++p) S[p] = a.S0;
+    if (in_row) {
+        // The address of a store is (wave-uniform row pointer) + (lane offset): the row pointer advances on the scalar
+        // unit and the lane offset never changes, so a step spends no vector instruction on addressing.
+        double* row = a.out + (int64_t)blockIdx.x * (256 * PPL);
+        const unsigned lane_bytes = threadIdx.x * (8u * PPL);
+        // (hipcc picks the scalar-base form for the first store only and rebuilds a 64-bit vector address inside the
+        // loop, hence the explicit instruction)
+        auto store_row = [&](double* r) {
+            if constexpr (PPL == 1) {
+                asm volatile("global_store_dwordx2 %0, %1, %2 nt" : : "v"(lane_bytes), "v"(S[0]), "s"(r) : "memory");
+            } else {
+                const v2d v = {S[0], S[PPL - 1]};
+                asm volatile("global_store_dwordx4 %0, %1, %2 nt" : : "v"(lane_bytes), "v"(v), "s"(r) : "memory");
+            }
+        };
+        store_row(row);
+        // One Philox block feeds two Box-Muller pairs = four steps.  The main loop takes whole blocks (both pairs
+        // written out, so no register copies select a pair); the tail runs pair by pair over the last <= 3 steps.
+        PhiloxLane lane_rng[PPL];
+#pragma unroll
+        for (int p = 0; p < PPL; ++p) lane_rng[p] = philox_lane_setup(a.path_begin + (uint64_t)(i + p), STREAM_PRICE, a.k1);
+        auto step = [&](const double (&e)[PPL]) {
+#pragma unroll
+            for (int p = 0; p < PPL; ++p)
+                S[p] = MODE == 3 ? fm::scaled_exp_small6(S[p], e[p]) : SMALL ? fm::scaled_exp_small(S[p], e[p]) : fm::scaled_exp(S[p], e[p]);
+            row += a.ld;
+            store_row(row);
+        };
+        auto pair_exponents = [&](uint32_t wa, uint32_t wb, double& e0, double& e1) {  // drift + vol*z of two steps
+            if (MODE >= 2) fm::box_muller_pair_affine_scaled(wa, wb, tab, a.c_k, a.c_l, a.drift, e0, e1);
+            else fm::box_muller_pair_affine(wa, wb, tab, a.vol, a.drift, e0, e1);
+        };
+        const int n_blocks = a.n_steps >> 2;
 #pragma unroll 1
-    for (int b = 0; b < n_blocks; ++b) {
-        const Philox4 w = philox4x32_10_lane(lane_rng, (uint32_t)b, a.k0, a.k1);
-        double e0, e1;
-        pair_exponents(w.w0, w.w1, e0, e1);
-        step(e0);
-        step(e1);
-        pair_exponents(w.w2, w.w3, e0, e1);
-        step(e0);
-        step(e1);
-    }
-    const int rest = a.n_steps & 3;
-    if (rest) {  // wave-uniform
-        const Philox4 w = philox4x32_10_lane(lane_rng, (uint32_t)n_blocks, a.k0, a.k1);
-        double e0, e1;
-        pair_exponents(w.w0, w.w1, e0, e1);
-        step(e0);
-        if (rest >= 2) step(e1);
-        if (rest == 3) {
-            pair_exponents(w.w2, w.w3, e0, e1);
+        for (int b = 0; b < n_blocks; ++b) {
+            Philox4 w[PPL];
+#pragma unroll
+            for (int p = 0; p < PPL; ++p) w[p] = philox4x32_10_lane(lane_rng[p], (uint32_t)b, a.k0, a.k1);
+            double e0[PPL], e1[PPL];
+#pragma unroll
+            for (int p = 0; p < PPL; ++p) pair_exponents(w[p].w0, w[p].w1, e0[p], e1[p]);
             step(e0);
+            step(e1);
+#pragma unroll
+            for (int p = 0; p < PPL; ++p) pair_exponents(w[p].w2, w[p].w3, e0[p], e1[p]);
+            step(e0);
+            step(e1);
+        }
+        const int rest = a.n_steps & 3;
+        if (rest) {  // wave-uniform
+            Philox4 w[PPL];
+#pragma unroll
+            for (int p = 0; p < PPL; ++p) w[p] = philox4x32_10_lane(lane_rng[p], (uint32_t)n_blocks, a.k0, a.k1);
+            double e0[PPL], e1[PPL];
+#pragma unroll
+            for (int p = 0; p < PPL; ++p) pair_exponents(w[p].w0, w[p].w1, e0[p], e1[p]);
+            step(e0);
+            if (rest >= 2) step(e1);
+            if (rest == 3) {
+#pragma unroll
+                for (int p = 0; p < PPL; ++p) pair_exponents(w[p].w2, w[p].w3, e0[p], e1[p]);
+                step(e0);
+            }
         }
     }
     if (PAYOFF) {
         __shared__ double red[2 * 4];
-        const double pay = live ? payoff_of(a.is_call != 0, S, a.K) : 0.0;
-        double v[2] = {pay, pay * pay};
+        double v[2] = {0.0, 0.0};
+#pragma unroll
+        for (int p = 0; p < PPL; ++p) {
+            const double pay = (in_row && i + p < a.n_paths) ? payoff_of(a.is_call != 0, S[p], a.K) : 0.0;
+            v[0] += pay;
+            v[1] += pay * pay;
+        }
         block_sum<2, 4>(v, red);
         if (threadIdx.x == 0) {
             a.partials[2 * (int64_t)blockIdx.x] = v[0];
@@ -188,10 +221,31 @@ int finish_sums(mcg_ctx* ctx, int64_t n_blocks, int64_t n_local, double out3[3])
     return MCG_OK;
 }
 
+template <bool PAYOFF, int PPL>
+static void launch_gbm_mode(mcg_ctx* ctx, const GbmArgs& a, int mode, unsigned n_blocks) {
+    const dim3 grid(n_blocks), block(256);
+    if (mode == 3) hipLaunchKernelGGL((k_gbm_paths<PAYOFF, 3, PPL>), grid, block, 0, ctx->stream, a);
+    else if (mode == 2) hipLaunchKernelGGL((k_gbm_paths<PAYOFF, 2, PPL>), grid, block, 0, ctx->stream, a);
+    else if (mode == 1) hipLaunchKernelGGL((k_gbm_paths<PAYOFF, 1, PPL>), grid, block, 0, ctx->stream, a);
+    else hipLaunchKernelGGL((k_gbm_paths<PAYOFF, 0, PPL>), grid, block, 0, ctx->stream, a);
+}
+
+// paths per lane: 2 once every CU has several workgroups of 512 paths to work on (MCG_GBM_PPL overrides, for timing studies)
+static int gbm_paths_per_lane(const mcg_ctx* ctx, int64_t n_paths) {
+    static const int forced = [] {
+        const char* e = std::getenv("MCG_GBM_PPL");
+        return e ? std::atoi(e) : 0;
+    }();
+    if (forced == 1 || forced == 2) return forced;
+    return n_paths >= (int64_t)ctx->n_cus * 512 * 8 ? 2 : 1;
+}
+
 int launch_gbm(mcg_ctx* ctx, mcg_paths* P, uint64_t seed, double S0, double r, double sigma, double dt,
                bool want_payoff, double K, int is_call) {
-    const int64_t n_blocks = (P->n_paths + 255) / 256;
+    const int ppl = gbm_paths_per_lane(ctx, P->n_paths);
+    const int64_t n_blocks = (P->n_paths + 256 * ppl - 1) / (256 * ppl);
     if (n_blocks > 0x7fffffffLL) return fail(MCG_ERR_INVALID, "n_paths too large for one launch");
+    if ((P->ld & 255) != 0) return fail(MCG_ERR_INVALID, "path matrix rows must be padded to 256 columns");
     if (want_payoff) {
         int rc = ensure_cap(ctx, &ctx->partials, &ctx->partials_cap, (size_t)(2 * n_blocks));
         if (rc) return rc;
@@ -219,17 +273,12 @@ int launch_gbm(mcg_ctx* ctx, mcg_paths* P, uint64_t seed, double S0, double r, d
         const int mode = !small ? 0 : !(a.vol > 1e-100) ? 1 : reach <= fm::SMALL6_EXP_BOUND ? 3 : 2;
         a.c_k = -0x1.62e42fefa39efp+0 * (a.vol * a.vol);
         a.c_l = -2.0 * (a.vol * a.vol);
-        const dim3 grid((unsigned)n_blocks), block(256);
         if (want_payoff) {
-            if (mode == 3) hipLaunchKernelGGL((k_gbm_paths<true, 3>), grid, block, 0, ctx->stream, a);
-            else if (mode == 2) hipLaunchKernelGGL((k_gbm_paths<true, 2>), grid, block, 0, ctx->stream, a);
-            else if (mode == 1) hipLaunchKernelGGL((k_gbm_paths<true, 1>), grid, block, 0, ctx->stream, a);
-            else hipLaunchKernelGGL((k_gbm_paths<true, 0>), grid, block, 0, ctx->stream, a);
+            if (ppl == 2) launch_gbm_mode<true, 2>(ctx, a, mode, (unsigned)n_blocks);
+            else launch_gbm_mode<true, 1>(ctx, a, mode, (unsigned)n_blocks);
         } else {
-            if (mode == 3) hipLaunchKernelGGL((k_gbm_paths<false, 3>), grid, block, 0, ctx->stream, a);
-            else if (mode == 2) hipLaunchKernelGGL((k_gbm_paths<false, 2>), grid, block, 0, ctx->stream, a);
-            else if (mode == 1) hipLaunchKernelGGL((k_gbm_paths<false, 1>), grid, block, 0, ctx->stream, a);
-            else hipLaunchKernelGGL((k_gbm_paths<false, 0>), grid, block, 0, ctx->stream, a);
+            if (ppl == 2) launch_gbm_mode<false, 2>(ctx, a, mode, (unsigned)n_blocks);
+            else launch_gbm_mode<false, 1>(ctx, a, mode, (unsigned)n_blocks);
         }
     }
     MCG_HIP(hipGetLastError());

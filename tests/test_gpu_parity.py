@@ -62,6 +62,23 @@ def test_gbm_paths_match_oracle(eng, orc, n_paths, n_steps):
     P.free()
 
 
+@pytest.mark.parametrize("n_paths,n_steps,sigma", [(1_049_700, 7, 0.2), (1_050_001, 5, 0.2), (1_049_700, 4, 1.5)])
+def test_gbm_two_paths_per_lane_matches_oracle(eng, orc, n_paths, n_steps, sigma):
+    """From 1M paths (256 CUs x 8 workgroups of 512) a lane carries two adjacent paths and stores 16 bytes per step.
+    1 049 700 paths pad to 4101 x 256 columns: the upper two waves of the last 512-column workgroup lie beyond the row.
+    Steps with a tail of 3 / 1 / 0 after the whole Philox blocks; sigma = 1.5 takes the general exponential.  Paths and
+    the fused payoff sums against the oracle; odd path_begin (the pair is a pair of COLUMNS, not of ids)."""
+    T = n_steps * DT
+    P = eng.gbm(SEED, 100.0, 0.04, sigma, DT, n_steps, n_paths, path_begin=777, payoff=(101.0, True))
+    got = P.to_host_step_major()
+    want = orc.paths_gbm(SEED, 100.0, 0.04, sigma, DT, n_steps, 777, n_paths)
+    assert got.shape == want.shape and rel_err(got, want) < 1e-11
+    m, se = eng.price_european(P, 101.0, 0.04, T, True)
+    om, ose = orc.price_european(want, 101.0, 0.04, T, True)
+    assert abs(m - om) <= 1e-10 * om and abs(se - ose) <= 1e-8 * ose
+    P.free()
+
+
 @pytest.mark.parametrize("n_steps", [2, 3, 4, 5, 6, 9, 11])
 def test_gbm_block_loop_tails_and_64_bit_path_ids(eng, orc, n_steps):
     """The generator runs per Philox block (4 steps) with a tail of 1-3 steps, and the Philox counter carries the full
