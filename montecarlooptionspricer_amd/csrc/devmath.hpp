@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "philox.hpp"
 
 namespace mcg {
@@ -33,10 +35,37 @@ __device__ __forceinline__ double payoff_of(bool is_call, double s, double k) {
     return is_call ? fmax(0.0, s - k) : fmax(0.0, k - s);
 }
 
-// Butterfly sum over the 64 lanes of a wave; every lane ends with the total.
+// Butterfly sum over the 64 lanes of a wave (strides 32, 16, 8, 4, 2, 1); every lane ends with the total.
+// No LDS: strides 32 and 16 swap halves / rows between two copies of the value (v_permlane32_swap, v_permlane16_swap:
+// afterwards the two registers of a lane hold both addends of its butterfly), strides 8 .. 1 are DPP moves.  The stride-4
+// stage reads lane + 4 (mod 16) instead of lane ^ 4: after the stride-8 stage lanes l and l ^ 8 hold the same value, so
+// the addend is the same.  Bit-identical to the __shfl_xor butterfly it replaces (22 vector instructions per value
+// instead of six ~100-cycle trips through ds_bpermute: the per-date exchange of the LSM sweeps waits on this).
+// Must be called with all 64 lanes active.
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    typedef unsigned v2u __attribute__((ext_vector_type(2)));
+    {
+        const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+        const v2u l = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+        const v2u h = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        v = __hiloint2double((int)h.x, (int)l.x) + __hiloint2double((int)h.y, (int)l.y);
+    }
+    {
+        const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+        const v2u l = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+        const v2u h = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        v = __hiloint2double((int)h.x, (int)l.x) + __hiloint2double((int)h.y, (int)l.y);
+    }
+    auto dpp = [](double x, auto ctrl_tag) {
+        constexpr int ctrl = decltype(ctrl_tag)::value;
+        const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), ctrl, 0xF, 0xF, true);
+        const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), ctrl, 0xF, 0xF, true);
+        return __hiloint2double(hi, lo);
+    };
+    v += dpp(v, std::integral_constant<int, 0x128>{});  // row_ror:8
+    v += dpp(v, std::integral_constant<int, 0x124>{});  // row_ror:4
+    v += dpp(v, std::integral_constant<int, 0x4E>{});   // quad_perm [2,3,0,1]
+    v += dpp(v, std::integral_constant<int, 0xB1>{});   // quad_perm [1,0,3,2]
     return v;
 }
 

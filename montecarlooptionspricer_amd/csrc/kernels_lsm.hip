@@ -302,6 +302,18 @@ struct LsmCoopArgs {
     double* gather;
 };
 
+// -DMCG_LSM_TRACE (timing studies only): workgroup 0 stamps the phases of the first 32 exchanges of k_lsm_coop with the
+// 100 MHz wall clock; run_lsm_coop prints the differences to stderr.
+#ifdef MCG_LSM_TRACE
+__device__ unsigned long long g_lsm_trace[32 * 8];
+#define LSM_TRACE(round_, slot_)                                                             \
+    do {                                                                                     \
+        if (blockIdx.x == 0 && threadIdx.x == 0 && (round_) < 32) g_lsm_trace[(round_) * 8 + (slot_)] = wall_clock64(); \
+    } while (0)
+#else
+#define LSM_TRACE(round_, slot_) do { } while (0)
+#endif
+
 __device__ __forceinline__ bool lsm_is_sentinel(double v) {
     return (unsigned long long)__double_as_longlong(v) == (((unsigned long long)LSM_SENTINEL32 << 32) | LSM_SENTINEL32);
 }
@@ -440,11 +452,14 @@ __device__ __forceinline__ void lsm_reduce_solve_publish(const LsmCoopArgs& a, u
         }
     }
     if (GATHER) {
+        LSM_TRACE(round, 3);  // this wave's moments are in
         __syncthreads();
+        LSM_TRACE(round, 4);  // everybody's
         if (threadIdx.x == 0) {
             if (centered) lsm_solve_centered(sm_mom, NB, mu, a.K, sm_coef, ws);
             else lsm_solve_nb<NB>(sm_mom, 1.0, a.K, sm_coef);
         }
+        LSM_TRACE(round, 5);  // solved
         __syncthreads();
         return;
     }
@@ -489,6 +504,7 @@ __device__ __forceinline__ void lsm_exchange(const LsmCoopArgs& a, double (&m)[3
                                              int round, F&& after_publish) {
     if (a.gather) {  // (uniform) every workgroup gathers, reduces and solves by itself
         constexpr int NM = 3 * NB - 1;
+        LSM_TRACE(round, 1);  // moments accumulated
         block_sum<NM, 4>(m, red);
         if (threadIdx.x == 0) {
             double* slot = a.gather + (int64_t)round * NM * gridDim.x;
@@ -496,6 +512,7 @@ __device__ __forceinline__ void lsm_exchange(const LsmCoopArgs& a, double (&m)[3
             for (int t = 0; t < NM; ++t) lsm_st_shared(slot + (int64_t)t * gridDim.x + blockIdx.x, m[t]);
         }
         after_publish();
+        LSM_TRACE(round, 2);  // published, next row requested
         lsm_reduce_solve_publish<NB, true>(a, gridDim.x, parity, gave_up, sm_mom, sm_coef, centered, mu, ws, round);
         return;
     }
@@ -505,160 +522,12 @@ __device__ __forceinline__ void lsm_exchange(const LsmCoopArgs& a, double (&m)[3
     else lsm_poll_coefficients(a, parity, gave_up, sm_coef);
 }
 
-// Second launch bound = workgroups per CU the register budget must allow.
-template <int NB, int PPT, bool KEEP>
-__global__ __launch_bounds__(256, (PPT >= 16 ? 2 : 3)) void k_lsm_coop(LsmCoopArgs a) {
-    constexpr int NM = 3 * NB - 1;
-    __shared__ double red[NM * 4];
-    __shared__ double sm_mom[32];
-    __shared__ double sm_coef[16];
-    __shared__ double sm_ws[lsm_ws_doubles(NB)];
-    const bool call = a.is_call != 0;
-    const unsigned G = gridDim.x;
-    // Path q of this thread is column first + q * stride.  `first` is the only per-lane part of an address: rows and
-    // the q * stride offsets are wave-uniform and stay in scalar registers (a per-lane 64-bit address per path would
-    // cost as many VGPRs as V itself).
-    const unsigned first = blockIdx.x * 256u + threadIdx.x;
-    int64_t stride = (int64_t)G * 256;
-    // columns first + q * stride exist for q < n_live (one per-lane integer instead of PPT lane masks)
-    const int n_live = (int64_t)first < a.n ? (int)std::min<int64_t>(PPT, (a.n - 1 - first) / stride + 1) : 0;
-    int parity = 0, round = 0;         // round: exchanges so far (every workgroup counts alike; only workgroup 0 uses it)
-    bool gave_up = a.spin_limit == 0;  // this thread has hit the spin limit once (limit 0, tests: from the start)
-    if (gave_up && blockIdx.x == 0 && threadIdx.x == 0)
-        __hip_atomic_store(a.timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    double V[PPT];
-    {
-        const double* last = a.data + (int64_t)(a.n_cols - 1) * a.ld;
-#pragma unroll
-        for (int q = 0; q < PPT; ++q) {
-            const double* rq = last + (int64_t)q * stride;
-            V[q] = q < n_live ? payoff_of(call, rq[first], a.K) : 0.0;  // LSMPricer.cpp:37-40
-        }
-    }
-    // While the moments travel to workgroup 0 and the coefficients back (~10 us), the next date's row is already
-    // on its way from HBM into s_nxt -- when the registers allow a second row (PPT <= 16).
-    constexpr bool PREFETCH = PPT <= 16;
-    static_assert(KEEP, "the date's prices stay in registers between the regression pass and the update");
-    auto load_row = [&](int j, double (&dst)[PPT]) {
-        const double* row = a.data + (int64_t)j * a.ld;
-        // The PPT offsets q * stride are recomputed on the scalar unit for every row: as loop invariants hipcc
-        // hoists all of them, and 2 x PPT scalar registers do not exist.
-        asm volatile("" : "+s"(stride));
-#pragma unroll
-        for (int q = 0; q < PPT; ++q) {
-            const double* rq = row + (int64_t)q * stride;
-            dst[q] = q < n_live ? rq[first] : 0.0;
-        }
-    };
-    int j = a.n_cols - 2;
-    for (; j >= 0 && j * a.dt > a.maturity; --j) {  // LSMPricer.cpp:43-49, uniform over the grid
-#pragma unroll
-        for (int q = 0; q < PPT; ++q) V[q] *= a.disc;
-    }
-    double s_j[PPT], s_nxt[PREFETCH ? PPT : 1];
-    if (j >= 0) load_row(j, s_j);
-    for (; j >= 0; --j) {  // every remaining date regresses (this_time <= maturity from here on)
-        double m[NM];
-#pragma unroll
-        for (int q = 0; q < NM; ++q) m[q] = 0.0;
-#pragma unroll
-        for (int q = 0; q < PPT; ++q) {  // regression inputs, :51-74
-            const double s = s_j[q];
-            if (q < n_live && payoff_of(call, s, a.K) > 1e-14) {
-                const double x = fma(s, a.invK, -1.0);
-                const double y = V[q] * a.disc;
-                double pw = 1.0;
-#pragma unroll
-                for (int t = 0; t < 2 * NB - 1; ++t) {
-                    m[t] += pw;
-                    if (t < NB) m[2 * NB - 1 + t] = fma(pw, y, m[2 * NB - 1 + t]);
-                    pw *= x;
-                }
-            }
-        }
-        lsm_exchange<NB>(a, m, parity, gave_up, red, sm_mom, sm_coef, false, 0.0, sm_ws, round++, [&]() {
-            if constexpr (PREFETCH) {
-                if (j >= 1) load_row(j - 1, s_nxt);
-            }
-        });
-        if (__builtin_amdgcn_readfirstlane(sm_coef[LSM_C_REFINE] != 0.0 ? 1 : 0)) {  // (the same LDS word in every lane)
-            // Grid-uniform (every workgroup holds the same coefficient block): the date is re-fitted about the mean of its
-            // regressor -- the prices and V are still in registers -- through one more exchange (lsm_solve_nb).
-            const double mu = sm_coef[LSM_C_HINT];
-            __syncthreads();  // everyone has read the block before the next exchange rewrites sm_coef
-#pragma unroll
-            for (int q = 0; q < NM; ++q) m[q] = 0.0;
-#pragma unroll
-            for (int q = 0; q < PPT; ++q)
-                lsm_accumulate_centered<NB>(m, q < n_live && payoff_of(call, s_j[q], a.K) > 1e-14, s_j[q], V[q], a.invK, mu, a.disc);
-            parity ^= 1;
-            lsm_exchange<NB>(a, m, parity, gave_up, red, sm_mom, sm_coef, true, mu, sm_ws, round++, []() {});
-        }
-        double c[NB];
-#pragma unroll
-        for (int t = 0; t < NB; ++t) c[t] = sm_coef[t];
-        const double n_itm = sm_coef[LSM_C_COUNT], center = sm_coef[LSM_C_CENTER];
-#pragma unroll
-        for (int q = 0; q < PPT; ++q) {  // :78-94
-            const double s = s_j[q];
-            const double pay = payoff_of(call, s, a.K);
-            const double vn = V[q] * a.disc;
-            double v;
-            if (pay > 1e-14 && n_itm > 0.0) {
-                v = fmax(pay, lsm_continuation<NB>(c, center, fma(s, a.invK, -1.0)));
-            } else if (pay < 1e-14) {
-                v = vn;
-            } else {
-                v = 0.0;
-            }
-            V[q] = q < n_live ? v : 0.0;
-        }
-        if (j >= 1) {
-            if constexpr (PREFETCH) {
-#pragma unroll
-                for (int q = 0; q < PPT; ++q) s_j[q] = s_nxt[q];
-            } else {
-                load_row(j - 1, s_j);
-            }
-        }
-        parity ^= 1;
-    }
-    double f[2] = {0.0, 0.0};
-#pragma unroll
-    for (int q = 0; q < PPT; ++q) {
-        if (q < n_live) {
-            f[0] += V[q];
-            f[1] += V[q] * V[q];
-        }
-    }
-    __syncthreads();
-    block_sum<2, 4>(f, red);
-    if (threadIdx.x == 0) {
-        a.out[2 * (int64_t)blockIdx.x] = f[0];
-        a.out[2 * (int64_t)blockIdx.x + 1] = f[1];
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// The one-launch sweep for shards beyond the register-resident variant above: up to 64 paths per thread, i.e. 8.39M
-// paths on 512 co-resident workgroups (2 per CU) -- BASELINE.json's C5 shard (8M x 252) in ONE launch.
-// V lives in registers (two adjacent paths per 16-byte unit, NU units per thread: 128 of the 256 VGPRs at NU = 32),
-// which leaves no registers to stage loads in.  The path matrix therefore streams through an LDS ring filled by
-// LDS-DMA (global_load_lds_dwordx4: HBM -> LDS with no VGPR destination, 1 KiB per wave-instruction into the wave's
-// own slice of a slot, so no barrier guards the ring): 16 slots x 4 KiB = 64 KiB per workgroup, i.e. the loads of
-// eight units (S_j and S_{j-1}) are always in flight while one unit is being processed, and the first eight units
-// of the NEXT date are fetched while the moments and coefficients travel between the workgroups.
-// Per date j the loop is the per-date kernels' fused form -- update V with S_j, accumulate date j-1's moments from
-// S_{j-1} -- so every row is read twice, 16 B per path and date against their 32 (V never touches memory).  Reading
-// each row once would need it on chip between the two passes; tools/ubench_mall.hip shows the memory-side cache does
-// not provide that (a 64 MB row re-read 20 us later comes at HBM speed), and with V filling half the register file
-// the other half plus LDS cannot hold a row either.
-// Branch-free bodies (no exec-masked regions: the unrolled unit loop must stay one basic block so that the loads of
-// the next pipeline stage can be scheduled across it), written for the instruction count -- at 64 paths per thread
-// this loop, not HBM, is what a date costs.  PayoffFunction (include/core/common.h:8-14) as max(sg s + nsK, 0) with
-// (sg, nsK) = (1, -K) for a call and (-1, K) for a put: one FMA, same rounding as s - K / K - s.  A path that is not
-// in the money enters the sums with weight w = 0 (one select on the high word of 1.0), i.e. adds exact zeros; in the
-// money the products are the same x^t the other kernels form, bit for bit.
+// Branch-free per-path bodies of the one-launch sweeps (k_lsm_coop and k_lsm_big; no exec-masked regions: with 16 to 64
+// paths per thread the divergent `if (in the money)` of the per-date kernels costs more than the arithmetic it skips).
+// PayoffFunction (include/core/common.h:8-14) as max(sg s + nsK, 0) with (sg, nsK) = (1, -K) for a call and (-1, K) for a
+// put: one FMA, same rounding as s - K / K - s.  A path that is not in the money enters the sums with weight w = 0 (one
+// select on the high word of 1.0), i.e. adds exact zeros; in the money the products are the same x^t the other kernels
+// form, bit for bit.
 struct LsmPay {
     double sg, nsK;
 };
@@ -700,6 +569,181 @@ __device__ __forceinline__ double lsm_update(const LsmPay& p, double s, double v
     return lsm_select(__builtin_amdgcn_ballot_w64(pay > 1e-14) & any_itm, fmax(pay, cont), v);
 }
 
+#ifndef MCG_COOP_BRANCHFREE
+#define MCG_COOP_BRANCHFREE 0
+#endif
+// Second launch bound = workgroups per CU the register budget must allow.
+template <int NB, int PPT, bool KEEP>
+__global__ __launch_bounds__(256, (PPT >= 16 ? 2 : 3)) void k_lsm_coop(LsmCoopArgs a) {
+    constexpr int NM = 3 * NB - 1;
+    __shared__ double red[NM * 4];
+    __shared__ double sm_mom[32];
+    __shared__ double sm_coef[16];
+    __shared__ double sm_ws[lsm_ws_doubles(NB)];
+    const bool call = a.is_call != 0;
+    const unsigned G = gridDim.x;
+    // Path q of this thread is column first + q * stride.  `first` is the only per-lane part of an address: rows and
+    // the q * stride offsets are wave-uniform and stay in scalar registers (a per-lane 64-bit address per path would
+    // cost as many VGPRs as V itself).
+    const unsigned first = blockIdx.x * 256u + threadIdx.x;
+    int64_t stride = (int64_t)G * 256;
+    // columns first + q * stride exist for q < n_live (one per-lane integer instead of PPT lane masks)
+    const int n_live = (int64_t)first < a.n ? (int)std::min<int64_t>(PPT, (a.n - 1 - first) / stride + 1) : 0;
+    int parity = 0, round = 0;         // round: exchanges so far (every workgroup counts alike; only workgroup 0 uses it)
+    bool gave_up = a.spin_limit == 0;  // this thread has hit the spin limit once (limit 0, tests: from the start)
+    if (gave_up && blockIdx.x == 0 && threadIdx.x == 0)
+        __hip_atomic_store(a.timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    double V[PPT];
+    {
+        const double* last = a.data + (int64_t)(a.n_cols - 1) * a.ld;
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            const double* rq = last + (int64_t)q * stride;
+            V[q] = q < n_live ? payoff_of(call, rq[first], a.K) : 0.0;  // LSMPricer.cpp:37-40
+        }
+    }
+    // While the moments travel to workgroup 0 and the coefficients back (~10 us), the next date's row is already
+    // on its way from HBM into s_nxt -- when the registers allow a second row (PPT <= 16).
+    constexpr bool PREFETCH = PPT <= 16;
+    // A slot beyond the shard (q >= n_live) carries V = 0 and a price that is never in the money: it then adds exact
+    // zeros to every sum and keeps V = 0 through the update below, with no per-slot test in either loop.
+    const LsmPay pay{call ? 1.0 : -1.0, call ? -a.K : a.K};
+    const double dead = call ? 0.0 : 1e300;
+    static_assert(KEEP, "the date's prices stay in registers between the regression pass and the update");
+    auto load_row = [&](int j, double (&dst)[PPT]) {
+        const double* row = a.data + (int64_t)j * a.ld;
+        // The PPT offsets q * stride are recomputed on the scalar unit for every row: as loop invariants hipcc
+        // hoists all of them, and 2 x PPT scalar registers do not exist.
+        asm volatile("" : "+s"(stride));
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            const double* rq = row + (int64_t)q * stride;
+            dst[q] = q < n_live ? rq[first] : dead;
+        }
+    };
+    int j = a.n_cols - 2;
+    for (; j >= 0 && j * a.dt > a.maturity; --j) {  // LSMPricer.cpp:43-49, uniform over the grid
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) V[q] *= a.disc;
+    }
+    double s_j[PPT], s_nxt[PREFETCH ? PPT : 1];
+    if (j >= 0) load_row(j, s_j);
+    for (; j >= 0; --j) {  // every remaining date regresses (this_time <= maturity from here on)
+        LSM_TRACE(round, 0);
+        double m[NM];
+#pragma unroll
+        for (int q = 0; q < NM; ++q) m[q] = 0.0;
+#if MCG_COOP_BRANCHFREE
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) lsm_accumulate<NB>(m, pay, s_j[q], V[q], a.invK, a.disc);  // regression inputs, :51-74
+#else
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {  // regression inputs, :51-74
+            const double s = s_j[q];
+            if (q < n_live && payoff_of(call, s, a.K) > 1e-14) {
+                const double x = fma(s, a.invK, -1.0);
+                const double y = V[q] * a.disc;
+                double pw = 1.0;
+#pragma unroll
+                for (int t = 0; t < 2 * NB - 1; ++t) {
+                    m[t] += pw;
+                    if (t < NB) m[2 * NB - 1 + t] = fma(pw, y, m[2 * NB - 1 + t]);
+                    pw *= x;
+                }
+            }
+        }
+#endif
+        lsm_exchange<NB>(a, m, parity, gave_up, red, sm_mom, sm_coef, false, 0.0, sm_ws, round++, [&]() {
+            if constexpr (PREFETCH) {
+                if (j >= 1) load_row(j - 1, s_nxt);
+            }
+        });
+        if (__builtin_amdgcn_readfirstlane(sm_coef[LSM_C_REFINE] != 0.0 ? 1 : 0)) {  // (the same LDS word in every lane)
+            // Grid-uniform (every workgroup holds the same coefficient block): the date is re-fitted about the mean of its
+            // regressor -- the prices and V are still in registers -- through one more exchange (lsm_solve_nb).
+            const double mu = sm_coef[LSM_C_HINT];
+            __syncthreads();  // everyone has read the block before the next exchange rewrites sm_coef
+#pragma unroll
+            for (int q = 0; q < NM; ++q) m[q] = 0.0;
+#pragma unroll
+            for (int q = 0; q < PPT; ++q)
+                lsm_accumulate_centered<NB>(m, q < n_live && payoff_of(call, s_j[q], a.K) > 1e-14, s_j[q], V[q], a.invK, mu, a.disc);
+            parity ^= 1;
+            lsm_exchange<NB>(a, m, parity, gave_up, red, sm_mom, sm_coef, true, mu, sm_ws, round++, []() {});
+        }
+        double c[NB];
+#pragma unroll
+        for (int t = 0; t < NB; ++t) c[t] = sm_coef[t];
+        const double n_itm = sm_coef[LSM_C_COUNT], center = sm_coef[LSM_C_CENTER];
+#if MCG_COOP_BRANCHFREE
+        const unsigned long long any_itm = n_itm > 0.0 ? ~0ull : 0ull;  // (the same LDS word in every lane)
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) V[q] = lsm_update<NB>(pay, s_j[q], V[q], c, center, any_itm, a.invK, a.disc);  // :78-94
+#else
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {  // :78-94
+            const double s = s_j[q];
+            const double pay_q = payoff_of(call, s, a.K);
+            const double vn = V[q] * a.disc;
+            double v;
+            if (pay_q > 1e-14 && n_itm > 0.0) {
+                v = fmax(pay_q, lsm_continuation<NB>(c, center, fma(s, a.invK, -1.0)));
+            } else if (pay_q < 1e-14) {
+                v = vn;
+            } else {
+                v = 0.0;
+            }
+            V[q] = q < n_live ? v : 0.0;
+        }
+#endif
+        LSM_TRACE(round - 1, 6);  // V updated
+        if (j >= 1) {
+            if constexpr (PREFETCH) {
+#pragma unroll
+                for (int q = 0; q < PPT; ++q) s_j[q] = s_nxt[q];
+            } else {
+                load_row(j - 1, s_j);
+            }
+        }
+        LSM_TRACE(round - 1, 7);  // next row in registers
+        parity ^= 1;
+    }
+    double f[2] = {0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < PPT; ++q) {
+        if (q < n_live) {
+            f[0] += V[q];
+            f[1] += V[q] * V[q];
+        }
+    }
+    __syncthreads();
+    block_sum<2, 4>(f, red);
+    if (threadIdx.x == 0) {
+        a.out[2 * (int64_t)blockIdx.x] = f[0];
+        a.out[2 * (int64_t)blockIdx.x + 1] = f[1];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The one-launch sweep for shards beyond the register-resident variant above: up to 64 paths per thread, i.e. 8.39M
+// paths on 512 co-resident workgroups (2 per CU) -- BASELINE.json's C5 shard (8M x 252) in ONE launch.
+// V lives in registers (two adjacent paths per 16-byte unit, NU units per thread: 128 of the 256 VGPRs at NU = 32),
+// which leaves no registers to stage loads in.  The path matrix therefore streams through an LDS ring filled by
+// LDS-DMA (global_load_lds_dwordx4: HBM -> LDS with no VGPR destination, 1 KiB per wave-instruction into the wave's
+// own slice of a slot, so no barrier guards the ring): 16 slots x 4 KiB = 64 KiB per workgroup, i.e. the loads of
+// eight units (S_j and S_{j-1}) are always in flight while one unit is being processed, and the first eight units
+// of the NEXT date are fetched while the moments and coefficients travel between the workgroups.
+// Per date j the loop is the per-date kernels' fused form -- update V with S_j, accumulate date j-1's moments from
+// S_{j-1} -- so every row is read twice, 16 B per path and date against their 32 (V never touches memory).  Reading
+// each row once would need it on chip between the two passes; tools/ubench_mall.hip shows the memory-side cache does
+// not provide that (a 64 MB row re-read 20 us later comes at HBM speed), and with V filling half the register file
+// the other half plus LDS cannot hold a row either.
+// Branch-free bodies (no exec-masked regions: the unrolled unit loop must stay one basic block so that the loads of
+// the next pipeline stage can be scheduled across it), written for the instruction count -- at 64 paths per thread
+// this loop, not HBM, is what a date costs.  PayoffFunction (include/core/common.h:8-14) as max(sg s + nsK, 0) with
+// (sg, nsK) = (1, -K) for a call and (-1, K) for a put: one FMA, same rounding as s - K / K - s.  A path that is not
+// in the money enters the sums with weight w = 0 (one select on the high word of 1.0), i.e. adds exact zeros; in the
+// money the products are the same x^t the other kernels form, bit for bit.
 // f(integral_constant<int, I>) for I = 0 .. N-1: a loop whose index is a compile-time constant in the body
 // (immediate operands of inline asm, slot numbers)
 template <int I, int N, class F>
@@ -1073,6 +1117,18 @@ static int run_lsm_coop(mcg_ctx* ctx, const mcg_paths* P, double r, double K, do
         rc = finish_sums(ctx, workers, N, sums3);  // synchronises the stream
     }
     if (rc) return rc;
+#ifdef MCG_LSM_TRACE
+    {
+        unsigned long long tr[32 * 8];
+        if (hipMemcpyFromSymbol(tr, HIP_SYMBOL(g_lsm_trace), sizeof(tr)) == hipSuccess) {
+            for (int r = 4; r < 12; ++r) {
+                std::fprintf(stderr, "lsm trace round %2d (us):", r);
+                for (int k = 1; k < 8; ++k) std::fprintf(stderr, " %d:%.2f", k, (double)(tr[r * 8 + k] - tr[r * 8]) * 0.01);
+                std::fprintf(stderr, "  next:%.2f\n", (double)(tr[(r + 1) * 8] - tr[r * 8]) * 0.01);
+            }
+        }
+    }
+#endif
     int timed_out = reinterpret_cast<const unsigned*>(ctx->h_scalars + SC_BARRIER)[0] != 0 ? 1 : 0;
     if (mbox) {  // the ranks agree: one time-out anywhere voids the sweep everywhere (they fall back together)
         rc = shm_sum_flag(ctx, timed_out, &timed_out);

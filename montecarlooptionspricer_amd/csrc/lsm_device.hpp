@@ -36,10 +36,82 @@ __host__ __device__ constexpr int lsm_ws_doubles(int nb) { return 7 * nb * nb + 
 // K <= 0 switches the refinement request off.
 // NB is a template parameter so that every loop unrolls and G, Q live in registers: with a run-time size the
 // arrays go to scratch memory and the (serial, one-thread) solve takes ~20 us instead of ~2.
+// Fallback of lsm_solve_nb for a date whose equilibrated Gram matrix has no LDL^T factorisation (a pivot <= 1e-10:
+// fewer distinct in-the-money prices than basis functions): cyclic Jacobi, pseudo-inverse with relative eigenvalue cut
+// 1e-12.  buf = G[nb][nb] (equilibrated) | rhs[nb] (scaled) | d[nb] (the scaling); run-time nb, matrices in memory.  A
+// rare path -- and with refinement on (K > 0) its result is replaced by lsm_solve_centered's anyway -- kept out of line
+// so that its arrays do not count against the registers of the kernels that inline the fast path.
+__device__ __noinline__ void lsm_solve_jacobi(int nb, double* buf, double* coef) {
+    double* G = buf;
+    const double* rhs = buf + nb * nb;
+    const double* d = rhs + nb;
+    double Q[9 * 9], sol[9];
+    for (int a = 0; a < nb; ++a)
+        for (int b = 0; b < nb; ++b) Q[a * nb + b] = a == b ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 50; ++sweep) {
+        double off = 0.0;
+        for (int p = 0; p < nb; ++p)
+            for (int q = p + 1; q < nb; ++q) off += G[p * nb + q] * G[p * nb + q];
+        if (off < 1e-60) break;
+        for (int p = 0; p < nb - 1; ++p) {
+            for (int q = p + 1; q < nb; ++q) {
+                const double apq = G[p * nb + q];
+                if (apq == 0.0) continue;
+                const double theta = (G[q * nb + q] - G[p * nb + p]) / (2.0 * apq);
+                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double cs = 1.0 / sqrt(t * t + 1.0), sn = t * cs;
+                for (int k = 0; k < nb; ++k) {
+                    const double gkp = G[k * nb + p], gkq = G[k * nb + q];
+                    G[k * nb + p] = cs * gkp - sn * gkq;
+                    G[k * nb + q] = sn * gkp + cs * gkq;
+                }
+                for (int k = 0; k < nb; ++k) {
+                    const double gpk = G[p * nb + k], gqk = G[q * nb + k];
+                    G[p * nb + k] = cs * gpk - sn * gqk;
+                    G[q * nb + k] = sn * gpk + cs * gqk;
+                }
+                for (int k = 0; k < nb; ++k) {
+                    const double qkp = Q[k * nb + p], qkq = Q[k * nb + q];
+                    Q[k * nb + p] = cs * qkp - sn * qkq;
+                    Q[k * nb + q] = sn * qkp + cs * qkq;
+                }
+            }
+        }
+    }
+    double lmax = 0.0;
+    for (int a = 0; a < nb; ++a) lmax = fmax(lmax, G[a * nb + a]);
+    const double cut = lmax * 1e-12;
+    for (int a = 0; a < nb; ++a) sol[a] = 0.0;
+    for (int e = 0; e < nb; ++e) {
+        const double lam = G[e * nb + e];
+        if (!(lam > cut)) continue;
+        double proj = 0.0;
+        for (int a = 0; a < nb; ++a) proj += Q[a * nb + e] * rhs[a];
+        const double w = proj / lam;
+        for (int a = 0; a < nb; ++a) sol[a] += w * Q[a * nb + e];
+    }
+    for (int a = 0; a < nb; ++a) coef[a] = sol[a] * d[a];
+}
+
+// 1/x and x^(-1/2) for positive normal x from the hardware seeds (v_rcp_f64, v_rsq_f64) and two Newton steps (one
+// second-order step), <= 1 ulp: the solve runs on ONE thread between two grid-wide hand-shakes of the one-launch
+// sweeps, where the ~35 dependent instructions of a correctly rounded fp64 division (a dozen of them per date) were a
+// quarter of the date's 9 us.
+__device__ __forceinline__ double lsm_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return fma(fma(-x, r, 1.0), r, r);
+}
+__device__ __forceinline__ double lsm_rsqrt(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    const double e = fma(-(x * y), y, 1.0);  // 1 - x y^2
+    return fma(y * e, fma(e, 0.375, 0.5), y);
+}
+
 template <int NB>
 __device__ __forceinline__ void lsm_solve_nb(const double* moments, double min_count, double K, double* coef) {
     constexpr int nb = NB;
-    double G[NB][NB], Q[NB][NB], rhs[NB], d[NB], sol[NB];
+    double G[NB][NB], Q[NB][NB], rhs[NB], d[NB], sol[NB], inv_piv[NB];
     const double count = moments[0];
     coef[LSM_C_COUNT] = count;
     for (int a = 0; a < 9; ++a) coef[a] = 0.0;
@@ -47,40 +119,51 @@ __device__ __forceinline__ void lsm_solve_nb(const double* moments, double min_c
     coef[LSM_C_REFINE] = 0.0;
     coef[LSM_C_HINT] = 0.0;
     if (!(count >= min_count) || !(count > 0.0)) return;  // too few samples: coefficients stay 0
+#pragma unroll
     for (int a = 0; a < nb; ++a) {
         const double g = moments[2 * a];
-        d[a] = g > 0.0 ? 1.0 / sqrt(g) : 0.0;
+        d[a] = g > 0.0 ? lsm_rsqrt(g) : 0.0;
     }
+#pragma unroll
     for (int a = 0; a < nb; ++a) {
         rhs[a] = moments[2 * nb - 1 + a] * d[a];
+#pragma unroll
         for (int b = 0; b < nb; ++b) G[a][b] = moments[a + b] * d[a] * d[b];
     }
     // ---- fast path: LDL^T in Q (L below the diagonal, D on it) ----
+    // No early exit: a loop that can break is not unrolled, and its G / Q then live in scratch memory behind run-time
+    // indices (that was most of the 2 us this solve took between two grid-wide hand-shakes).  After a failed pivot the
+    // remaining columns are computed on a stand-in pivot of 1 and never used.
     bool ok = true;
     double piv_min = 1.0;
-    for (int j = 0; j < nb && ok; ++j) {
+#pragma unroll
+    for (int j = 0; j < nb; ++j) {
         double dj = G[j][j];
+#pragma unroll
         for (int k = 0; k < j; ++k) dj -= Q[j][k] * Q[j][k] * Q[k][k];
-        if (!(dj > 1e-10)) {
-            ok = false;
-            break;
-        }
-        piv_min = fmin(piv_min, dj);
+        const bool good = dj > 1e-10;
+        if (ok && good) piv_min = fmin(piv_min, dj);
+        ok = ok && good;
         Q[j][j] = dj;
-        const double inv = 1.0 / dj;
+        const double inv = lsm_rcp(good ? dj : 1.0);
+        inv_piv[j] = inv;
+#pragma unroll
         for (int i = j + 1; i < nb; ++i) {
             double v = G[i][j];
+#pragma unroll
             for (int k = 0; k < j; ++k) v -= Q[i][k] * Q[j][k] * Q[k][k];
             Q[i][j] = v * inv;
         }
     }
     bool trusted = ok;  // fast path accurate AND Eigen certainly at full rank
     if (nb > 1 && K > 0.0) {
-        const double mean_x = moments[1] / count;
-        const double var_x = fmax(moments[2] / count - mean_x * mean_x, 0.0);
+        const double inv_count = lsm_rcp(count);
+        const double mean_x = moments[1] * inv_count;
+        const double var_x = fmax(fma(moments[2], inv_count, -(mean_x * mean_x)), 0.0);
         const double mean_s = K * (1.0 + mean_x);
         const double scale = fmax(fabs(mean_s), 1.0);
-        const double ratio = K * sqrt(var_x) / (scale * scale);
+        // (an estimate compared with a threshold four orders of magnitude away: sqrt as x * x^(-1/2))
+        const double ratio = var_x > 0.0 ? K * (var_x * lsm_rsqrt(var_x)) * lsm_rcp(scale * scale) : 0.0;
         double est = 1.0;
         for (int t = 1; t < nb; ++t) est *= ratio;
         trusted = ok && piv_min > 1e-6 && est > 1e4 * nb * 2.220446049250313e-16;
@@ -90,66 +173,34 @@ __device__ __forceinline__ void lsm_solve_nb(const double* moments, double min_c
         }
     }
     if (ok) {
+#pragma unroll
         for (int i = 0; i < nb; ++i) {  // L y = rhs
             double v = rhs[i];
+#pragma unroll
             for (int k = 0; k < i; ++k) v -= Q[i][k] * sol[k];
             sol[i] = v;
         }
-        for (int i = 0; i < nb; ++i) sol[i] /= Q[i][i];
+#pragma unroll
+        for (int i = 0; i < nb; ++i) sol[i] *= inv_piv[i];
+#pragma unroll
         for (int i = nb - 1; i >= 0; --i) {  // L^T x = y
             double v = sol[i];
+#pragma unroll
             for (int k = i + 1; k < nb; ++k) v -= Q[k][i] * sol[k];
             sol[i] = v;
         }
+#pragma unroll
         for (int a = 0; a < nb; ++a) coef[a] = sol[a] * d[a];
         return;
     }
-    // ---- rank-deficient / ill-conditioned date: Jacobi pseudo-inverse ----
-    for (int a = 0; a < nb; ++a)
-        for (int b = 0; b < nb; ++b) Q[a][b] = a == b ? 1.0 : 0.0;
-    for (int sweep = 0; sweep < 50; ++sweep) {
-        double off = 0.0;
-        for (int p = 0; p < nb; ++p)
-            for (int q = p + 1; q < nb; ++q) off += G[p][q] * G[p][q];
-        if (off < 1e-60) break;
-        for (int p = 0; p < nb - 1; ++p) {
-            for (int q = p + 1; q < nb; ++q) {
-                const double apq = G[p][q];
-                if (apq == 0.0) continue;
-                const double theta = (G[q][q] - G[p][p]) / (2.0 * apq);
-                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                const double cs = 1.0 / sqrt(t * t + 1.0), sn = t * cs;
-                for (int k = 0; k < nb; ++k) {
-                    const double gkp = G[k][p], gkq = G[k][q];
-                    G[k][p] = cs * gkp - sn * gkq;
-                    G[k][q] = sn * gkp + cs * gkq;
-                }
-                for (int k = 0; k < nb; ++k) {
-                    const double gpk = G[p][k], gqk = G[q][k];
-                    G[p][k] = cs * gpk - sn * gqk;
-                    G[q][k] = sn * gpk + cs * gqk;
-                }
-                for (int k = 0; k < nb; ++k) {
-                    const double qkp = Q[k][p], qkq = Q[k][q];
-                    Q[k][p] = cs * qkp - sn * qkq;
-                    Q[k][q] = sn * qkp + cs * qkq;
-                }
-            }
-        }
+    // ---- rank-deficient / ill-conditioned date: Jacobi pseudo-inverse, out of line (lsm_solve_jacobi) ----
+    double buf[NB * NB + 2 * NB];
+    for (int a = 0; a < nb; ++a) {
+        for (int b = 0; b < nb; ++b) buf[a * nb + b] = G[a][b];
+        buf[nb * nb + a] = rhs[a];
+        buf[nb * nb + nb + a] = d[a];
     }
-    double lmax = 0.0;
-    for (int a = 0; a < nb; ++a) lmax = fmax(lmax, G[a][a]);
-    const double cut = lmax * 1e-12;
-    for (int a = 0; a < nb; ++a) sol[a] = 0.0;
-    for (int e = 0; e < nb; ++e) {
-        const double lam = G[e][e];
-        if (!(lam > cut)) continue;
-        double proj = 0.0;
-        for (int a = 0; a < nb; ++a) proj += Q[a][e] * rhs[a];
-        const double w = proj / lam;
-        for (int a = 0; a < nb; ++a) sol[a] += w * Q[a][e];
-    }
-    for (int a = 0; a < nb; ++a) coef[a] = sol[a] * d[a];
+    lsm_solve_jacobi(nb, buf, coef);
 }
 
 // The refined solve: Eigen's bdcSvd().solve(b) on the raw monomials (LSMPricer.cpp:76), reproduced from the moments
