@@ -522,8 +522,9 @@ __device__ __forceinline__ void lsm_exchange(const LsmCoopArgs& a, double (&m)[3
     else lsm_poll_coefficients(a, parity, gave_up, sm_coef);
 }
 
-// Branch-free per-path bodies of the one-launch sweeps (k_lsm_coop and k_lsm_big; no exec-masked regions: with 16 to 64
-// paths per thread the divergent `if (in the money)` of the per-date kernels costs more than the arithmetic it skips).
+// Branch-free per-path bodies of k_lsm_big (no exec-masked regions: the unrolled unit loop must stay one basic block so
+// that the loads of the next pipeline stage can be scheduled across it).  (Tried in k_lsm_coop too: at one wave per SIMD
+// and 16 paths per thread the branchy bodies are twice as fast there.)
 // PayoffFunction (include/core/common.h:8-14) as max(sg s + nsK, 0) with (sg, nsK) = (1, -K) for a call and (-1, K) for a
 // put: one FMA, same rounding as s - K / K - s.  A path that is not in the money enters the sums with weight w = 0 (one
 // select on the high word of 1.0), i.e. adds exact zeros; in the money the products are the same x^t the other kernels
@@ -569,9 +570,6 @@ __device__ __forceinline__ double lsm_update(const LsmPay& p, double s, double v
     return lsm_select(__builtin_amdgcn_ballot_w64(pay > 1e-14) & any_itm, fmax(pay, cont), v);
 }
 
-#ifndef MCG_COOP_BRANCHFREE
-#define MCG_COOP_BRANCHFREE 0
-#endif
 // Second launch bound = workgroups per CU the register budget must allow.
 template <int NB, int PPT, bool KEEP>
 __global__ __launch_bounds__(256, (PPT >= 16 ? 2 : 3)) void k_lsm_coop(LsmCoopArgs a) {
@@ -605,10 +603,6 @@ __global__ __launch_bounds__(256, (PPT >= 16 ? 2 : 3)) void k_lsm_coop(LsmCoopAr
     // While the moments travel to workgroup 0 and the coefficients back (~10 us), the next date's row is already
     // on its way from HBM into s_nxt -- when the registers allow a second row (PPT <= 16).
     constexpr bool PREFETCH = PPT <= 16;
-    // A slot beyond the shard (q >= n_live) carries V = 0 and a price that is never in the money: it then adds exact
-    // zeros to every sum and keeps V = 0 through the update below, with no per-slot test in either loop.
-    const LsmPay pay{call ? 1.0 : -1.0, call ? -a.K : a.K};
-    const double dead = call ? 0.0 : 1e300;
     static_assert(KEEP, "the date's prices stay in registers between the regression pass and the update");
     auto load_row = [&](int j, double (&dst)[PPT]) {
         const double* row = a.data + (int64_t)j * a.ld;
@@ -618,7 +612,7 @@ __global__ __launch_bounds__(256, (PPT >= 16 ? 2 : 3)) void k_lsm_coop(LsmCoopAr
 #pragma unroll
         for (int q = 0; q < PPT; ++q) {
             const double* rq = row + (int64_t)q * stride;
-            dst[q] = q < n_live ? rq[first] : dead;
+            dst[q] = q < n_live ? rq[first] : 0.0;
         }
     };
     int j = a.n_cols - 2;
@@ -633,10 +627,6 @@ __global__ __launch_bounds__(256, (PPT >= 16 ? 2 : 3)) void k_lsm_coop(LsmCoopAr
         double m[NM];
 #pragma unroll
         for (int q = 0; q < NM; ++q) m[q] = 0.0;
-#if MCG_COOP_BRANCHFREE
-#pragma unroll
-        for (int q = 0; q < PPT; ++q) lsm_accumulate<NB>(m, pay, s_j[q], V[q], a.invK, a.disc);  // regression inputs, :51-74
-#else
 #pragma unroll
         for (int q = 0; q < PPT; ++q) {  // regression inputs, :51-74
             const double s = s_j[q];
@@ -652,7 +642,6 @@ __global__ __launch_bounds__(256, (PPT >= 16 ? 2 : 3)) void k_lsm_coop(LsmCoopAr
                 }
             }
         }
-#endif
         lsm_exchange<NB>(a, m, parity, gave_up, red, sm_mom, sm_coef, false, 0.0, sm_ws, round++, [&]() {
             if constexpr (PREFETCH) {
                 if (j >= 1) load_row(j - 1, s_nxt);
@@ -675,27 +664,21 @@ __global__ __launch_bounds__(256, (PPT >= 16 ? 2 : 3)) void k_lsm_coop(LsmCoopAr
 #pragma unroll
         for (int t = 0; t < NB; ++t) c[t] = sm_coef[t];
         const double n_itm = sm_coef[LSM_C_COUNT], center = sm_coef[LSM_C_CENTER];
-#if MCG_COOP_BRANCHFREE
-        const unsigned long long any_itm = n_itm > 0.0 ? ~0ull : 0ull;  // (the same LDS word in every lane)
-#pragma unroll
-        for (int q = 0; q < PPT; ++q) V[q] = lsm_update<NB>(pay, s_j[q], V[q], c, center, any_itm, a.invK, a.disc);  // :78-94
-#else
 #pragma unroll
         for (int q = 0; q < PPT; ++q) {  // :78-94
             const double s = s_j[q];
-            const double pay_q = payoff_of(call, s, a.K);
+            const double pay = payoff_of(call, s, a.K);
             const double vn = V[q] * a.disc;
             double v;
-            if (pay_q > 1e-14 && n_itm > 0.0) {
-                v = fmax(pay_q, lsm_continuation<NB>(c, center, fma(s, a.invK, -1.0)));
-            } else if (pay_q < 1e-14) {
+            if (pay > 1e-14 && n_itm > 0.0) {
+                v = fmax(pay, lsm_continuation<NB>(c, center, fma(s, a.invK, -1.0)));
+            } else if (pay < 1e-14) {
                 v = vn;
             } else {
                 v = 0.0;
             }
             V[q] = q < n_live ? v : 0.0;
         }
-#endif
         LSM_TRACE(round - 1, 6);  // V updated
         if (j >= 1) {
             if constexpr (PREFETCH) {
