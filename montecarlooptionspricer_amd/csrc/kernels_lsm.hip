@@ -296,10 +296,6 @@ struct LsmCoopArgs {
     // nullptr on a single GPU
     double* mbox;
     int mb_ranks, mb_rank;
-    // k_lsm_coop, small grids on one GPU: every workgroup gathers ALL partial moments itself and solves redundantly
-    // (one trip through the coherence point per date instead of two): gather[round][NM][gridDim.x], sentinel-filled,
-    // every slot written once per sweep.  nullptr: workgroup 0 reduces, solves and publishes (above).
-    double* gather;
 };
 
 // -DMCG_LSM_TRACE (timing studies only): workgroup 0 stamps the phases of the first 32 exchanges of k_lsm_coop with the
@@ -394,14 +390,12 @@ __device__ __forceinline__ void lsm_node_allreduce(const LsmCoopArgs& a, int rou
 // centered: this round carries the moments of a refinement pass about `mu` (lsm_solve_nb asked for it on the previous
 // round of the same date); ws = LDS workspace of lsm_solve_centered; round = exchange counter of this sweep (the slot
 // of the node mailbox when the sweep is sharded over the GPUs of a node).
-// GATHER: called by EVERY workgroup on the round's own slots of a.gather: nothing is recycled and nothing published --
-// each workgroup ends with the same coefficient block in its own sm_coef (same values, same summation order).
-template <int NB, bool GATHER = false>
+template <int NB>
 __device__ __forceinline__ void lsm_reduce_solve_publish(const LsmCoopArgs& a, unsigned G, int parity, bool& gave_up, double* sm_mom,
                                                          double* sm_coef, bool centered, double mu, double* ws, int round) {
     constexpr int NM = 3 * NB - 1;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    double* part = GATHER ? a.gather + (int64_t)round * NM * G : a.partials + (int64_t)parity * NM * G;
+    double* part = a.partials + (int64_t)parity * NM * G;
     double* coef_now = a.coef + 16 * parity;
     for (int t0 = wave; t0 < NM; t0 += 8) {
         const int t1 = t0 + 4;
@@ -438,10 +432,8 @@ __device__ __forceinline__ void lsm_reduce_solve_publish(const LsmCoopArgs& a, u
             if (b < G) {
                 sum0 += v0[k];
                 sum1 += v1[k];
-                if (!GATHER) {
-                    lsm_st_shared(slot0 + b, lsm_sentinel());  // recycled two dates from now
-                    if (two) lsm_st_shared(slot1 + b, lsm_sentinel());
-                }
+                lsm_st_shared(slot0 + b, lsm_sentinel());  // recycled two dates from now
+                if (two) lsm_st_shared(slot1 + b, lsm_sentinel());
             }
         }
         sum0 = wave_sum(sum0);
@@ -451,26 +443,17 @@ __device__ __forceinline__ void lsm_reduce_solve_publish(const LsmCoopArgs& a, u
             if (two) sm_mom[t1] = sum1;
         }
     }
-    if (GATHER) {
-        LSM_TRACE(round, 3);  // this wave's moments are in
-        __syncthreads();
-        LSM_TRACE(round, 4);  // everybody's
-        if (threadIdx.x == 0) {
-            if (centered) lsm_solve_centered(sm_mom, NB, mu, a.K, sm_coef, ws);
-            else lsm_solve_nb<NB>(sm_mom, 1.0, a.K, sm_coef);
-        }
-        LSM_TRACE(round, 5);  // solved
-        __syncthreads();
-        return;
-    }
+    LSM_TRACE(round, 3);  // workgroup 0: this wave's moments are in
     // all partials of this date are in: every workgroup is past the previous date's coefficients
     if (threadIdx.x < LSM_COEF_DOUBLES) lsm_st_shared(a.coef + 16 * (parity ^ 1) + threadIdx.x, lsm_sentinel());
     if (a.mbox) lsm_node_allreduce<NM>(a, round, gave_up, sm_mom);  // (uniform) local -> node-wide moments
     __syncthreads();
+    LSM_TRACE(round, 4);  // everybody's
     if (threadIdx.x == 0) {
         if (centered) lsm_solve_centered(sm_mom, NB, mu, a.K, sm_coef, ws);
         else lsm_solve_nb<NB>(sm_mom, 1.0, a.K, sm_coef);
     }
+    LSM_TRACE(round, 5);  // solved
     __builtin_amdgcn_s_waitcnt(0);  // the recycling stores are acknowledged before anything newer goes out
     __syncthreads();
     if (threadIdx.x < LSM_COEF_DOUBLES) lsm_st_shared(coef_now + threadIdx.x, sm_coef[threadIdx.x]);
@@ -502,22 +485,10 @@ template <int NB, class F>
 __device__ __forceinline__ void lsm_exchange(const LsmCoopArgs& a, double (&m)[3 * NB - 1], int parity, bool& gave_up,
                                              double* red, double* sm_mom, double* sm_coef, bool centered, double mu, double* ws,
                                              int round, F&& after_publish) {
-    if (a.gather) {  // (uniform) every workgroup gathers, reduces and solves by itself
-        constexpr int NM = 3 * NB - 1;
-        LSM_TRACE(round, 1);  // moments accumulated
-        block_sum<NM, 4>(m, red);
-        if (threadIdx.x == 0) {
-            double* slot = a.gather + (int64_t)round * NM * gridDim.x;
-#pragma unroll
-            for (int t = 0; t < NM; ++t) lsm_st_shared(slot + (int64_t)t * gridDim.x + blockIdx.x, m[t]);
-        }
-        after_publish();
-        LSM_TRACE(round, 2);  // published, next row requested
-        lsm_reduce_solve_publish<NB, true>(a, gridDim.x, parity, gave_up, sm_mom, sm_coef, centered, mu, ws, round);
-        return;
-    }
+    LSM_TRACE(round, 1);  // moments accumulated
     lsm_publish_partials<NB>(a, m, gridDim.x, blockIdx.x, parity, red);
     after_publish();
+    LSM_TRACE(round, 2);  // published, next row requested
     if (blockIdx.x == 0) lsm_reduce_solve_publish<NB>(a, gridDim.x, parity, gave_up, sm_mom, sm_coef, centered, mu, ws, round);
     else lsm_poll_coefficients(a, parity, gave_up, sm_coef);
 }
@@ -572,7 +543,7 @@ __device__ __forceinline__ double lsm_update(const LsmPay& p, double s, double v
 
 // Second launch bound = workgroups per CU the register budget must allow.
 template <int NB, int PPT, bool KEEP>
-__global__ __launch_bounds__(256, (PPT >= 16 ? 2 : 3)) void k_lsm_coop(LsmCoopArgs a) {
+__global__ __launch_bounds__(256, (PPT >= 8 ? 2 : 3)) void k_lsm_coop(LsmCoopArgs a) {
     constexpr int NM = 3 * NB - 1;
     __shared__ double red[NM * 4];
     __shared__ double sm_mom[32];
@@ -960,12 +931,13 @@ struct CoopVariant {
     bool exact;     // occupancy is fixed by LDS (2 workgroups per CU): no margin below the query
 };
 
-constexpr int LSM_N_VARIANTS = 4;
+constexpr int LSM_N_VARIANTS = 5;
 
 template <int NB>
 const CoopVariant* coop_variants() {
     static const CoopVariant v[LSM_N_VARIANTS] = {
         {(const void*)k_lsm_coop<NB, 4, true>, 4, 0, false},
+        {(const void*)k_lsm_coop<NB, 8, true>, 8, 0, false},
         {(const void*)k_lsm_coop<NB, 16, true>, 16, 0, false},
         {(const void*)k_lsm_big<NB, 16>, 32, LSM_RING_SLOTS * 256 * sizeof(double2), true},
         {(const void*)k_lsm_big<NB, 32>, 64, LSM_RING_SLOTS * 256 * sizeof(double2), true}};
@@ -1006,6 +978,7 @@ static int run_lsm_coop(mcg_ctx* ctx, const mcg_paths* P, double r, double K, do
     int grid = 0, workers = 0;
     static const int min_ppt = std::getenv("MCG_LSM_COOP_MIN_PPT") ? std::atoi(std::getenv("MCG_LSM_COOP_MIN_PPT")) : 0;  // experiments
     static std::atomic<int> occ_cache[10][LSM_N_VARIANTS];  // workgroups per CU of each variant (0 = not asked yet); same on every device
+    static std::atomic<int> regs_cache[10][LSM_N_VARIANTS]; // its VGPR count (hipFuncGetAttributes)
     for (int k = 0; eligible && k < LSM_N_VARIANTS; ++k) {
         if (vars[k].ppt < min_ppt) continue;
         int occ = occ_cache[nb][k].load(std::memory_order_relaxed);
@@ -1018,14 +991,20 @@ static int run_lsm_coop(mcg_ctx* ctx, const mcg_paths* P, double r, double K, do
                 (void)hipGetLastError();
                 occ = -1;
             }
+            hipFuncAttributes fa;
+            if (hipFuncGetAttributes(&fa, vars[k].fn) == hipSuccess) regs_cache[nb][k].store(fa.numRegs, std::memory_order_relaxed);
+            else (void)hipGetLastError();
             occ_cache[nb][k].store(occ, std::memory_order_relaxed);
         }
         if (occ < 1) continue;
         // The occupancy query can read one workgroup per CU high for kernels with ~100 SGPRs (MI355X_MICROARCH.md,
         // "Correctness boundaries"), and nothing would reject the over-sized grid: stay an eighth below it -- except
         // where LDS alone fixes two workgroups per CU (k_lsm_big: 64 KiB each of the CU's 160).
-        const int64_t g_max = vars[k].exact ? std::min<int64_t>((int64_t)std::min(occ, 2) * ctx->n_cus, LSM_COOP_MAX_GRID)
-                                            : std::min<int64_t>((int64_t)std::min(occ, 4) * ctx->n_cus * 7 / 8, LSM_COOP_MAX_GRID);
+        // ... or the registers do: a kernel with more than 168 VGPRs cannot have a third workgroup (4 waves) on a CU
+        // whatever the query says (k_lsm_coop at 8 and 16 paths per thread).
+        const bool pinned = vars[k].exact || regs_cache[nb][k].load(std::memory_order_relaxed) > 168;
+        const int64_t g_max = pinned ? std::min<int64_t>((int64_t)std::min(occ, 2) * ctx->n_cus, LSM_COOP_MAX_GRID)
+                                     : std::min<int64_t>((int64_t)std::min(occ, 4) * ctx->n_cus * 7 / 8, LSM_COOP_MAX_GRID);
         const int64_t per_block = 256 * (int64_t)vars[k].ppt;
         // k_lsm_big: workgroup 0 only reduces and solves, the paths belong to workgroups 1 .. grid-1
         const int64_t extra = vars[k].exact ? 1 : 0;
@@ -1044,15 +1023,11 @@ static int run_lsm_coop(mcg_ctx* ctx, const mcg_paths* P, double r, double K, do
     }
     if (!use) return MCG_OK;
     // buffer: {sum, sum^2} per contributing workgroup | [2][nm][workers] moment slots | [2][16] coefficient slots
-    //         | (gather mode) [rounds][nm][grid] moment slots, written once each
-    // Gather mode: k_lsm_coop<NB, 16> on one GPU.  Measured on the 50-date sweep (ms, reducer / gather): 600k paths
-    // 0.535 / 0.430, 1M 0.592 / 0.455, 1.8M 0.780 / 0.696 -- one trip through the coherence point per date instead of two;
-    // with 4 paths per thread (three workgroups per CU, <= 0.5M paths) the reducer is the faster one (250k: 0.380 / 0.486).
-    static const bool gather_off = std::getenv("MCG_LSM_NO_GATHER") != nullptr;  // experiments
-    const bool gather = !use->exact && use->ppt == 16 && !mbox && !gather_off;
+    // (Until the per-date solve left scratch memory, workgroups of small grids gathered ALL partial moments themselves and
+    // solved redundantly -- one trip per date instead of two.  With a 1-us solve the single reducer is as fast at 244
+    // workgroups and twice as fast at 488, where the gathering workgroups' polls crowd out the stores they wait for.)
     const size_t n_slots = 2 * (size_t)nm * workers + 32;
-    const size_t n_gather = gather ? (size_t)rounds_needed * nm * grid : 0;
-    int rc = ensure_cap(ctx, &ctx->partials, &ctx->partials_cap, 2 * (size_t)workers + n_slots + n_gather);
+    int rc = ensure_cap(ctx, &ctx->partials, &ctx->partials_cap, 2 * (size_t)workers + n_slots);
     if (rc) return rc;
     LsmCoopArgs a;
     a.data = P->data;
@@ -1075,10 +1050,9 @@ static int run_lsm_coop(mcg_ctx* ctx, const mcg_paths* P, double r, double K, do
     a.mbox = mbox;
     a.mb_ranks = shm_n_ranks(ctx);
     a.mb_rank = shm_rank(ctx);
-    a.gather = gather ? a.coef + 32 : nullptr;
     a.spin_limit = LSM_SPIN_LIMIT;
     if (const char* e = std::getenv("MCG_LSM_SPIN_LIMIT")) a.spin_limit = (unsigned)std::strtoul(e, nullptr, 10);
-    MCG_HIP(hipMemsetD32Async((hipDeviceptr_t)a.partials, (int)LSM_SENTINEL32, 2 * (n_slots + n_gather), ctx->stream));
+    MCG_HIP(hipMemsetD32Async((hipDeviceptr_t)a.partials, (int)LSM_SENTINEL32, 2 * n_slots, ctx->stream));
     MCG_HIP(hipMemsetAsync(a.timeout, 0, sizeof(unsigned), ctx->stream));
     if (mbox) {  // this rank's mailbox rows hold the reserved NaN again, and so do everybody else's, before anyone launches
         rc = shm_arm_mailbox(ctx, rounds_needed, ((uint64_t)LSM_SENTINEL32 << 32) | LSM_SENTINEL32);
