@@ -213,8 +213,8 @@ def extra_configs(eng, N) -> list:
                 kernels[kname]["hbm_frac"] = b / (kernels[kname]["ms_per_pass"] * 1e-3) / 1e9 / HBM_PEAK_GBS
         if "lsm_sweep" in kernels:
             # what the one-launch sweeps are designed to move: 8 B per path and date with the row kept in registers
-            # (<= 1.8M paths), 16 B when it streams through the LDS ring (k_lsm_big); V never touches memory
-            moved = (8.0 if paths <= 1_800_000 else 16.0) * steps * paths
+            # (<= 2.09M paths = 512 workgroups x 4096), 16 B when it streams through the LDS ring (k_lsm_big); V never touches memory
+            moved = (8.0 if paths <= 2_097_152 else 16.0) * steps * paths
             kernels["lsm_sweep"]["design_bytes_per_pass"] = moved
             kernels["lsm_sweep"]["hbm_frac_of_design_bytes"] = moved / (kernels["lsm_sweep"]["ms_per_pass"] * 1e-3) / 1e9 / HBM_PEAK_GBS
         dom = max(alg, key=lambda k: kernels.get(k, {}).get("ms_per_pass", 0.0))
@@ -454,7 +454,7 @@ def main() -> None:
                 "hbm_frac": 40.0 * n_steps * count / max(sweep_ms / per_pass * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS,
                 "design_bytes_per_pass": design,   # what this execution shape moves: 16 B one-launch (k_lsm_big), 32 B per-date kernels
                 "hbm_frac_of_design_bytes": design / max(sweep_ms / per_pass * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS,
-                "shape": "one launch (V in registers; beyond 1.8M paths the matrix streams through an LDS-DMA ring)" if one_launch
+                "shape": "one launch (V in registers; beyond 2.09M paths the matrix streams through an LDS-DMA ring)" if one_launch
                          else "per-date kernels (one all-reduce of 8 moments per exercise date)"}
             pmc5 = os.path.join(ROOT, "profiles", "r02_c5_pmc_traffic.json")
             if os.path.exists(pmc5) and count == 8_000_000 and n_steps == 252:
