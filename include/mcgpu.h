@@ -139,7 +139,7 @@ int mcg_price_european(mcg_ctx* ctx, const mcg_paths* paths, double K, double r,
 int mcg_price_lsm(mcg_ctx* ctx, const mcg_paths* paths, double r, double K, double maturity,
                   double dt, int is_call, int poly_order, double* mean, double* std_err);
 
-/* Whether this ctx still uses the one-launch LSM sweep (single GPU, <= ~1.8M paths): it is switched off for the
+/* Whether this ctx still uses the one-launch LSM sweep (one launch per price up to 8.37M paths per GPU, order <= 4): it is switched off for the
  * rest of the ctx's life when the in-kernel hand-shake between workgroups ever times out (another process holding
  * part of the GPU); mcg_price_lsm then answers from the per-date kernels, as it does for that call already. */
 int mcg_lsm_one_launch_enabled(mcg_ctx* ctx, int* enabled);
