@@ -258,13 +258,17 @@ def test_lsm_matches_oracle_on_same_paths(eng, orc, is_call, poly):
 
 @pytest.mark.parametrize("n,steps,poly,call", [(300_000, 20, 2, False), (1_200_000, 12, 3, False), (3_000_000, 6, 2, False),
                                                (70_000, 30, 4, False), (5_000, 9, 0, False), (2_400_001, 7, 2, True),
-                                               (5_000_000, 5, 2, False), (8_300_003, 4, 1, False), (6_100_000, 4, 4, False)])
+                                               (5_000_000, 5, 2, False), (8_300_003, 4, 1, False), (6_100_000, 4, 4, False),
+                                               (524_288, 8, 2, False), (524_289, 8, 2, False), (800_001, 10, 3, True),
+                                               (1_048_576, 6, 2, False), (1_048_577, 6, 2, False),
+                                               (2_097_152, 5, 2, False), (2_097_153, 5, 2, False)])
 def test_lsm_single_launch_sweep_equals_per_date_kernels(eng, n, steps, poly, call):
     """Single GPU runs the whole sweep as one launch (V in registers, workgroups exchanging moments and coefficients
     through sentinel slots); a context with a collective installed takes the per-date kernels.  Same arithmetic,
     different summation order of the moments: prices agree to rounding.  The sizes hit the register-resident variants
-    (4 and 16 paths per thread) and both LDS-ring variants (32 and 64 paths per thread, up to 8.37M paths; odd path
-    counts leave the shard's last unit half empty and its last workgroups short)."""
+    (4, 8 and 16 paths per thread: 512 workgroups x 1024 / 2048 / 4096 paths, each boundary from both sides) and both
+    LDS-ring variants (32 and 64 paths per thread, up to 8.37M paths; odd path counts leave the shard's last unit half
+    empty and its last workgroups short)."""
     import montecarlooptionspricer_amd as mc
     dt = 1.0 / steps
     P = eng.gbm(SEED + 1, 100.0, 0.04, 0.25, dt, steps, n)
