@@ -1,4 +1,4 @@
-"""C5 at its real shard size, and the N>1 PRODUCT path with two real ranks (run with -m gpu on an MI355X).
+"""C5 at its real shard size, and the N>1 PRODUCT path with two (and four) real ranks (run with -m gpu on an MI355X).
 
   * test_c5_shard_full_size: BASELINE.json configs[4] as one of its eight shards -- rBergomi (H = 0.1, eta = 1.9)
     8M paths x 252 steps, American put, LSM order 2 -- through the per-date kernels every sharded run takes, once
@@ -61,19 +61,22 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("mode", ["gloo", "shm", "shm_timeout"])
+@pytest.mark.parametrize("mode", ["gloo", "shm", "shm_timeout", "shm4"])
 def test_two_rank_processes_equal_single_rank(tmp_path, mode):
     """mode "gloo": a host all-reduce callback, the per-date LSM kernels (what RCCL runs use).  mode "shm": the
     library's node-local shared-memory communicator -- each rank's LSM sweep is ONE launch, and the two persistent
     kernels exchange their per-date moments through the device-mapped mailbox while both are resident on the GPU.
     mode "shm_timeout": the same with every hand-shake forced to give up: the ranks agree (sum of their time-out flags)
-    to discard the sweep and answer from the per-date kernels over the segment's host all-reduce."""
+    to discard the sweep and answer from the per-date kernels over the segment's host all-reduce.  mode "shm4": FOUR ranks
+    on the one GPU through the shared-memory communicator (four mailbox rows per round, four persistent grids resident
+    together), unequal shards."""
     sys.path.insert(0, HERE)
     from mp_rank_worker import JOBS
 
-    world, port, out = 2, _free_port(), str(tmp_path / "res.json")
+    world, port, out = (4 if mode == "shm4" else 2), _free_port(), str(tmp_path / "res.json")
+    worker_mode = "shm" if mode == "shm4" else mode
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "mp_rank_worker.py"), str(r), str(world), str(port), out, mode],
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "mp_rank_worker.py"), str(r), str(world), str(port), out, worker_mode],
                               env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     logs = []
     for p in procs:
@@ -109,12 +112,12 @@ def test_two_rank_processes_equal_single_rank(tmp_path, mode):
         if mode == "gloo":
             assert res["allreduce_calls"] == {"3": 4, "8": JOBS["lsm_steps"] + JOBS["rb_steps"]}
             assert res["gbm_lsm_sweep_launches"] == JOBS["lsm_steps"] + 2          # one per date + terminal + final sums
-        elif mode == "shm":
+        elif mode in ("shm", "shm4"):
             assert res["one_launch_enabled"], "\n".join(logs)                       # no hand-shake ever timed out
             assert res["gbm_lsm_sweep_launches"] == 1 and res["rb_lsm_sweep_launches"] == 1
         else:   # forced time-out: the void sweep (1 launch) is discarded on BOTH ranks, the per-date kernels answer
             assert not res["one_launch_enabled"]
             assert res["gbm_lsm_sweep_launches"] == 1 + JOBS["lsm_steps"] + 2
             assert res["rb_lsm_sweep_launches"] == JOBS["rb_steps"] + 2              # sticky: no second attempt
-    assert ranks[0]["shard"][0] == 0 and ranks[1]["shard"][0] % 2 == 0
-    assert ranks[0]["shard"][1] + ranks[1]["shard"][1] == JOBS["rb_paths"]
+    assert ranks[0]["shard"][0] == 0 and all(r["shard"][0] % 2 == 0 for r in ranks)
+    assert sum(r["shard"][1] for r in ranks) == JOBS["rb_paths"]
