@@ -6,7 +6,7 @@
 // checked against mpmath in tests (mcg_debug_eval).
 //
 //   scaled_exp(S, a)        S * e^a           any finite a (overflow -> inf, underflow -> 0)
-//   neg2log(u, tab)         -2 ln u           u in (0, 1); 128-entry {1/c, -2 ln c} table in LDS
+//   neg2log(u, tab)         -2 ln u           u in (0, 1); 1024-entry {1/c, -2 ln c} table in LDS
 //   sqrt_pos(x)             sqrt(x)           x in [1e-300, 1e300], no denormal/negative handling
 //   sincos_table(wb, tab)   cos/sin(2 pi f)   f = ((wb >> 8) + 1/2) 2^-24, from the raw Philox word; 512-entry table
 //   normal_quad_fast(...)   the four normals of one Philox block (philox.hpp's contract)
@@ -22,7 +22,7 @@
 namespace mcg {
 namespace fm {
 
-constexpr int LOG_TAB_ENTRIES = 128;     // x 16 B = 2 KiB of LDS per workgroup
+constexpr int LOG_TAB_ENTRIES = 1024;    // x 16 B = 16 KiB of LDS per workgroup
 constexpr int SINCOS_TAB_ENTRIES = 512;  // x 16 B = 8 KiB
 
 // The two lookup tables as they sit in LDS (and, back to back, in the device buffer they are
@@ -111,11 +111,8 @@ __device__ __forceinline__ void horner2(double& qa, double& qb, double ra, doubl
 // reads hipcc puts an `s_nop 0` (it cannot see that the statement is a plain FMA); inside a statement there is none,
 // and dependent VALU instructions need none.
 #define MCG_H2(n) "v_fma_f64 %0, %0, %2, %" #n "\n\tv_fma_f64 %1, %1, %3, %" #n "\n\t"
-__device__ __forceinline__ void horner2x5(double& qa, double& qb, double ra, double rb, double c1, double c2, double c3,
-                                          double c4, double c5) {
-    asm(MCG_H2(4) MCG_H2(5) MCG_H2(6) MCG_H2(7) MCG_H2(8)
-        : "+v"(qa), "+v"(qb)
-        : "v"(ra), "v"(rb), "s"(c1), "s"(c2), "s"(c3), "s"(c4), "s"(c5));
+__device__ __forceinline__ void horner2x3(double& qa, double& qb, double ra, double rb, double c1, double c2, double c3) {
+    asm(MCG_H2(4) MCG_H2(5) MCG_H2(6) : "+v"(qa), "+v"(qb) : "v"(ra), "v"(rb), "s"(c1), "s"(c2), "s"(c3));
 }
 __device__ __forceinline__ void horner2x6(double& qa, double& qb, double ra, double rb, double c1, double c2, double c3,
                                           double c4, double c5, double c6) {
@@ -216,9 +213,9 @@ __device__ __forceinline__ double scaled_exp_small6(double S, double a) {
     return __builtin_fma(S, em1, S);
 }
 
-// -2 ln u for u in (0,1).  u = z * 2^k with z = frexp mantissa in [0.5, 1) (v_frexp_exp_i32_f64, v_frexp_mant_f64); i = top seven mantissa bits = interval of z, r = z/c_i - 1 via one FMA with the tabulated 1/c_i;
-// ln z = ln c_i + log1p(r), log1p(r) = r + r^2 q(r), q of degree 5 on |r| <= 0.0045 (max rel err 2^-61.6).
-// The last interval [1 - 2^-8, 1) has c = 1 exactly, so u -> 1 keeps full relative accuracy (no cancellation).
+// -2 ln u for u in (0,1).  u = z * 2^k with z = frexp mantissa in [0.5, 1) (v_frexp_exp_i32_f64, v_frexp_mant_f64); i = top ten mantissa bits = interval of z, r = z/c_i - 1 via one FMA with the tabulated 1/c_i;
+// ln z = ln c_i + log1p(r), log1p(r) = r + r^2 q(r), q of degree 3 on |r| <= 2^-11 (max rel err 2^-60.4; 1024 intervals -- with 128 it took degree 5, two FMAs more per pair).
+// The last interval [1 - 2^-11, 1) has c = 1 exactly, so u -> 1 keeps full relative accuracy (no cancellation).
 // tab: LDS, entry i = {1/c_i, -2 ln c_i}.
 struct LogSplit {
     double z;      // mantissa in [0.5, 1)
@@ -229,7 +226,7 @@ __device__ __forceinline__ LogSplit log_split(double u) {
     const uint32_t hi = (uint32_t)__double2hiint(u);
     LogSplit s;
     s.k = __builtin_amdgcn_frexp_exp(u);
-    s.idx = (hi >> 13) & 127u;
+    s.idx = (hi >> 10) & 1023u;
     s.z = __builtin_amdgcn_frexp_mant(u);  // (a v_and_or on the high word costs two register copies on top)
     return s;
 }
@@ -237,12 +234,10 @@ __device__ __forceinline__ LogSplit log_split(double u) {
 // (split, table entry) -> -2 ln u
 __device__ __forceinline__ double neg2log_entry(const LogSplit& sp, const double2 e) {
     const double r = __builtin_fma(sp.z, e.x, -1.0);
-    double q = 0x1.24940e22d9958p-3;
-    q = fma_sc(q, r, -0x1.555752f357b5cp-3);
-    q = fma_sc(q, r, 0x1.99999998b8291p-3);
-    q = fma_sc(q, r, -0x1.ffffffff02617p-3);
-    q = fma_sc(q, r, 0x1.5555555555556p-2);
-    q = fma_sc(q, r, -0x1.0000000000000p-1);
+    double q = 0x1.99999e5b2a5bcp-3;
+    q = fma_sc(q, r, -0x1.000002c63f1bap-2);
+    q = fma_sc(q, r, 0x1.5555555555542p-2);
+    q = fma_sc(q, r, -0x1.fffffffffffe9p-2);
     const double l1p = __builtin_fma(r * r, q, r);  // log1p(r)
     // -2 ln u = -2 k ln2 + (-2 ln c) - 2 log1p(r)
     const double base = __builtin_fma((double)sp.k, -0x1.62e42fefa39efp+0, e.y);
@@ -252,9 +247,8 @@ __device__ __forceinline__ double neg2log_entry(const LogSplit& sp, const double
 __device__ __forceinline__ void neg2log_entry2(const LogSplit& s0, const double2 e0, const LogSplit& s1, const double2 e1,
                                                double& out0, double& out1) {
     const double r0 = __builtin_fma(s0.z, e0.x, -1.0), r1 = __builtin_fma(s1.z, e1.x, -1.0);
-    double q0 = 0x1.24940e22d9958p-3, q1 = 0x1.24940e22d9958p-3;
-    horner2x5(q0, q1, r0, r1, -0x1.555752f357b5cp-3, 0x1.99999998b8291p-3, -0x1.ffffffff02617p-3, 0x1.5555555555556p-2,
-              -0x1.0000000000000p-1);
+    double q0 = 0x1.99999e5b2a5bcp-3, q1 = 0x1.99999e5b2a5bcp-3;
+    horner2x3(q0, q1, r0, r1, -0x1.000002c63f1bap-2, 0x1.5555555555542p-2, -0x1.fffffffffffe9p-2);
     const double l0 = __builtin_fma(r0 * r0, q0, r0), l1 = __builtin_fma(r1 * r1, q1, r1);
     out0 = __builtin_fma(-2.0, l0, __builtin_fma((double)s0.k, -0x1.62e42fefa39efp+0, e0.y));
     out1 = __builtin_fma(-2.0, l1, __builtin_fma((double)s1.k, -0x1.62e42fefa39efp+0, e1.y));
@@ -271,12 +265,10 @@ __device__ __forceinline__ double neg2log_scaled(double u, const double2* tab, d
     const LogSplit sp = log_split(u);
     const double2 e = tab[sp.idx];
     const double r = __builtin_fma(sp.z, e.x, -1.0);
-    double q = 0x1.24940e22d9958p-3;
-    q = fma_sc(q, r, -0x1.555752f357b5cp-3);
-    q = fma_sc(q, r, 0x1.99999998b8291p-3);
-    q = fma_sc(q, r, -0x1.ffffffff02617p-3);
-    q = fma_sc(q, r, 0x1.5555555555556p-2);
-    q = fma_sc(q, r, -0x1.0000000000000p-1);
+    double q = 0x1.99999e5b2a5bcp-3;
+    q = fma_sc(q, r, -0x1.000002c63f1bap-2);
+    q = fma_sc(q, r, 0x1.5555555555542p-2);
+    q = fma_sc(q, r, -0x1.fffffffffffe9p-2);
     const double l1p = __builtin_fma(r * r, q, r);
     const double base = __builtin_fma((double)sp.k, c_k, e.y);
     return __builtin_fma(c_l, l1p, base);
@@ -385,7 +377,7 @@ __device__ __forceinline__ void normal_quad_fast(uint32_t k0, uint32_t k1, uint6
     z[3] = r1 * __builtin_fma(a1.y, cd1, a1.x * sd1);
 }
 
-// Cooperative copy of both tables (global, 10 KiB) into LDS; call before the first normal and
+// Cooperative copy of both tables (global, 24 KiB) into LDS; call before the first normal and
 // follow with __syncthreads().
 __device__ __forceinline__ void load_tables(Tables* lds, const double2* __restrict__ gtab) {
     double2* dst = reinterpret_cast<double2*>(lds);

@@ -254,7 +254,7 @@ static int init_impl(mcg_ctx** out, int device, bool adopt, void* external_strea
     }
     if (hipMalloc((void**)&ctx->log_tab, sizeof(fm::LOG_TAB_HOST) + sizeof(fm::SINCOS_TAB_HOST)) != hipSuccess ||
         hipMemcpy(ctx->log_tab, fm::LOG_TAB_HOST, sizeof(fm::LOG_TAB_HOST), hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(ctx->log_tab + 256, fm::SINCOS_TAB_HOST, sizeof(fm::SINCOS_TAB_HOST), hipMemcpyHostToDevice) !=
+        hipMemcpy(ctx->log_tab + sizeof(fm::LOG_TAB_HOST) / sizeof(double), fm::SINCOS_TAB_HOST, sizeof(fm::SINCOS_TAB_HOST), hipMemcpyHostToDevice) !=
             hipSuccess) {
         mcg_finalize(ctx);
         return fail(MCG_ERR_OOM, "table upload failed");

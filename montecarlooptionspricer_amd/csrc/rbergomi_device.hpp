@@ -70,7 +70,8 @@ __host__ __device__ inline int rb_pairs_per_block(int M) { return M < 32 ? 256 :
 #ifndef RB_EAGER_PRICE
 #define RB_EAGER_PRICE true
 #endif
-__host__ __device__ inline int rb_stage_bufs(int M) { return rb_log_tiles(M) == 2 ? RB_NBUF : 1; }
+// (one buffer from Mz = 1024 on: with the 24 KiB of generator tables next to it, two would leave room for one workgroup per CU only)
+__host__ __device__ inline int rb_stage_bufs(int M) { return rb_log_tiles(M) == 2 && M < 1024 ? RB_NBUF : 1; }
 __host__ __device__ inline size_t rb_stage_units(int M) {  // double2 units per buffer
     return M < 32 ? 0 : (size_t)(M >> rb_log_tiles(M)) * (size_t)(rb_pairs_per_block(M) + 1);
 }
@@ -221,7 +222,7 @@ __device__ __forceinline__ void rb_fft_block(const RbArgs& a, const RbLds& L, in
     constexpr int NT = 1 << LT;  // 4-step tiles per lane
     constexpr int PW = 4 * P;    // pairs per workgroup
     constexpr int RS = PW + 1;   // staging row stride in 16-byte units (one unit of padding)
-    constexpr int NBUF = LT == 2 ? RB_NBUF : 1;
+    constexpr int NBUF = (LT == 2 && LG < 6) ? RB_NBUF : 1;  // = rb_stage_bufs(Mz)
     const int lane = tid & 63, wave = tid >> 6;
     const int g = lane >> (6 - LG), c = lane & (P - 1);
     const int64_t q = block_index * (4 * P) + wave * P + c;  // pair index within the launch

@@ -89,29 +89,38 @@ hi = struct.unpack("<d", struct.pack("<Q", bits))[0]
 print(hi.hex(), float(ln2 - mp.mpf(hi)).hex(), float(1 / ln2).hex())
 
 
-# ---- log table: 128 intervals of width 2^-8 over z in [0.5, 1) (z = frexp mantissa of u, so the interval index is
-# the top seven mantissa bits); entry = {invc, -2*log(c)} with c := 1/invc evaluated from the ROUNDED invc so that
-# log z = log c + log1p(z*invc - 1) holds exactly.  The last interval [1 - 2^-8, 1) uses c = 1 exactly (r = z - 1 is
-# then exact and the logarithm stays relatively accurate as u -> 1).
+# ---- log table: 2^LOG_BITS intervals over z in [0.5, 1) (z = frexp mantissa of u, so the interval index is the top
+# LOG_BITS mantissa bits); entry = {invc, -2*log(c)} with c := 1/invc evaluated from the ROUNDED invc so that
+# log z = log c + log1p(z*invc - 1) holds exactly.  The last interval uses c = 1 exactly (r = z - 1 is then exact and
+# the logarithm stays relatively accurate as u -> 1).  1024 intervals (16 KiB of LDS) keep |r| <= 2^-11, where
+# log1p(r) = r + r^2 q(r) needs q of degree 3 only (128 intervals: degree 5, two FMAs more per Box-Muller pair).
+LOG_BITS = 10
+LOG_R = None
+
+
 def log_table(path):
+    global LOG_R
+    n = 1 << LOG_BITS
+    w = mp.mpf(2) ** -(LOG_BITS + 1)
     rows = []
     worst_r = mp.mpf(0)
-    for i in range(128):
-        a = mp.mpf("0.5") + i * mp.mpf(2) ** -8
-        b = a + mp.mpf(2) ** -8
+    for i in range(n):
+        a = mp.mpf("0.5") + i * w
+        b = a + w
         c = (a + b) / 2
-        if i == 127:
+        if i == n - 1:
             c = mp.mpf(1)       # u -> 1-: r = z - 1 exactly, no cancellation against ln c
         invc = float(1 / c)
         m2logc = float(2 * mp.log(mp.mpf(invc)))          # -2*log(c) with c := 1/invc (rounded)
         worst_r = max(worst_r, abs(a * mp.mpf(invc) - 1), abs(b * mp.mpf(invc) - 1))
         rows.append((invc, m2logc))
-    print("log table: max |r| =", mp.nstr(worst_r, 6), "(polynomial fitted on |r| <= 0.0045)")
+    LOG_R = worst_r * mp.mpf("1.02")
+    print("log table: max |r| =", mp.nstr(worst_r, 6), "(polynomial fitted on |r| <=", mp.nstr(LOG_R, 6), ")")
     with open(path, "w") as f:
         f.write("// GENERATED by tools/gen_coeffs.py -- do not edit.\n")
-        f.write("// {1/c_i, -2 ln c_i}: 128 intervals of width 2^-8 over [0.5,1); c_i = midpoint, c_127 = 1.\n")
+        f.write(f"// {{1/c_i, -2 ln c_i}}: {n} intervals of width 2^-{LOG_BITS + 1} over [0.5,1); c_i = midpoint, c_{n - 1} = 1.\n")
         f.write("#pragma once\nnamespace mcg { namespace fm {\n")
-        f.write("static const double LOG_TAB_HOST[256] = {\n")
+        f.write(f"static const double LOG_TAB_HOST[{2 * n}] = {{\n")
         for invc, l in rows:
             f.write(f"    {invc.hex()}, {l.hex()},\n")
         f.write("};\n} }\n")
@@ -139,13 +148,13 @@ sincos_table(_tab)
 
 
 # ---- second generation of the GBM step's polynomials (one instruction less each) ------------------
-# (a) log1p(r) = r + r^2 * q(r), q of degree 5 on |r| <= 0.0045: 5 FMA + 1 MUL + 1 FMA (the r^3 p(r) form takes 8)
-Rl = mp.mpf("0.0045")
-for deg in (5,):
+# (a) log1p(r) = r + r^2 * q(r), q of degree 3 on the table's |r| <= 2^-11: 3 FMA + 1 MUL + 1 FMA
+Rl = LOG_R
+for deg in (3,):
     q = cheb_fit(lambda r: (mp.log(1 + r) - r) / (r * r) if abs(r) > mp.mpf('1e-15') else -mp.mpf(1) / 2 + r / 3, -Rl, Rl, deg)
     qr = rounded(q)
     err = max_err(lambda r: r + r * r * horner(qr, r), lambda r: mp.log(1 + r), -Rl, Rl, rel=True)
-    print(f"log1p q deg {deg} on |r|<=0.0045: max rel err {mp.nstr(err, 5)} (2^{mp.nstr(mp.log(err, 2), 5)})")
+    print(f"log1p q deg {deg} on |r|<={mp.nstr(Rl, 5)}: max rel err {mp.nstr(err, 5)} (2^{mp.nstr(mp.log(err, 2), 5)})")
     show(f"LOG_Q deg {deg}", qr)
 # (b) e^a = 1 + a + a^2 q(a) on |a| <= 0.1 with q of degree 6 (the 0.125 bound needs degree 7)
 for bound, deg in ((mp.mpf("0.1"), 6), (mp.mpf("0.125"), 7)):
