@@ -24,12 +24,15 @@ namespace fm {
 
 constexpr int LOG_TAB_ENTRIES = 1024;    // x 16 B = 16 KiB of LDS per workgroup
 constexpr int SINCOS_TAB_ENTRIES = 512;  // x 16 B = 8 KiB
+constexpr int EXP2_TAB_ENTRIES = 64;     // x 8 B = 512 B
+constexpr int TABLE_UNITS = LOG_TAB_ENTRIES + SINCOS_TAB_ENTRIES + EXP2_TAB_ENTRIES / 2;  // 16-byte units of all three
 
-// The two lookup tables as they sit in LDS (and, back to back, in the device buffer they are
-// staged from: fm::LOG_TAB_HOST followed by fm::SINCOS_TAB_HOST).
+// The lookup tables as they sit in LDS (and, back to back, in the device buffer they are staged from:
+// fm::LOG_TAB_HOST, fm::SINCOS_TAB_HOST, fm::EXP2_TAB_HOST).
 struct Tables {
     double2 log[LOG_TAB_ENTRIES];        // {1/c_i, -2 ln c_i}
     double2 sincos[SINCOS_TAB_ENTRIES];  // {cos, sin}(2 pi i / 512)
+    double exp2[EXP2_TAB_ENTRIES];       // 2^(j/64)
 };
 
 __device__ __forceinline__ double from_words(uint32_t hi, uint32_t lo) { return __hiloint2double((int)hi, (int)lo); }
@@ -126,11 +129,9 @@ __device__ __forceinline__ void horner2x9(double& qa, double& qb, double ra, dou
         : "+v"(qa), "+v"(qb)
         : "v"(ra), "v"(rb), "s"(c1), "s"(c2), "s"(c3), "s"(c4), "s"(c5), "s"(c6), "s"(c7), "s"(c8), "s"(c9));
 }
-__device__ __forceinline__ void horner2x10(double& qa, double& qb, double ra, double rb, double c1, double c2, double c3,
-                                           double c4, double c5, double c6, double c7, double c8, double c9, double c10) {
-    asm(MCG_H2(4) MCG_H2(5) MCG_H2(6) MCG_H2(7) MCG_H2(8) MCG_H2(9) MCG_H2(10) MCG_H2(11) MCG_H2(12) MCG_H2(13)
-        : "+v"(qa), "+v"(qb)
-        : "v"(ra), "v"(rb), "s"(c1), "s"(c2), "s"(c3), "s"(c4), "s"(c5), "s"(c6), "s"(c7), "s"(c8), "s"(c9), "s"(c10));
+__device__ __forceinline__ void horner2x4(double& qa, double& qb, double ra, double rb, double c1, double c2, double c3,
+                                          double c4) {
+    asm(MCG_H2(4) MCG_H2(5) MCG_H2(6) MCG_H2(7) : "+v"(qa), "+v"(qb) : "v"(ra), "v"(rb), "s"(c1), "s"(c2), "s"(c3), "s"(c4));
 }
 #undef MCG_H2
 
@@ -148,19 +149,21 @@ __device__ __forceinline__ void exp_full2(double a, double b, double& ea, double
     eb = __builtin_ldexp(1.0 + __builtin_fma(rb * rb, qb, rb), (int)kb);
 }
 
-// 2^ta, 2^tb for arguments that are ALREADY in units of ln 2 (the caller folds log2(e) into whatever produces them:
-// the rBergomi variance factor is 2^(c X + table)): k = rint(t), f = t - k exactly, 2^f = 1 + f g(f) with g of degree 10
-// on |f| <= 1/2 (max rel err 2^-55.5, tools/gen_coeffs.py), result = ldexp(., k).  16 instructions per value, against
-// the 20 of exp_full2: no multiply by log2(e), no two-step reduction by ln 2, no separate r^2.
-__device__ __forceinline__ void exp2_pair(double ta, double tb, double& ea, double& eb) {
-    const double ka = __builtin_rint(ta), kb = __builtin_rint(tb);
-    const double fa = ta - ka, fb = tb - kb;
-    double qa = 0x1.e9d419696e0e9p-32, qb = 0x1.e9d419696e0e9p-32;
-    horner2x10(qa, qb, fa, fb, 0x1.e6065f532c950p-28, 0x1.b524fad88ed30p-24, 0x1.62bfd46781ef6p-20, 0x1.ffcbfc6712438p-17,
-               0x1.4309130975155p-13, 0x1.5d87fe78a526dp-10, 0x1.3b2ab6fba1dc6p-7, 0x1.c6b08d704a0c2p-5,
-               0x1.ebfbdff82c598p-3, 0x1.62e42fefa39efp-1);
-    ea = __builtin_ldexp(__builtin_fma(qa, fa, 1.0), (int)ka);
-    eb = __builtin_ldexp(__builtin_fma(qb, fb, 1.0), (int)kb);
+// 2^(ta/64), 2^(tb/64) for arguments that are ALREADY in units of (ln 2)/64 (the caller folds 64 log2(e) into whatever
+// produces them: the rBergomi variance factor is 2^((c X + table)/64)): n = rint(t) = 64 k + j, g = t - n exactly,
+// 2^(t/64) = 2^k * 2^(j/64) * 2^(g/64), the middle factor from a 64-entry LDS table, the last as 1 + g h(g) with h of
+// degree 4 on |g| <= 1/2 (max rel err 2^-58.6, tools/gen_coeffs.py).  10 fp64 instructions per value (+3 integer, one
+// LDS read) against the 15 of a degree-10 polynomial on the whole octave and the 20 of exp_full2 -- and fp64 instructions
+// are what the generator's clock pays for.
+__device__ __forceinline__ void exp2_pair(double ta, double tb, const Tables* tab, double& ea, double& eb) {
+    const double na = __builtin_rint(ta), nb = __builtin_rint(tb);
+    const int ia = (int)na, ib = (int)nb;  // v_cvt_i32_f64 saturates: |t| beyond 2^31 ends in ldexp's clamp either way
+    const double Ta = tab->exp2[ia & 63], Tb = tab->exp2[ib & 63];
+    const double ga = ta - na, gb = tb - nb;
+    double qa = 0x1.5d881278aaf92p-40, qb = 0x1.5d881278aaf92p-40;
+    horner2x4(qa, qb, ga, gb, 0x1.3b2ad03af0e55p-31, 0x1.c6b08d70496bfp-23, 0x1.ebfbdff82ac4dp-15, 0x1.62e42fefa39efp-7);
+    ea = __builtin_ldexp(__builtin_fma(Ta * ga, qa, Ta), ia >> 6);
+    eb = __builtin_ldexp(__builtin_fma(Tb * gb, qb, Tb), ib >> 6);
 }
 
 // e^a - 1, e^b - 1 for |a|, |b| <= 0.1 (the polynomial of scaled_exp_small6) and for <= 0.34 (that of scaled_exp
@@ -377,17 +380,17 @@ __device__ __forceinline__ void normal_quad_fast(uint32_t k0, uint32_t k1, uint6
     z[3] = r1 * __builtin_fma(a1.y, cd1, a1.x * sd1);
 }
 
-// Cooperative copy of both tables (global, 24 KiB) into LDS; call before the first normal and
+// Cooperative copy of the tables (global, 24.5 KiB) into LDS; call before the first normal and
 // follow with __syncthreads().
 __device__ __forceinline__ void load_tables(Tables* lds, const double2* __restrict__ gtab) {
     double2* dst = reinterpret_cast<double2*>(lds);
-    for (int i = threadIdx.x; i < LOG_TAB_ENTRIES + SINCOS_TAB_ENTRIES; i += blockDim.x) dst[i] = gtab[i];
+    for (int i = threadIdx.x; i < TABLE_UNITS; i += blockDim.x) dst[i] = gtab[i];
 }
 
 // The same copy with the logarithm table's second column multiplied by `scale` (neg2log_scaled).
 __device__ __forceinline__ void load_tables_scaled(Tables* lds, const double2* __restrict__ gtab, double scale) {
     double2* dst = reinterpret_cast<double2*>(lds);
-    for (int i = threadIdx.x; i < LOG_TAB_ENTRIES + SINCOS_TAB_ENTRIES; i += blockDim.x) {
+    for (int i = threadIdx.x; i < TABLE_UNITS; i += blockDim.x) {
         double2 e = gtab[i];
         if (i < LOG_TAB_ENTRIES) e.y *= scale;
         dst[i] = e;

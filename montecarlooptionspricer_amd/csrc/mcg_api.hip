@@ -252,10 +252,12 @@ static int init_impl(mcg_ctx** out, int device, bool adopt, void* external_strea
         mcg_finalize(ctx);
         return fail(MCG_ERR_OOM, "workspace allocation failed");
     }
-    if (hipMalloc((void**)&ctx->log_tab, sizeof(fm::LOG_TAB_HOST) + sizeof(fm::SINCOS_TAB_HOST)) != hipSuccess ||
+    // (the three generated tables back to back = fm::Tables, fastmath.hpp)
+    constexpr size_t n_log = sizeof(fm::LOG_TAB_HOST) / sizeof(double), n_sc = sizeof(fm::SINCOS_TAB_HOST) / sizeof(double);
+    if (hipMalloc((void**)&ctx->log_tab, sizeof(fm::LOG_TAB_HOST) + sizeof(fm::SINCOS_TAB_HOST) + sizeof(fm::EXP2_TAB_HOST)) != hipSuccess ||
         hipMemcpy(ctx->log_tab, fm::LOG_TAB_HOST, sizeof(fm::LOG_TAB_HOST), hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(ctx->log_tab + sizeof(fm::LOG_TAB_HOST) / sizeof(double), fm::SINCOS_TAB_HOST, sizeof(fm::SINCOS_TAB_HOST), hipMemcpyHostToDevice) !=
-            hipSuccess) {
+        hipMemcpy(ctx->log_tab + n_log, fm::SINCOS_TAB_HOST, sizeof(fm::SINCOS_TAB_HOST), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(ctx->log_tab + n_log + n_sc, fm::EXP2_TAB_HOST, sizeof(fm::EXP2_TAB_HOST), hipMemcpyHostToDevice) != hipSuccess) {
         mcg_finalize(ctx);
         return fail(MCG_ERR_OOM, "table upload failed");
     }

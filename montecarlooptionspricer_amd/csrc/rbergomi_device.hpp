@@ -90,9 +90,9 @@ struct RbLds {
     double2* stage;
 };
 
-// comp_scale: the FFT variants keep the compensator as (log2(e)/2) comp -- their variance factor is
-// e^{(X + comp)/2} = 2^{(log2(e)/2) X + table} (fm::exp2_pair) --, the direct variant as it is.
-constexpr double RB_HALF_LOG2E = 0x1.71547652b82fep-1;  // log2(e) / 2
+// comp_scale: the FFT variants keep the compensator as 32 log2(e) comp -- their variance factor is
+// e^{(X + comp)/2} = 2^{(32 log2(e) X + table)/64} (fm::exp2_pair) --, the direct variant as it is.
+constexpr double RB_HALF_LOG2E = 0x1.71547652b82fep+5;  // 64 log2(e) / 2: fm::exp2_pair takes its argument in units of (ln 2)/64
 __device__ __forceinline__ RbLds rb_stage_lds(const RbArgs& a, double* smem, fm::Tables* tabs, double comp_scale) {
     const int M = a.M;
     double* amp = smem;
@@ -382,8 +382,8 @@ __device__ __forceinline__ void rb_fft_block(const RbArgs& a, const RbLds& L, in
             double* const ib = xi + t * 4;
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
-                const double cmp = L.comp[nl + v];  // (log2(e)/2) comp_n
-                fm::exp2_pair(fma(ia[v], RB_HALF_LOG2E, cmp), fma(ib[v], RB_HALF_LOG2E, cmp), ia[v], ib[v]);
+                const double cmp = L.comp[nl + v];  // 32 log2(e) comp_n
+                fm::exp2_pair(fma(ia[v], RB_HALF_LOG2E, cmp), fma(ib[v], RB_HALF_LOG2E, cmp), tabs, ia[v], ib[v]);
                 __builtin_amdgcn_sched_barrier(0);  // one step's pair of chains at a time: more of them cost registers, not time
             }
             {

@@ -140,11 +140,22 @@ def sincos_table(path):
     print("  2pi*2^-24 =", float(2 * mp.pi / 2 ** 24).hex(), " pi*2^-24 =", float(mp.pi / 2 ** 24).hex())
 
 
+def exp2_table(path):
+    """2^(j/64), j = 0..63 (correctly rounded) for fastmath.hpp::exp2_pair."""
+    with open(path, "a") as f:
+        f.write("\n// 2^(j/64), j = 0..63 (correctly rounded)\n")
+        f.write("namespace mcg { namespace fm {\nstatic const double EXP2_TAB_HOST[64] = {\n")
+        for j in range(64):
+            f.write(f"    {float(mp.mpf(2) ** (mp.mpf(j) / 64)).hex()},\n")
+        f.write("};\n} }\n")
+
+
 import os
 _tab = os.environ.get("MCG_TABLES_OUT") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "montecarlooptionspricer_amd",
                                                         "csrc", "fastmath_tables.hpp")
 log_table(_tab)
 sincos_table(_tab)
+exp2_table(_tab)
 
 
 # ---- second generation of the GBM step's polynomials (one instruction less each) ------------------
@@ -163,3 +174,12 @@ for bound, deg in ((mp.mpf("0.1"), 6), (mp.mpf("0.125"), 7)):
     err = max_err(lambda r: 1 + r + r * r * horner(qr, r), lambda r: mp.e ** r, -bound, bound)
     print(f"exp-small q deg {deg} on |a|<={bound}: max rel err {mp.nstr(err, 5)} (2^{mp.nstr(mp.log(err, 2), 5)})")
     show(f"EXP_SMALL_Q deg {deg}", qr)
+
+# (c) 2^(g/64) = 1 + g h(g) on |g| <= 1/2 (exp2_pair: t = n/64 + g/64 with n = rint(64 t); the table supplies 2^(j/64))
+Lg = mp.mpf("0.5") * mp.mpf("1.0002")
+for deg in (4,):
+    h = cheb_fit(lambda g: (mp.mpf(2) ** (g / 64) - 1) / g if abs(g) > mp.mpf('1e-20') else mp.log(2) / 64, -Lg, Lg, deg)
+    hr = rounded(h)
+    err = max_err(lambda g: 1 + g * horner(hr, g), lambda g: mp.mpf(2) ** (g / 64), -Lg, Lg)
+    print(f"exp2/64 h deg {deg}: max rel err {mp.nstr(err, 5)} (2^{mp.nstr(mp.log(err, 2), 5)})")
+    show(f"EXP2_H deg {deg}", hr)
