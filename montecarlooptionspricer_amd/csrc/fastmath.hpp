@@ -234,27 +234,31 @@ __device__ __forceinline__ LogSplit log_split(double u) {
     return s;
 }
 
-// (split, table entry) -> -2 ln u
+// -2 log1p(r) = r P(r), P(r) = -2 - 2 r q(r) = fma(r, Q(r), -2) with Q = -2 q: one instruction less than
+// -2 (r + r^2 q(r)) -- no r^2 -- and exact doubling of q's coefficients (tools/gen_coeffs.py: LOG_Q2).
+constexpr double LOG_Q2_3 = -0x1.99999e5b2a5bcp-2, LOG_Q2_2 = 0x1.000002c63f1bap-1, LOG_Q2_1 = -0x1.5555555555542p-1,
+                 LOG_Q2_0 = 0x1.fffffffffffe9p-1;
+
+// (split, table entry) -> -2 ln u = -2 k ln2 + (-2 ln c) + r P(r)
 __device__ __forceinline__ double neg2log_entry(const LogSplit& sp, const double2 e) {
     const double r = __builtin_fma(sp.z, e.x, -1.0);
-    double q = 0x1.99999e5b2a5bcp-3;
-    q = fma_sc(q, r, -0x1.000002c63f1bap-2);
-    q = fma_sc(q, r, 0x1.5555555555542p-2);
-    q = fma_sc(q, r, -0x1.fffffffffffe9p-2);
-    const double l1p = __builtin_fma(r * r, q, r);  // log1p(r)
-    // -2 ln u = -2 k ln2 + (-2 ln c) - 2 log1p(r)
+    double q = LOG_Q2_3;
+    q = fma_sc(q, r, LOG_Q2_2);
+    q = fma_sc(q, r, LOG_Q2_1);
+    q = fma_sc(q, r, LOG_Q2_0);
+    const double P = __builtin_fma(r, q, -2.0);
     const double base = __builtin_fma((double)sp.k, -0x1.62e42fefa39efp+0, e.y);
-    return __builtin_fma(-2.0, l1p, base);
+    return __builtin_fma(r, P, base);
 }
 // two of them, the polynomial chains interleaved (bit-identical to neg2log_entry twice)
 __device__ __forceinline__ void neg2log_entry2(const LogSplit& s0, const double2 e0, const LogSplit& s1, const double2 e1,
                                                double& out0, double& out1) {
     const double r0 = __builtin_fma(s0.z, e0.x, -1.0), r1 = __builtin_fma(s1.z, e1.x, -1.0);
-    double q0 = 0x1.99999e5b2a5bcp-3, q1 = 0x1.99999e5b2a5bcp-3;
-    horner2x3(q0, q1, r0, r1, -0x1.000002c63f1bap-2, 0x1.5555555555542p-2, -0x1.fffffffffffe9p-2);
-    const double l0 = __builtin_fma(r0 * r0, q0, r0), l1 = __builtin_fma(r1 * r1, q1, r1);
-    out0 = __builtin_fma(-2.0, l0, __builtin_fma((double)s0.k, -0x1.62e42fefa39efp+0, e0.y));
-    out1 = __builtin_fma(-2.0, l1, __builtin_fma((double)s1.k, -0x1.62e42fefa39efp+0, e1.y));
+    double q0 = LOG_Q2_3, q1 = LOG_Q2_3;
+    horner2x3(q0, q1, r0, r1, LOG_Q2_2, LOG_Q2_1, LOG_Q2_0);
+    const double P0 = __builtin_fma(r0, q0, -2.0), P1 = __builtin_fma(r1, q1, -2.0);
+    out0 = __builtin_fma(r0, P0, __builtin_fma((double)s0.k, -0x1.62e42fefa39efp+0, e0.y));
+    out1 = __builtin_fma(r1, P1, __builtin_fma((double)s1.k, -0x1.62e42fefa39efp+0, e1.y));
 }
 __device__ __forceinline__ double neg2log(double u, const double2* tab) {
     const LogSplit sp = log_split(u);
@@ -262,19 +266,26 @@ __device__ __forceinline__ double neg2log(double u, const double2* tab) {
 }
 
 // vol^2 * (-2 ln u): the same evaluation with the scale folded into its constants -- the table's second column is
-// pre-multiplied when it is staged (load_tables_scaled), c_k = -2 ln2 * vol^2, c_l = -2 vol^2 -- so that the
-// square root yields vol * sqrt(-2 ln u) directly and the GBM step saves a multiply.
-__device__ __forceinline__ double neg2log_scaled(double u, const double2* tab, double c_k, double c_l) {
+// pre-multiplied when it is staged (load_tables_scaled), and the host hands over c_k = -2 ln2 vol^2, c_l = -2 vol^2 and
+// the polynomial's coefficients times vol^2 -- so that the square root yields vol * sqrt(-2 ln u) directly and the GBM
+// step saves a multiply:  vol^2 (-2 log1p(r)) = r (c_l + r (vol^2 Q(r))).
+struct LogScale {
+    double c_k, c_l, q3, q2, q1, q0;
+};
+__host__ __device__ inline LogScale make_log_scale(double vol2) {
+    return LogScale{-0x1.62e42fefa39efp+0 * vol2, -2.0 * vol2, LOG_Q2_3 * vol2, LOG_Q2_2 * vol2, LOG_Q2_1 * vol2, LOG_Q2_0 * vol2};
+}
+__device__ __forceinline__ double neg2log_scaled(double u, const double2* tab, const LogScale& L) {
     const LogSplit sp = log_split(u);
     const double2 e = tab[sp.idx];
     const double r = __builtin_fma(sp.z, e.x, -1.0);
-    double q = 0x1.99999e5b2a5bcp-3;
-    q = fma_sc(q, r, -0x1.000002c63f1bap-2);
-    q = fma_sc(q, r, 0x1.5555555555542p-2);
-    q = fma_sc(q, r, -0x1.fffffffffffe9p-2);
-    const double l1p = __builtin_fma(r * r, q, r);
-    const double base = __builtin_fma((double)sp.k, c_k, e.y);
-    return __builtin_fma(c_l, l1p, base);
+    double q = L.q3;
+    q = fma_sc(q, r, L.q2);
+    q = fma_sc(q, r, L.q1);
+    q = fma_sc(q, r, L.q0);
+    const double P = __builtin_fma(r, q, L.c_l);
+    const double base = __builtin_fma((double)sp.k, L.c_k, e.y);
+    return __builtin_fma(r, P, base);
 }
 
 // sqrt for positive normal x in five instructions (measured <= 0.75 ulp): with y = rsq(x) accurate to
@@ -340,9 +351,9 @@ __device__ __forceinline__ void box_muller_pair_affine(uint32_t wa, uint32_t wb,
 }
 
 // The affine pair with vol folded into the logarithm (tables staged by load_tables_scaled(vol^2)); vol > 0.
-__device__ __forceinline__ void box_muller_pair_affine_scaled(uint32_t wa, uint32_t wb, const Tables* tab, double c_k,
-                                                              double c_l, double shift, double& a0, double& a1) {
-    const double rad = sqrt_pos(neg2log_scaled(radius_u01(wa, wb), tab->log, c_k, c_l));  // = vol * sqrt(-2 ln u)
+__device__ __forceinline__ void box_muller_pair_affine_scaled(uint32_t wa, uint32_t wb, const Tables* tab, const LogScale& L,
+                                                              double shift, double& a0, double& a1) {
+    const double rad = sqrt_pos(neg2log_scaled(radius_u01(wa, wb), tab->log, L));  // = vol * sqrt(-2 ln u)
     double c, s;
     sincos_table(wb, tab->sincos, c, s);
     a0 = __builtin_fma(rad, c, shift);

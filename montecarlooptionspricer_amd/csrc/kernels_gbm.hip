@@ -23,7 +23,7 @@ struct GbmArgs {
     uint64_t path_begin;
     uint32_t k0, k1;   // Philox key = seed
     double S0, drift, vol;
-    double c_k, c_l;   // MODE 2: -2 ln2 vol^2, -2 vol^2
+    fm::LogScale ls;   // MODE >= 2: the logarithm's constants times vol^2 (fm::neg2log_scaled)
     double K;
     int is_call;
     double* partials;  // [gridDim.x][2]
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void k_gbm_paths(GbmArgs a) {
             store_row(row);
         };
         auto pair_exponents = [&](uint32_t wa, uint32_t wb, double& e0, double& e1) {  // drift + vol*z of two steps
-            if (MODE >= 2) fm::box_muller_pair_affine_scaled(wa, wb, tab, a.c_k, a.c_l, a.drift, e0, e1);
+            if (MODE >= 2) fm::box_muller_pair_affine_scaled(wa, wb, tab, a.ls, a.drift, e0, e1);
             else fm::box_muller_pair_affine(wa, wb, tab, a.vol, a.drift, e0, e1);
         };
         const int n_blocks = a.n_steps >> 2;
@@ -271,8 +271,7 @@ int launch_gbm(mcg_ctx* ctx, mcg_paths* P, uint64_t seed, double S0, double r, d
         const double reach = std::fabs(a.drift) + std::fabs(a.vol) * fm::MAX_ABS_NORMAL;
         // vol^2 (-2 ln u) must stay a normal positive double for modes 2 and 3
         const int mode = !small ? 0 : !(a.vol > 1e-100) ? 1 : reach <= fm::SMALL6_EXP_BOUND ? 3 : 2;
-        a.c_k = -0x1.62e42fefa39efp+0 * (a.vol * a.vol);
-        a.c_l = -2.0 * (a.vol * a.vol);
+        a.ls = fm::make_log_scale(a.vol * a.vol);
         if (want_payoff) {
             if (ppl == 2) launch_gbm_mode<true, 2>(ctx, a, mode, (unsigned)n_blocks);
             else launch_gbm_mode<true, 1>(ctx, a, mode, (unsigned)n_blocks);

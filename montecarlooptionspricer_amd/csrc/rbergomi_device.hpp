@@ -388,17 +388,18 @@ __device__ __forceinline__ void rb_fft_block(const RbArgs& a, const RbLds& L, in
             }
             {
                 double z[4];
-                fm::normal_quad_fast<RB_EAGER_PRICE>(a.k0, a.k1, id_a, (uint32_t)(nl >> 2), STREAM_PRICE, tabs, z);
+                // (sqrt(xi dt) folded into the pairs' radii: z = sqrt(xi dt) N(0,1))
+                fm::normal_quad_fast<RB_EAGER_PRICE>(a.k0, a.k1, id_a, (uint32_t)(nl >> 2), STREAM_PRICE, tabs, z, sq_xi_dt, sq_xi_dt);
 #pragma unroll
-                for (int v = 0; v < 4; ++v)  // (r - v/2) dt + sqrt(v dt) z,  v = xi e^2
-                    ia[v] = fma(sq_xi_dt * ia[v], z[v], fma(neg_half_xi_dt, ia[v] * ia[v], r_dt));
+                for (int v = 0; v < 4; ++v)  // (r - v/2) dt + sqrt(v dt) N,  v = xi e^2
+                    ia[v] = fma(ia[v], z[v], fma(neg_half_xi_dt, ia[v] * ia[v], r_dt));
             }
             __builtin_amdgcn_sched_barrier(0);
             {
                 double z[4];
-                fm::normal_quad_fast<RB_EAGER_PRICE>(a.k0, a.k1, id_b, (uint32_t)(nl >> 2), STREAM_PRICE, tabs, z);
+                fm::normal_quad_fast<RB_EAGER_PRICE>(a.k0, a.k1, id_b, (uint32_t)(nl >> 2), STREAM_PRICE, tabs, z, sq_xi_dt, sq_xi_dt);
 #pragma unroll
-                for (int v = 0; v < 4; ++v) ib[v] = fma(sq_xi_dt * ib[v], z[v], fma(neg_half_xi_dt, ib[v] * ib[v], r_dt));
+                for (int v = 0; v < 4; ++v) ib[v] = fma(ib[v], z[v], fma(neg_half_xi_dt, ib[v] * ib[v], r_dt));
             }
             double big = 0.0;
 #pragma unroll

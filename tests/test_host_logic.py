@@ -93,7 +93,7 @@ def test_device_math_tables_and_coefficients_come_from_the_generator(tmp_path):
     assert out.read_text() == committed
     header = open(os.path.join(root, "montecarlooptionspricer_amd", "csrc", "fastmath.hpp")).read()
     lines = res.stdout.splitlines()
-    for tag in ("LOG_Q deg 3", "EXP_SMALL_Q deg 6", "EXP_SMALL_Q deg 7", "EXP_Q deg 9"):
+    for tag in ("LOG_Q2 deg 3 (-2 q: the header's LOG_Q2_0..3)", "EXP_SMALL_Q deg 6", "EXP_SMALL_Q deg 7", "EXP_Q deg 9"):
         idx = next(i for i, l in enumerate(lines) if l.strip() == "// " + tag)
         coefs = re.findall(r"-?0x[0-9a-f.]+p[+-]\d+", lines[idx + 1])
         assert coefs, tag

@@ -167,6 +167,7 @@ for deg in (3,):
     err = max_err(lambda r: r + r * r * horner(qr, r), lambda r: mp.log(1 + r), -Rl, Rl, rel=True)
     print(f"log1p q deg {deg} on |r|<={mp.nstr(Rl, 5)}: max rel err {mp.nstr(err, 5)} (2^{mp.nstr(mp.log(err, 2), 5)})")
     show(f"LOG_Q deg {deg}", qr)
+    show(f"LOG_Q2 deg {deg} (-2 q: the header's LOG_Q2_0..3)", [-2 * v for v in qr])
 # (b) e^a = 1 + a + a^2 q(a) on |a| <= 0.1 with q of degree 6 (the 0.125 bound needs degree 7)
 for bound, deg in ((mp.mpf("0.1"), 6), (mp.mpf("0.125"), 7)):
     q = cheb_fit(lambda r: (mp.e ** r - 1 - r) / (r * r) if abs(r) > mp.mpf('1e-15') else mp.mpf(1) / 2 + r / 6, -bound, bound, deg)
