@@ -266,18 +266,19 @@ __global__ __launch_bounds__(256) void k_lsm_final(const double* V, int64_t n, d
 // uses no fence, no read-modify-write and no flag: every exchanged double is written and read with agent-scope (sc1)
 // stores and loads, which go through to the device coherence point one by one, and every slot announces itself --
 // it holds a reserved NaN pattern until its value arrives:
-//   every workgroup : partial moments -> partials[parity][t][b]
+//   every workgroup : partial moments -> partials[set][t][b]   (set = 0, 1 alternating; 2 for a refinement round)
 //   workgroup 0     : each lane polls its own slots (all loads of a round in flight together) until none is the
-//                     sentinel; fixed-order reduction; solve; coefficients -> coef[parity][0..9]
+//                     sentinel; fixed-order reduction; solve; coefficients -> coef[set][0..12]
 //   every workgroup : lanes 0..9 poll one coefficient each
 // Two one-way trips per date.  Slots are recycled two dates later: workgroup 0 puts the sentinel back into the
-// partials right after reading them and into coef[parity] once the NEXT date's partials have all arrived (every
+// partials right after reading them and into the earlier coefficient blocks once the NEXT date's partials have all arrived (every
 // workgroup has then used those coefficients); it waits for the acknowledgement of these stores (s_waitcnt) before
 // it publishes anything newer.  The path matrix is read-only and V never leaves the registers, so nothing else
 // needs coherence.  The grid is sized by the occupancy query (minus a margin) so that all workgroups are co-resident,
 // one such kernel runs at a time per process, and every spin is bounded and raises a flag instead of hanging.
 // Sharded runs keep the per-date kernels: their all-reduce is issued from the host between two launches.
 constexpr unsigned LSM_SENTINEL32 = 0xFFF85EA7u;  // both halves of the reserved NaN (hipMemsetD32 fills the buffers)
+constexpr int LSM_AREA_REFINE = 2;                // slot set of refinement rounds (regular rounds alternate between sets 0 and 1)
 constexpr int LSM_COOP_MAX_GRID = 512;            // 8 slots per lane and moment in workgroup 0, two moments in flight
 
 struct LsmCoopArgs {
@@ -286,8 +287,8 @@ struct LsmCoopArgs {
     int n_cols;
     double K, invK, maturity, dt, disc;
     int is_call;
-    double* partials;  // [2][NM][gridDim.x], sentinel-filled
-    double* coef;      // [2][16], sentinel-filled: coefficients, [9] = ITM count
+    double* partials;  // [3][NM][gridDim.x], sentinel-filled: slot sets 0 / 1 of the regular rounds, 2 of refinement rounds
+    double* coef;      // [3][16], sentinel-filled: coefficients, [9] = ITM count
     unsigned* timeout; // set when a spin gives up
     unsigned spin_limit; // polling rounds before a spin gives up (LSM_SPIN_LIMIT; MCG_LSM_SPIN_LIMIT in tests)
     int u_full;          // k_lsm_big: units 0 .. u_full-1 lie inside the shard for EVERY thread (no masking needed)
@@ -329,11 +330,11 @@ constexpr unsigned LSM_SPIN_LIMIT = 1u << 20;  // rounds of ~1.5 us; a co-reside
 
 // every contributing workgroup: block-reduce the per-thread moments and send them off
 template <int NB>
-__device__ __forceinline__ void lsm_publish_partials(const LsmCoopArgs& a, double (&m)[3 * NB - 1], unsigned G, unsigned b, int parity,
+__device__ __forceinline__ void lsm_publish_partials(const LsmCoopArgs& a, double (&m)[3 * NB - 1], unsigned G, unsigned b, int area,
                                                      double* red) {
     constexpr int NM = 3 * NB - 1;
     block_sum<NM, 4>(m, red);
-    double* part = a.partials + (int64_t)parity * NM * G;
+    double* part = a.partials + (int64_t)area * NM * G;
     if (threadIdx.x == 0) {
 #pragma unroll
         for (int t = 0; t < NM; ++t) lsm_st_shared(part + (int64_t)t * G + b, m[t]);
@@ -391,12 +392,12 @@ __device__ __forceinline__ void lsm_node_allreduce(const LsmCoopArgs& a, int rou
 // round of the same date); ws = LDS workspace of lsm_solve_centered; round = exchange counter of this sweep (the slot
 // of the node mailbox when the sweep is sharded over the GPUs of a node).
 template <int NB>
-__device__ __forceinline__ void lsm_reduce_solve_publish(const LsmCoopArgs& a, unsigned G, int parity, bool& gave_up, double* sm_mom,
+__device__ __forceinline__ void lsm_reduce_solve_publish(const LsmCoopArgs& a, unsigned G, int area, bool& gave_up, double* sm_mom,
                                                          double* sm_coef, bool centered, double mu, double* ws, int round) {
     constexpr int NM = 3 * NB - 1;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    double* part = a.partials + (int64_t)parity * NM * G;
-    double* coef_now = a.coef + 16 * parity;
+    double* part = a.partials + (int64_t)area * NM * G;
+    double* coef_now = a.coef + 16 * area;
     for (int t0 = wave; t0 < NM; t0 += 8) {
         const int t1 = t0 + 4;
         const bool two = t1 < NM;
@@ -444,8 +445,13 @@ __device__ __forceinline__ void lsm_reduce_solve_publish(const LsmCoopArgs& a, u
         }
     }
     LSM_TRACE(round, 3);  // workgroup 0: this wave's moments are in
-    // all partials of this date are in: every workgroup is past the previous date's coefficients
-    if (threadIdx.x < LSM_COEF_DOUBLES) lsm_st_shared(a.coef + 16 * (parity ^ 1) + threadIdx.x, lsm_sentinel());
+    // All partials of a regular round are in: every workgroup is past every earlier coefficient block -- the previous
+    // regular round's and, if that date was re-fitted, the refinement round's.  (A refinement round recycles nothing:
+    // the blocks it could recycle are the ones the next regular round takes care of.)
+    if (area != LSM_AREA_REFINE && threadIdx.x < 2 * LSM_COEF_DOUBLES) {
+        const int blk = threadIdx.x < LSM_COEF_DOUBLES ? (area ^ 1) : LSM_AREA_REFINE;
+        lsm_st_shared(a.coef + 16 * blk + threadIdx.x % LSM_COEF_DOUBLES, lsm_sentinel());
+    }
     if (a.mbox) lsm_node_allreduce<NM>(a, round, gave_up, sm_mom);  // (uniform) local -> node-wide moments
     __syncthreads();
     LSM_TRACE(round, 4);  // everybody's
@@ -460,8 +466,8 @@ __device__ __forceinline__ void lsm_reduce_solve_publish(const LsmCoopArgs& a, u
 }
 
 // every other workgroup: the first LSM_COEF_DOUBLES lanes poll one entry of the coefficient block each into sm_coef
-__device__ __forceinline__ void lsm_poll_coefficients(const LsmCoopArgs& a, int parity, bool& gave_up, double* sm_coef) {
-    double* coef_now = a.coef + 16 * parity;
+__device__ __forceinline__ void lsm_poll_coefficients(const LsmCoopArgs& a, int area, bool& gave_up, double* sm_coef) {
+    double* coef_now = a.coef + 16 * area;
     if (threadIdx.x < LSM_COEF_DOUBLES) {
         double cv = lsm_ld_shared(coef_now + threadIdx.x);
         unsigned spins = 0;
@@ -482,15 +488,15 @@ __device__ __forceinline__ void lsm_poll_coefficients(const LsmCoopArgs& a, int 
 // k_lsm_coop: workgroup 0 contributes AND reduces.  after_publish() runs right after this workgroup's partial moments
 // have left: the place to put loads in flight that should overlap the ~10 us the moments and coefficients travel.
 template <int NB, class F>
-__device__ __forceinline__ void lsm_exchange(const LsmCoopArgs& a, double (&m)[3 * NB - 1], int parity, bool& gave_up,
+__device__ __forceinline__ void lsm_exchange(const LsmCoopArgs& a, double (&m)[3 * NB - 1], int area, bool& gave_up,
                                              double* red, double* sm_mom, double* sm_coef, bool centered, double mu, double* ws,
                                              int round, F&& after_publish) {
     LSM_TRACE(round, 1);  // moments accumulated
-    lsm_publish_partials<NB>(a, m, gridDim.x, blockIdx.x, parity, red);
+    lsm_publish_partials<NB>(a, m, gridDim.x, blockIdx.x, area, red);
     after_publish();
     LSM_TRACE(round, 2);  // published, next row requested
-    if (blockIdx.x == 0) lsm_reduce_solve_publish<NB>(a, gridDim.x, parity, gave_up, sm_mom, sm_coef, centered, mu, ws, round);
-    else lsm_poll_coefficients(a, parity, gave_up, sm_coef);
+    if (blockIdx.x == 0) lsm_reduce_solve_publish<NB>(a, gridDim.x, area, gave_up, sm_mom, sm_coef, centered, mu, ws, round);
+    else lsm_poll_coefficients(a, area, gave_up, sm_coef);
 }
 
 // Branch-free per-path bodies of k_lsm_big (no exec-masked regions: the unrolled unit loop must stay one basic block so
@@ -558,7 +564,7 @@ __global__ __launch_bounds__(256, (PPT >= 8 ? 2 : 3)) void k_lsm_coop(LsmCoopArg
     int64_t stride = (int64_t)G * 256;
     // columns first + q * stride exist for q < n_live (one per-lane integer instead of PPT lane masks)
     const int n_live = (int64_t)first < a.n ? (int)std::min<int64_t>(PPT, (a.n - 1 - first) / stride + 1) : 0;
-    int parity = 0, round = 0;         // round: exchanges so far (every workgroup counts alike; only workgroup 0 uses it)
+    int area = 0, round = 0;           // area: slot set of the regular round (0 / 1); round: exchanges so far (workgroup 0 uses it)
     bool gave_up = a.spin_limit == 0;  // this thread has hit the spin limit once (limit 0, tests: from the start)
     if (gave_up && blockIdx.x == 0 && threadIdx.x == 0)
         __hip_atomic_store(a.timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -613,7 +619,7 @@ __global__ __launch_bounds__(256, (PPT >= 8 ? 2 : 3)) void k_lsm_coop(LsmCoopArg
                 }
             }
         }
-        lsm_exchange<NB>(a, m, parity, gave_up, red, sm_mom, sm_coef, false, 0.0, sm_ws, round++, [&]() {
+        lsm_exchange<NB>(a, m, area, gave_up, red, sm_mom, sm_coef, false, 0.0, sm_ws, round++, [&]() {
             if constexpr (PREFETCH) {
                 if (j >= 1) load_row(j - 1, s_nxt);
             }
@@ -628,8 +634,7 @@ __global__ __launch_bounds__(256, (PPT >= 8 ? 2 : 3)) void k_lsm_coop(LsmCoopArg
 #pragma unroll
             for (int q = 0; q < PPT; ++q)
                 lsm_accumulate_centered<NB>(m, q < n_live && payoff_of(call, s_j[q], a.K) > 1e-14, s_j[q], V[q], a.invK, mu, a.disc);
-            parity ^= 1;
-            lsm_exchange<NB>(a, m, parity, gave_up, red, sm_mom, sm_coef, true, mu, sm_ws, round++, []() {});
+            lsm_exchange<NB>(a, m, LSM_AREA_REFINE, gave_up, red, sm_mom, sm_coef, true, mu, sm_ws, round++, []() {});
         }
         double c[NB];
 #pragma unroll
@@ -660,7 +665,7 @@ __global__ __launch_bounds__(256, (PPT >= 8 ? 2 : 3)) void k_lsm_coop(LsmCoopArg
             }
         }
         LSM_TRACE(round - 1, 7);  // next row in registers
-        parity ^= 1;
+        area ^= 1;
     }
     double f[2] = {0.0, 0.0};
 #pragma unroll
@@ -722,19 +727,18 @@ __device__ __forceinline__ void lsm_reduce_loop(const LsmCoopArgs& a, unsigned G
     int j = a.n_cols - 2;
     for (; j >= 0 && j * a.dt > a.maturity; --j) {
     }
-    int parity = 0, round = 0;
+    int area = 0, round = 0;
     for (; j >= 0; --j) {
-        lsm_reduce_solve_publish<NB>(a, G, parity, gave_up, sm_mom, sm_coef, false, 0.0, ws, round++);
+        lsm_reduce_solve_publish<NB>(a, G, area, gave_up, sm_mom, sm_coef, false, 0.0, ws, round++);
         __syncthreads();
         const bool refine = __builtin_amdgcn_readfirstlane(sm_coef[LSM_C_REFINE] != 0.0 ? 1 : 0) != 0;
         const double mu = sm_coef[LSM_C_HINT];
         __syncthreads();  // sm_mom / sm_coef are rewritten on the next round
-        parity ^= 1;
         if (refine) {  // the workers answer a refinement request with one more round for the same date
-            lsm_reduce_solve_publish<NB>(a, G, parity, gave_up, sm_mom, sm_coef, true, mu, ws, round++);
+            lsm_reduce_solve_publish<NB>(a, G, LSM_AREA_REFINE, gave_up, sm_mom, sm_coef, true, mu, ws, round++);
             __syncthreads();
-            parity ^= 1;
         }
+        area ^= 1;
     }
 }
 
@@ -797,7 +801,7 @@ __global__ __launch_bounds__(256, 2) void k_lsm_big(LsmCoopArgs a) {
                                          (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     };
     const unsigned ring_lane = (unsigned)(size_t)(__attribute__((address_space(3))) void*)ring + (unsigned)tid * 16u;
-    int parity = 0;
+    int area = 0;  // slot set of the regular round
     bool gave_up = a.spin_limit == 0;
 
     double V[2 * NU];
@@ -835,13 +839,13 @@ __global__ __launch_bounds__(256, 2) void k_lsm_big(LsmCoopArgs a) {
         // At j = 0 there is no earlier date: the pass still runs its moment half, on row 0 again, and nobody reads
         // the result -- cheaper than a second copy of the loop or a branch per unit.
         const char* row_n = row_of(j >= 1 ? j - 1 : 0);
-        lsm_publish_partials<NB>(a, m, G, wg, parity, red);
+        lsm_publish_partials<NB>(a, m, G, wg, area, red);
 #pragma unroll
         for (int u = 0; u < LA; ++u) {  // the first units of this date travel while the moments and coefficients do
             fetch(row_j, u, (2 * u) % LSM_RING_SLOTS);
             fetch(row_n, u, (2 * u + 1) % LSM_RING_SLOTS);
         }
-        lsm_poll_coefficients(a, parity, gave_up, sm_coef);
+        lsm_poll_coefficients(a, area, gave_up, sm_coef);
         if (__builtin_amdgcn_readfirstlane(sm_coef[LSM_C_REFINE] != 0.0 ? 1 : 0)) {  // (the same LDS word in every lane)
             // Grid-uniform and rare (lsm_solve_nb): date j is re-fitted about the mean of its regressor.  Row j is read
             // once more, by plain loads (V still holds the values its first moments were formed with), and the centred
@@ -857,9 +861,8 @@ __global__ __launch_bounds__(256, 2) void k_lsm_big(LsmCoopArgs a) {
                 lsm_accumulate_centered<NB>(m, lsm_pay(pf, sv.y) > 1e-14, sv.y, V[2 * u + 1], a.invK, mu, a.disc);
                 if ((u % 4) == 3) asm volatile("" ::: "memory");
             }
-            parity ^= 1;
-            lsm_publish_partials<NB>(a, m, G, wg, parity, red);
-            lsm_poll_coefficients(a, parity, gave_up, sm_coef);
+            lsm_publish_partials<NB>(a, m, G, wg, LSM_AREA_REFINE, red);
+            lsm_poll_coefficients(a, LSM_AREA_REFINE, gave_up, sm_coef);
         }
         double c[NB];
 #pragma unroll
@@ -906,7 +909,7 @@ __global__ __launch_bounds__(256, 2) void k_lsm_big(LsmCoopArgs a) {
             for (int t = 0; t < NM; ++t) asm volatile("" : "+v"(m[t]));
             __builtin_amdgcn_sched_barrier(0);
         });
-        parity ^= 1;
+        area ^= 1;
     }
     double f[2] = {0.0, 0.0};
 #pragma unroll
@@ -1022,11 +1025,11 @@ static int run_lsm_coop(mcg_ctx* ctx, const mcg_paths* P, double r, double K, do
         if (all != shm_n_ranks(ctx)) return MCG_OK;
     }
     if (!use) return MCG_OK;
-    // buffer: {sum, sum^2} per contributing workgroup | [2][nm][workers] moment slots | [2][16] coefficient slots
+    // buffer: {sum, sum^2} per contributing workgroup | [3][nm][workers] moment slots | [3][16] coefficient slots
     // (Until the per-date solve left scratch memory, workgroups of small grids gathered ALL partial moments themselves and
     // solved redundantly -- one trip per date instead of two.  With a 1-us solve the single reducer is as fast at 244
     // workgroups and twice as fast at 488, where the gathering workgroups' polls crowd out the stores they wait for.)
-    const size_t n_slots = 2 * (size_t)nm * workers + 32;
+    const size_t n_slots = 3 * (size_t)nm * workers + 48;  // three slot sets (two alternating + the refinement rounds'), three coefficient blocks
     int rc = ensure_cap(ctx, &ctx->partials, &ctx->partials_cap, 2 * (size_t)workers + n_slots);
     if (rc) return rc;
     LsmCoopArgs a;
@@ -1042,7 +1045,7 @@ static int run_lsm_coop(mcg_ctx* ctx, const mcg_paths* P, double r, double K, do
     a.is_call = is_call;
     a.out = ctx->partials;  // finish_sums reads {sum, sum^2} pairs from the head of the buffer
     a.partials = ctx->partials + 2 * (size_t)workers;
-    a.coef = a.partials + 2 * (size_t)nm * workers;
+    a.coef = a.partials + 3 * (size_t)nm * workers;
     a.timeout = reinterpret_cast<unsigned*>(ctx->scalars + SC_BARRIER);
     // test hook: MCG_LSM_SPIN_LIMIT=0 makes every wait give up at once and raises the time-out flag, which drives
     // the time-out -> per-date fall-back branch below on a healthy device (read on every call: tests flip it)
