@@ -340,6 +340,19 @@ __device__ __forceinline__ void lsm_publish_partials(const LsmCoopArgs& a, doubl
         for (int t = 0; t < NM; ++t) lsm_st_shared(part + (int64_t)t * G + b, m[t]);
     }
 }
+// ... only the moments T0 .. T0 + NT - 1 of the set (k_lsm_coop sends the power sums of a date, which do not depend on V, a
+// round ahead of its cross sums); red: NT * 4 doubles of its own
+template <int NB, int T0, int NT>
+__device__ __forceinline__ void lsm_publish_some(const LsmCoopArgs& a, double (&v)[NT], unsigned G, unsigned b, int area, double* red) {
+    constexpr int NM = 3 * NB - 1;
+    static_assert(T0 >= 0 && T0 + NT <= NM, "a range of the set's moments");
+    block_sum<NT, 4>(v, red);
+    double* part = a.partials + (int64_t)area * NM * G;
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) lsm_st_shared(part + (int64_t)(T0 + t) * G + b, v[t]);
+    }
+}
 
 // the reducing workgroup: poll all G partials, fixed-order sum, solve, publish the coefficients (and leave them in
 // sm_coef for its own threads).  The same fixed-order reduction as k_lsm_reduce_solve: wave w sums moments w, w+4, ...;
@@ -599,36 +612,88 @@ __global__ __launch_bounds__(256, (PPT >= 8 ? 2 : 3)) void k_lsm_coop(LsmCoopArg
     }
     double s_j[PPT], s_nxt[PREFETCH ? PPT : 1];
     if (j >= 0) load_row(j, s_j);
+    // A date's 2 NB - 1 power sums (count, sum x, sum x^2, ...) depend on its prices only, its NB cross sums on V as
+    // well.  With the next row prefetched (PREFETCH) a workgroup therefore forms and sends the NEXT date's power sums
+    // while this date's coefficients are on their way -- into the other slot set, which workgroup 0 reads a round later
+    // -- and only the cross sums (and their block reduction) remain between receiving the coefficients and sending the
+    // next partial moments.  early: the current date's power sums have gone out already.
+    constexpr int NP = 2 * NB - 1;
+    __shared__ double red_pow[NP * 4];
+    __shared__ double red_cross[NB * 4];
+    auto power_sums = [&](const double (&row)[PPT], double (&mp)[NP]) {
+#pragma unroll
+        for (int t = 0; t < NP; ++t) mp[t] = 0.0;
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            const double s = row[q];
+            if (q < n_live && payoff_of(call, s, a.K) > 1e-14) {
+                const double x = fma(s, a.invK, -1.0);
+                double pw = 1.0;
+#pragma unroll
+                for (int t = 0; t < NP; ++t) {
+                    mp[t] += pw;
+                    pw *= x;
+                }
+            }
+        }
+    };
+    bool early = false;
     for (; j >= 0; --j) {  // every remaining date regresses (this_time <= maturity from here on)
         LSM_TRACE(round, 0);
-        double m[NM];
+        double mc[NB];  // cross sums: sum x^t y, y = discounted value one date on (regression inputs, :51-74)
 #pragma unroll
-        for (int q = 0; q < NM; ++q) m[q] = 0.0;
+        for (int t = 0; t < NB; ++t) mc[t] = 0.0;
 #pragma unroll
-        for (int q = 0; q < PPT; ++q) {  // regression inputs, :51-74
+        for (int q = 0; q < PPT; ++q) {
             const double s = s_j[q];
             if (q < n_live && payoff_of(call, s, a.K) > 1e-14) {
                 const double x = fma(s, a.invK, -1.0);
                 const double y = V[q] * a.disc;
                 double pw = 1.0;
 #pragma unroll
-                for (int t = 0; t < 2 * NB - 1; ++t) {
-                    m[t] += pw;
-                    if (t < NB) m[2 * NB - 1 + t] = fma(pw, y, m[2 * NB - 1 + t]);
+                for (int t = 0; t < NB; ++t) {
+                    mc[t] = fma(pw, y, mc[t]);
                     pw *= x;
                 }
             }
         }
-        lsm_exchange<NB>(a, m, area, gave_up, red, sm_mom, sm_coef, false, 0.0, sm_ws, round++, [&]() {
+        LSM_TRACE(round, 1);  // moments accumulated
+        if (!early) {  // (uniform) first regression date, or no prefetch: the power sums go out with the cross sums
+            double mp[NP];
+            power_sums(s_j, mp);
+            lsm_publish_some<NB, 0, NP>(a, mp, G, blockIdx.x, area, red_pow);
+        }
+        lsm_publish_some<NB, NP, NB>(a, mc, G, blockIdx.x, area, red_cross);
+        bool next_early = false;
+        if constexpr (PREFETCH) {
+            if (j >= 1) load_row(j - 1, s_nxt);
+            next_early = j >= 1;
+        }
+        LSM_TRACE(round, 2);  // published, next row requested
+        auto send_next_power_sums = [&]() {
             if constexpr (PREFETCH) {
-                if (j >= 1) load_row(j - 1, s_nxt);
+                if (next_early) {  // (uniform)
+                    double mp[NP];
+                    power_sums(s_nxt, mp);
+                    lsm_publish_some<NB, 0, NP>(a, mp, G, blockIdx.x, area ^ 1, red_pow);
+                }
             }
-        });
+        };
+        if (blockIdx.x == 0) {  // workgroup 0 contributes AND reduces: its own next power sums wait until the coefficients are out
+            lsm_reduce_solve_publish<NB>(a, G, area, gave_up, sm_mom, sm_coef, false, 0.0, sm_ws, round);
+            send_next_power_sums();
+            __syncthreads();  // (red_pow's reader, thread 0, is done before anybody can come back to it)
+        } else {
+            send_next_power_sums();
+            lsm_poll_coefficients(a, area, gave_up, sm_coef);
+        }
+        ++round;
         if (__builtin_amdgcn_readfirstlane(sm_coef[LSM_C_REFINE] != 0.0 ? 1 : 0)) {  // (the same LDS word in every lane)
             // Grid-uniform (every workgroup holds the same coefficient block): the date is re-fitted about the mean of its
             // regressor -- the prices and V are still in registers -- through one more exchange (lsm_solve_nb).
             const double mu = sm_coef[LSM_C_HINT];
             __syncthreads();  // everyone has read the block before the next exchange rewrites sm_coef
+            double m[NM];
 #pragma unroll
             for (int q = 0; q < NM; ++q) m[q] = 0.0;
 #pragma unroll
@@ -666,6 +731,7 @@ __global__ __launch_bounds__(256, (PPT >= 8 ? 2 : 3)) void k_lsm_coop(LsmCoopArg
         }
         LSM_TRACE(round - 1, 7);  // next row in registers
         area ^= 1;
+        early = next_early;
     }
     double f[2] = {0.0, 0.0};
 #pragma unroll
