@@ -79,6 +79,29 @@ def test_gbm_two_paths_per_lane_matches_oracle(eng, orc, n_paths, n_steps, sigma
     P.free()
 
 
+def test_fused_payoff_sums_repeat_bit_for_bit():
+    """The sums a generator leaves for price_european are a fixed-order reduction (per workgroup / per share of the
+    persistent rBergomi kernel, then in chunks of 8192 partials, then one block): two contexts, and two runs on one,
+    return the same bits -- whichever workgroup drew which share."""
+    import montecarlooptionspricer_amd as mc
+    res = []
+    for rep in range(2):
+        e = mc.PathEngine(0)
+        for again in range(2):
+            P = e.gbm(SEED, 100.0, 0.04, 0.2, DT, 9, 3_000_001, payoff=(100.0, True))     # 5860 partials x 2 paths per lane
+            g = e.price_european(P, 100.0, 0.04, 9 * DT, True)
+            P.free()
+            Q = e.gbm(SEED, 100.0, 0.04, 0.2, DT, 3, 9_000_001, payoff=(100.0, False))    # 17579 partials: two chunk levels
+            g2 = e.price_european(Q, 100.0, 0.04, 3 * DT, False)
+            Q.free()
+            R = e.rbergomi(SEED, RB_S0, 0.04, 0.04, 0.1, 1.9, -0.9, DT, 40, 600_001, payoff=(100.0, False))  # 4688 shares on 512 workgroups
+            r = e.price_european(R, 100.0, 0.04, 40 * DT, False)
+            R.free()
+            res.append((g, g2, r))
+        e.close()
+    assert all(x == res[0] for x in res[1:]), res
+
+
 @pytest.mark.parametrize("n_steps", [2, 3, 4, 5, 6, 9, 11])
 def test_gbm_block_loop_tails_and_64_bit_path_ids(eng, orc, n_steps):
     """The generator runs per Philox block (4 steps) with a tail of 1-3 steps, and the Philox counter carries the full
