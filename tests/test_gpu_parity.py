@@ -367,6 +367,24 @@ def test_lsm_one_launch_timeout_falls_back_to_per_date_kernels(monkeypatch):
     e.close()
 
 
+@pytest.mark.parametrize("n", [300_000, 1_000_000, 3_000_000])
+def test_lsm_one_launch_sweep_repeats_bit_for_bit(n):
+    """The one-launch sweeps sum every moment in a fixed order (threads, waves, workgroups), whatever the timing of the
+    hand-shakes (4, 8 paths per thread and the LDS-ring variant): the same paths give the same bits, run after run and
+    context after context."""
+    import montecarlooptionspricer_amd as mc
+    res = []
+    for rep in range(2):
+        e = mc.PathEngine(0)
+        P = e.gbm(SEED + 5, 100.0, 0.04, 0.3, 0.05, 20, n)
+        for again in range(2):
+            res.append(e.price_lsm(P, 0.04, 100.0, 1.0, 0.05, False, 2))
+        assert e.lsm_one_launch_enabled()
+        P.free()
+        e.close()
+    assert all(x == res[0] for x in res[1:]), res
+
+
 def test_lsm_american_put_bounds(eng):
     """Sanity (not parity): American put >= European put (BS 6.0040 at these parameters)."""
     n, steps, dt = 200_000, 50, 0.02
