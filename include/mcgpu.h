@@ -93,6 +93,21 @@ int mcg_comm_init_rank(mcg_ctx* ctx, const unsigned char id[128], int n_ranks, i
  * At most 16 ranks. */
 int mcg_comm_init_shm(mcg_ctx* ctx, const char* name, int n_ranks, int rank);
 
+/* Opt-in, after mcg_comm_init_shm, collective over its ranks: keep the in-kernel mailbox in the GPUs' own HBM instead
+ * of the host segment.  Every rank allocates a mailbox in device memory, exports it (hipIpcGetMemHandle, handed over
+ * through the segment) and opens the peers' (hipIpcOpenMemHandle: on a multi-GPU node, peer memory over xGMI); a
+ * reducing workgroup then PUSHES its moments into every peer's mailbox and polls local memory only.  Taken into use
+ * only if every rank got through allocation, export, open and an in-kernel ping over the mappings; otherwise all
+ * ranks stay on the host mailbox together (status MCG_OK, *active = 0).  enable = 0 goes back to the host mailbox.
+ * The host segment keeps serving the barrier, the flags and the host all-reduce. */
+int mcg_comm_shm_peer_mailbox(mcg_ctx* ctx, int enable, int* active);
+
+/* What collective this ctx holds and how many ranks it has SEEN: kind 0 none, 1 callback (mcg_set_allreduce),
+ * 2 built-in RCCL, 3 node-local shared memory (host mailbox), 4 the same with the peer-memory mailbox active;
+ * n_ranks / rank as given at set-up; seen_ranks = ncclCommCount of the communicator (kind 2) or the number of
+ * processes attached to the segment (kinds 3, 4), 0 for a callback.  Any out pointer may be NULL. */
+int mcg_comm_info(mcg_ctx* ctx, int* kind, int* n_ranks, int* rank, int* seen_ranks);
+
 /* ---- path generation (replaces RoughVolatility.cpp:346-365, device side) ---------------- */
 /* GBM: the stepping loop of RoughVolatility.cpp:354-364 with v == sigma^2.
  * Paths [path_begin, path_begin + n_paths) of the global Philox stream `seed`. */
@@ -139,10 +154,14 @@ int mcg_price_european(mcg_ctx* ctx, const mcg_paths* paths, double K, double r,
 int mcg_price_lsm(mcg_ctx* ctx, const mcg_paths* paths, double r, double K, double maturity,
                   double dt, int is_call, int poly_order, double* mean, double* std_err);
 
-/* Whether this ctx still uses the one-launch LSM sweep (one launch per price up to 8.37M paths per GPU, order <= 4): it is switched off for the
- * rest of the ctx's life when the in-kernel hand-shake between workgroups ever times out (another process holding
- * part of the GPU); mcg_price_lsm then answers from the per-date kernels, as it does for that call already. */
+/* Whether this ctx currently uses the one-launch LSM sweep (one launch per price up to 8.37M paths per GPU, order <= 4):
+ * it is switched off for the next eight LSM prices when the in-kernel hand-shake between workgroups times out
+ * (another process holding part of the GPU); mcg_price_lsm answers those -- and the call that timed out -- from the
+ * per-date kernels (one launch per exercise date). */
 int mcg_lsm_one_launch_enabled(mcg_ctx* ctx, int* enabled);
+/* Allow the one-launch sweep again at once (after a time-out it comes back by itself eight LSM prices later).
+ * Sharded over mcg_comm_init_shm: call it on every rank or on none. */
+int mcg_lsm_one_launch_reset(mcg_ctx* ctx);
 
 /* AsymptoticAnalysis::PredictOptionPrice (src/models/AsymptoticAnalysisPricer.cpp:38-113) on a
  * device-resident matrix: mean over paths of the best discounted payoff among the dates (t <= maturity)
@@ -235,6 +254,17 @@ int mcg_timing_get(mcg_ctx* ctx, int kernel /* enum mcg_kernel */, double* total
  * fn 5: as 4 through the reference-grade (device library) implementation.
  * fn 6: y[0] = e^x for |x| <= 0.125 (the branch-free step exponential)   fn 7: the same for |x| <= 0.1. */
 int mcg_debug_eval(mcg_ctx* ctx, int fn, const double* x, double* y, int64_t n);
+/* Test hooks of the one-launch LSM sweeps' hand-shake: spin_limit = polling rounds before a wait gives up (0: every
+ * wait gives up at once, which drives the time-out -> per-date fall-back on a healthy device; < 0: the default);
+ * poll_delay = units of ~4 us by which workgroups other than the reducing one reach their coefficient poll late. */
+int mcg_debug_lsm_hooks(mcg_ctx* ctx, long long spin_limit, int poll_delay);
+/* Test hooks, host-only (no GPU needed): the shared segment's protocol on its own -- join `name` as `rank` of
+ * `n_ranks` (a stale segment of a crashed job under the same name is never joined), barrier (fails at once on every
+ * rank after a time-out or a poison), poison, leave. */
+int mcg_debug_shm_attach(const char* name, int n_ranks, int rank, double timeout_s, void** handle);
+int mcg_debug_shm_barrier(void* handle);
+int mcg_debug_shm_poison(void* handle);
+int mcg_debug_shm_detach(void* handle);
 
 #ifdef __cplusplus
 }

@@ -25,6 +25,7 @@ struct Rccl {
     int (*CommInitRank)(comm_t*, int, NcclId, int) = nullptr;
     int (*AllReduce)(const void*, void*, size_t, int, int, comm_t, hipStream_t) = nullptr;
     int (*CommDestroy)(comm_t) = nullptr;
+    int (*CommCount)(comm_t, int*) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
 };
 
@@ -52,6 +53,7 @@ void load_rccl() {
     g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(g_rccl.lib, "ncclCommInitRank");
     g_rccl.AllReduce = (decltype(g_rccl.AllReduce))dlsym(g_rccl.lib, "ncclAllReduce");
     g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(g_rccl.lib, "ncclCommDestroy");
+    g_rccl.CommCount = (decltype(g_rccl.CommCount))dlsym(g_rccl.lib, "ncclCommCount");
     g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(g_rccl.lib, "ncclGetErrorString");
     if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce) {
         g_load_err = "librccl is missing ncclGetUniqueId/ncclCommInitRank/ncclAllReduce";
@@ -93,6 +95,12 @@ void comm_release(mcg_ctx* ctx) {
         ctx->allreduce = nullptr;
         ctx->allreduce_user = nullptr;
     }
+}
+
+int comm_rccl_count(mcg_ctx* ctx) {
+    int n = 0;
+    if (!ctx->rccl_comm || !g_rccl.CommCount || g_rccl.CommCount((comm_t)ctx->rccl_comm, &n) != 0) return 0;
+    return n;
 }
 
 }  // namespace mcg

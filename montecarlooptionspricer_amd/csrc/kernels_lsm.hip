@@ -26,49 +26,143 @@ namespace mcg {
 
 enum { UPD_INIT = 0, UPD_REGRESS = 1, UPD_DISCOUNT = 2 };
 
-struct LsmArgs {
-    const double* S_upd;  // row being updated (date j), or the last row for UPD_INIT
-    const double* S_mom;  // row j-1 whose moments are accumulated (nullptr: none)
+// Agent-scope (sc1) accesses: through to the device's coherence point one by one, no fence (see the one-launch sweeps below).
+__device__ __forceinline__ void lsm_st_shared(double* p, double v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double lsm_ld_shared(const double* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The per-date route: ONE kernel per exercise date and -- sharded -- ONE collective between two of them.
+// (Sharded runs through RCCL or a callback, orders > 4, > 8.37M paths per GPU, the prices after a hand-shake time-out.)
+//   head : every workgroup solves the date's regression from the 3p+2 moments in `msg` (~1 us on one thread; sharded,
+//          `msg` has just been summed over the ranks, so every workgroup of every GPU obtains the same coefficients);
+//   body : V <- update with date j's fit (LSMPricer.cpp:78-94), moments of date j-1 accumulated from S_{j-1} and the
+//          new V (:51-74): reads S_j, S_{j-1}, V, writes V = 32 B per path and date;
+//   tail : per-workgroup partial moments leave by write-through stores; the LAST workgroup to finish (a relaxed
+//          ticket -- no fence: a fence would write the XCD's L2 back, V included) sums them in a fixed order into `msg`.
+// The host queues launch, all-reduce, launch, all-reduce, ... without ever looking at a result; WHICH date a launch
+// works on is decided on the device: a three-word state {date j, phase, centre} that every workgroup reads in its
+// head and the last workgroup advances in its tail.  That is what lets a date the first solve does not trust
+// (lsm_solve_nb's refinement request: few or nearly coincident in-the-money prices, orders >= 4) be re-fitted by the
+// reference's rank rule like in every other execution shape, although the re-fit needs a second, data-dependent
+// reduction: such a date simply takes TWO launches -- the first one only accumulates the moments of row j about the
+// mean regressor (V untouched: 16 B per path), the all-reduce that follows sums those instead, the second one solves
+// them with lsm_solve_centered and carries on.  Every rank takes the same decision from the same summed moments, so the
+// ranks stay in step.  Launches beyond the last date return at once; the host queues a few spare ones and, should a
+// sweep need more than it queued (it reads the state back once per batch), queues the rest.
+constexpr int LSM_ST_J = 0, LSM_ST_PHASE = 1, LSM_ST_MU = 2;  // state words (doubles)
+enum { LSM_PH_REGULAR = 0, LSM_PH_REFINED = 1, LSM_PH_INIT = 2 };
+
+struct LsmDateArgs {
+    const double* data;   // step-major matrix
+    int64_t ld, n;
     double* V;
-    int64_t n;
-    double K, invK, disc;
+    double K, invK, disc, dt, maturity;
     int is_call;
-    int upd;
-    const double* coef;   // device: the coefficient block of date j (lsm_device.hpp: LSM_C_*)
-    double* partials;     // [NM][gridDim.x] (moment-major: the reduce kernel reads contiguously)
-    int rev;              // walk the grid-stride chunks from the last to the first (see run_lsm)
+    double* msg;          // in: the moments the state's phase says (summed over the ranks); out: those of the next launch
+    double* state;        // {date j the next launch works on (< 0: done), phase, centre of a refinement}
+    double* partials;     // [NM][gridDim.x] (moment-major: the reducing workgroup reads contiguously)
+    unsigned* ticket;     // workgroups done; the last one resets it
 };
+
+// Tail of a launch.  HAVE: this launch produced partial moments m.  Returns true in the last workgroup to get here,
+// after it has summed all partials into msg (fixed order: wave w the moments w, w+4, ..; lane l the workgroups l,
+// l+64, ..) -- or zeroed msg when there were none.
+template <int NM>
+__device__ __forceinline__ bool lsm_date_tail(const LsmDateArgs& a, bool have, double (&m)[NM], double* red, unsigned* sm_last) {
+    const unsigned G = gridDim.x;
+    if (have) block_sum<NM, 4>(m, red);
+    if (threadIdx.x == 0) {
+        if (have) {
+#pragma unroll
+            for (int q = 0; q < NM; ++q) lsm_st_shared(a.partials + (int64_t)q * G + blockIdx.x, m[q]);
+            __builtin_amdgcn_s_waitcnt(0);  // the write-through stores are acknowledged before this workgroup's ticket is drawn
+        }
+        *sm_last = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == G - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    if (*sm_last == 0) return false;
+    // every workgroup has drawn its ticket, hence sent its partials and -- long before -- read msg and the state
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int q = wave; q < NM; q += 4) {
+        double s = 0.0;
+        if (have) {
+#pragma unroll 8
+            for (unsigned b = lane; b < G; b += 64) s += lsm_ld_shared(a.partials + (int64_t)q * G + b);
+            s = wave_sum(s);
+        }
+        if (lane == 0) a.msg[q] = s;
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return true;
+}
 
 // NB = poly_order + 1 basis functions; NM = (2p+1) power sums + (p+1) cross sums = 3*NB - 1.
 template <int NB>
-__global__ __launch_bounds__(256) void k_lsm_sweep(LsmArgs a) {
+__global__ __launch_bounds__(256) void k_lsm_date(LsmDateArgs a) {
     constexpr int NM = 3 * NB - 1;
     __shared__ double red[NM * 4];
+    __shared__ double sm_mom[32];
+    __shared__ double sm_coef[16];
+    __shared__ double sm_ws[lsm_ws_doubles(NB)];
+    __shared__ unsigned sm_last;
+    const int j = (int)a.state[LSM_ST_J];
+    if (j < 0) return;  // the sweep is over: a spare launch
+    const int phase = (int)a.state[LSM_ST_PHASE];
     const bool call = a.is_call != 0;
+    const bool reg = phase != LSM_PH_INIT && !(j * a.dt > a.maturity);  // LSMPricer.cpp:43-44
+    const double* S_j = a.data + (int64_t)j * a.ld;
     double c[NB];
     double n_itm = 0.0, center = 0.0;
-    if (a.upd == UPD_REGRESS) {
-#pragma unroll
-        for (int q = 0; q < NB; ++q) c[q] = a.coef[q];
-        n_itm = a.coef[LSM_C_COUNT];
-        center = a.coef[LSM_C_CENTER];
-    }
     double m[NM];
 #pragma unroll
     for (int q = 0; q < NM; ++q) m[q] = 0.0;
-
     const int64_t chunk = (int64_t)gridDim.x * 256;
     const int64_t n_chunks = (a.n + chunk - 1) / chunk;
+    const bool rev = (j & 1) != 0;  // consecutive dates walk the paths in opposite directions (see run_lsm)
+    if (reg) {
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int t = 0; t < NM; ++t) sm_mom[t] = a.msg[t];
+            if (phase == LSM_PH_REFINED) lsm_solve_centered(sm_mom, NB, a.state[LSM_ST_MU], a.K, sm_coef, sm_ws);
+            else lsm_solve_nb<NB>(sm_mom, 1.0, a.K, sm_coef);
+        }
+        __syncthreads();
+        if (phase == LSM_PH_REGULAR && sm_coef[LSM_C_REFINE] != 0.0) {  // (uniform over the grid and over the ranks)
+            // The date is re-fitted about the mean of its regressor: this launch only forms those moments.
+            const double mu = sm_coef[LSM_C_HINT];
+            for (int64_t k = 0; k < n_chunks; ++k) {
+                const int64_t i = (rev ? n_chunks - 1 - k : k) * chunk + (int64_t)blockIdx.x * 256 + threadIdx.x;
+                if (i >= a.n) continue;
+                const double s = S_j[i];
+                lsm_accumulate_centered<NB>(m, payoff_of(call, s, a.K) > 1e-14, s, a.V[i], a.invK, mu, a.disc);
+            }
+            if (lsm_date_tail<NM>(a, true, m, red, &sm_last) && threadIdx.x == 0) {
+                a.state[LSM_ST_PHASE] = (double)LSM_PH_REFINED;
+                a.state[LSM_ST_MU] = mu;
+            }
+            return;
+        }
+#pragma unroll
+        for (int q = 0; q < NB; ++q) c[q] = sm_coef[q];
+        n_itm = sm_coef[LSM_C_COUNT];
+        center = sm_coef[LSM_C_CENTER];
+    }
+    const bool have = j >= 1 && !((j - 1) * a.dt > a.maturity);  // date j-1 regresses: its inputs are formed here (:51-74)
+    const double* S_mom = a.data + (int64_t)(have ? j - 1 : j) * a.ld;
     for (int64_t k = 0; k < n_chunks; ++k) {
-        const int64_t i = (a.rev ? n_chunks - 1 - k : k) * chunk + (int64_t)blockIdx.x * 256 + threadIdx.x;
+        const int64_t i = (rev ? n_chunks - 1 - k : k) * chunk + (int64_t)blockIdx.x * 256 + threadIdx.x;
         if (i >= a.n) continue;
         double v;
-        if (a.upd == UPD_INIT) {
-            v = payoff_of(call, a.S_upd[i], a.K);  // LSMPricer.cpp:37-40
-        } else if (a.upd == UPD_DISCOUNT) {
+        if (phase == LSM_PH_INIT) {
+            v = payoff_of(call, S_j[i], a.K);  // LSMPricer.cpp:37-40
+        } else if (!reg) {
             v = a.V[i] * a.disc;  // :43-49
         } else {
-            const double s = a.S_upd[i];
+            const double s = S_j[i];
             const double pay = payoff_of(call, s, a.K);
             const double vn = a.V[i] * a.disc;
             if (pay > 1e-14 && n_itm > 0.0) {  // :78-86
@@ -80,8 +174,8 @@ __global__ __launch_bounds__(256) void k_lsm_sweep(LsmArgs a) {
             }
         }
         a.V[i] = v;
-        if (a.S_mom) {  // regression inputs of the next (earlier) date, :51-74
-            const double s = a.S_mom[i];
+        if (have) {
+            const double s = S_mom[i];
             if (payoff_of(call, s, a.K) > 1e-14) {
                 const double x = fma(s, a.invK, -1.0);
                 const double y = v * a.disc;
@@ -95,61 +189,30 @@ __global__ __launch_bounds__(256) void k_lsm_sweep(LsmArgs a) {
             }
         }
     }
-    if (a.S_mom) {
-        block_sum<NM, 4>(m, red);
-        if (threadIdx.x == 0) {
-#pragma unroll
-            for (int q = 0; q < NM; ++q) a.partials[(int64_t)q * gridDim.x + blockIdx.x] = m[q];
-        }
+    if (lsm_date_tail<NM>(a, have, m, red, &sm_last) && threadIdx.x == 0) {
+        a.state[LSM_ST_J] = (double)(j - 1);
+        a.state[LSM_ST_PHASE] = (double)LSM_PH_REGULAR;
     }
 }
 
-// What k_lsm_reduce_solve needs to re-fit a date about the mean of its regressor (lsm_solve_nb's refinement request):
-// the row the moments came from and the value vector they were formed with.  S == nullptr: never refine (sharded
-// runs -- the centred moments would need a second, data-dependent all-reduce -- and MartingaleOptimization's refit).
+// What the solve needs to know about MartingaleOptimization's refit (its samples are not a row of the matrix, its driver
+// is on the host anyway):
+//   request_only: solve the first pass with the refinement test on and leave the request in the coefficient block;
+//   centered:     the moments are already about `mu`: solve them with lsm_solve_centered.
 struct LsmRefine {
-    const double* S;
-    const double* V;
-    int64_t n;
-    double K, disc;
-    int is_call;
-    // MartingaleOptimization's refit (its samples are not a row of the matrix, its driver is on the host anyway):
-    //   request_only: solve the first pass with the refinement test on and leave the request in the coefficient block;
-    //   centered:     the moments are already about `mu`: solve them with lsm_solve_centered.
+    double K;
     int request_only, centered;
     double mu;
 };
 
-template <int NB>
-__device__ __forceinline__ void lsm_refine_block(const LsmRefine& rf, double mu, double* red, double* mc_out) {
-    constexpr int NM = 3 * NB - 1;
-    const bool call = rf.is_call != 0;
-    const double invK = 1.0 / rf.K;
-    double m[NM];
-#pragma unroll
-    for (int t = 0; t < NM; ++t) m[t] = 0.0;
-    for (int64_t i = threadIdx.x; i < rf.n; i += 256) {
-        const double sv = rf.S[i];
-        lsm_accumulate_centered<NB>(m, payoff_of(call, sv, rf.K) > 1e-14, sv, rf.V[i], invK, mu, rf.disc);
-    }
-    block_sum<NM, 4>(m, red);
-    if (threadIdx.x == 0) {
-#pragma unroll
-        for (int t = 0; t < NM; ++t) mc_out[t] = m[t];
-    }
-}
-
 // One block.  do_reduce: partials[nm][n_blocks] -> moments[nm] in a fixed order (wave w sums moments
 // w, w+4, ...: lanes stride over the blocks, then a wavefront butterfly).  do_solve: moments -> coef.
 // Single GPU: both in one launch.  Sharded: reduce, all-reduce of `moments`, then solve.
-// A date that asks for refinement (rare: lsm_solve_nb) is re-accumulated about its mean by THIS block alone --
-// one workgroup streaming the row, slow and correct -- and solved by lsm_solve_centered.
 __global__ __launch_bounds__(256) void k_lsm_reduce_solve(const double* partials, int n_blocks, int nm, int nb,
                                                           double* moments, double* coef, int do_reduce, int do_solve,
                                                           double min_count, LsmRefine rf) {
     __shared__ double sm[32];
     __shared__ double sm_c[16];
-    __shared__ double red[26 * 4];
     __shared__ double sm_ws[lsm_ws_doubles(9)];
     if (do_reduce) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -166,41 +229,21 @@ __global__ __launch_bounds__(256) void k_lsm_reduce_solve(const double* partials
         __syncthreads();
     }
     if (!do_solve) return;
-    if (rf.centered) {
-        if (threadIdx.x == 0) {
-            const double* mc = do_reduce ? sm : moments;
+    if (threadIdx.x == 0) {
+        const double* mc = do_reduce ? sm : moments;
+        if (rf.centered) {
             if (mc[0] >= min_count) {
                 lsm_solve_centered(mc, nb, rf.mu, rf.K, sm_c, sm_ws);
             } else {  // too few samples: coefficients stay 0 (as in lsm_solve_nb)
                 for (int t = 0; t < LSM_COEF_DOUBLES; ++t) sm_c[t] = 0.0;
                 sm_c[LSM_C_COUNT] = mc[0];
             }
+        } else {
+            lsm_solve_one(mc, nb, min_count, rf.request_only ? rf.K : 0.0, sm_c);
+            if (!rf.request_only) sm_c[LSM_C_REFINE] = 0.0;
         }
-        __syncthreads();
-        if (threadIdx.x < LSM_COEF_DOUBLES) coef[threadIdx.x] = sm_c[threadIdx.x];
-        return;
-    }
-    if (threadIdx.x == 0) {
-        lsm_solve_one(do_reduce ? sm : moments, nb, min_count, (rf.S || rf.request_only) ? rf.K : 0.0, sm_c);
-        if (!rf.S && !rf.request_only) sm_c[LSM_C_REFINE] = 0.0;
     }
     __syncthreads();
-    if (rf.S && sm_c[LSM_C_REFINE] != 0.0) {  // uniform
-        const double mu = sm_c[LSM_C_HINT];
-        switch (nb) {
-            case 1: lsm_refine_block<1>(rf, mu, red, sm); break;
-            case 2: lsm_refine_block<2>(rf, mu, red, sm); break;
-            case 3: lsm_refine_block<3>(rf, mu, red, sm); break;
-            case 4: lsm_refine_block<4>(rf, mu, red, sm); break;
-            case 5: lsm_refine_block<5>(rf, mu, red, sm); break;
-            case 6: lsm_refine_block<6>(rf, mu, red, sm); break;
-            case 7: lsm_refine_block<7>(rf, mu, red, sm); break;
-            case 8: lsm_refine_block<8>(rf, mu, red, sm); break;
-            default: lsm_refine_block<9>(rf, mu, red, sm); break;
-        }
-        if (threadIdx.x == 0) lsm_solve_centered(sm, nb, mu, rf.K, sm_c, sm_ws);
-        __syncthreads();
-    }
     if (threadIdx.x < LSM_COEF_DOUBLES) coef[threadIdx.x] = sm_c[threadIdx.x];
 }
 
@@ -279,6 +322,7 @@ __global__ __launch_bounds__(256) void k_lsm_final(const double* V, int64_t n, d
 // Sharded runs keep the per-date kernels: their all-reduce is issued from the host between two launches.
 constexpr unsigned LSM_SENTINEL32 = 0xFFF85EA7u;  // both halves of the reserved NaN (hipMemsetD32 fills the buffers)
 constexpr int LSM_AREA_REFINE = 2;                // slot set of refinement rounds (regular rounds alternate between sets 0 and 1)
+constexpr int LSM_COOP_RETRY_AFTER = 8;           // prices through the per-date kernels after a time-out before the one-launch sweep is tried again
 constexpr int LSM_COOP_MAX_GRID = 512;            // 8 slots per lane and moment in workgroup 0, two moments in flight
 
 struct LsmCoopArgs {
@@ -290,13 +334,19 @@ struct LsmCoopArgs {
     double* partials;  // [3][NM][gridDim.x], sentinel-filled: slot sets 0 / 1 of the regular rounds, 2 of refinement rounds
     double* coef;      // [3][16], sentinel-filled: coefficients, [9] = ITM count
     unsigned* timeout; // set when a spin gives up
-    unsigned spin_limit; // polling rounds before a spin gives up (LSM_SPIN_LIMIT; MCG_LSM_SPIN_LIMIT in tests)
+    unsigned spin_limit; // polling rounds before a spin gives up (LSM_SPIN_LIMIT; mcg_debug_lsm_hooks in tests)
+    unsigned poll_delay; // test hook: see lsm_poll_coefficients
     int u_full;          // k_lsm_big: units 0 .. u_full-1 lie inside the shard for EVERY thread (no masking needed)
     double* out;       // [2 * gridDim.x]: per-block {sum V, sum V^2}
-    // node-level exchange (mcg_comm_init_shm): mailbox[round][rank][SHM_ROW_DOUBLES] in device-mapped host memory,
-    // nullptr on a single GPU
+    // node-level exchange (mcg_comm_init_shm): mailbox[round][rank][SHM_ROW_DOUBLES], nullptr on a single GPU.
+    //   host mailbox (mb_push = 0): ONE copy in device-mapped host memory; every rank writes its row there and polls
+    //     the others' (each access crosses PCIe);
+    //   peer-memory mailbox (mb_push = 1): one copy per GPU in its own HBM; mbox = this rank's, mb_peer[r] = rank r's
+    //     as mapped here (hipIpcOpenMemHandle: peer memory over xGMI); a rank pushes its row into every copy and polls
+    //     only its own.
     double* mbox;
-    int mb_ranks, mb_rank;
+    int mb_ranks, mb_rank, mb_push;
+    double* mb_peer[SHM_MAX_RANKS];
 };
 
 // -DMCG_LSM_TRACE (timing studies only): workgroup 0 stamps the phases of the first 32 exchanges of k_lsm_coop with the
@@ -316,12 +366,6 @@ __device__ __forceinline__ bool lsm_is_sentinel(double v) {
 }
 __device__ __forceinline__ double lsm_sentinel() {
     return __longlong_as_double((long long)((((unsigned long long)LSM_SENTINEL32) << 32) | LSM_SENTINEL32));
-}
-__device__ __forceinline__ void lsm_st_shared(double* p, double v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ double lsm_ld_shared(const double* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 constexpr unsigned LSM_SPIN_LIMIT = 1u << 20;  // rounds of ~1.5 us; a co-resident grid needs a handful
 
@@ -358,22 +402,31 @@ __device__ __forceinline__ void lsm_publish_some(const LsmCoopArgs& a, double (&
 // sm_coef for its own threads).  The same fixed-order reduction as k_lsm_reduce_solve: wave w sums moments w, w+4, ...;
 // lane l the workgroups l, l+64, ...  Two of the wave's moments per round: all their slots are polled together, so the
 // usual date costs one round trip to the coherence point, not one per moment.
-// System-scope access to the node mailbox (host memory mapped into every GPU of the node: each access crosses PCIe).
+// System-scope access to the node mailbox (host memory mapped into every GPU of the node: each access crosses PCIe; or
+// the GPUs' own HBM, the peers' copies mapped over xGMI).
 __device__ __forceinline__ void lsm_st_node(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ __forceinline__ double lsm_ld_node(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 
 // Sum the local moments sm_mom[0..NM) over the GPUs of the node, inside the kernel: lane t of wave 0 publishes moment t in
-// this rank's row of the round's mailbox slot and polls the same entry of every rank's row (all loads of a poll in
-// flight together: one PCIe round trip) until none holds the reserved NaN; the sum runs in rank order, so every GPU
-// obtains the same bits.  Rows are written once per sweep; the host re-armed them before the launch (shm_arm_mailbox).
+// this rank's row of the round's mailbox slot -- in the one shared copy, or (peer-memory mailbox) in every GPU's copy --
+// and polls the same entry of every rank's row in the copy it reads (all loads of a poll in flight together: one PCIe
+// round trip, or local HBM) until none holds the reserved NaN; the sum runs in rank order, so every GPU obtains the same
+// bits.  Rows are written once per sweep; the host re-armed them before the launch (shm_arm_mailbox).
 template <int NM>
 __device__ __forceinline__ void lsm_node_allreduce(const LsmCoopArgs& a, int round, bool& gave_up, double* sm_mom) {
     static_assert(NM <= SHM_ROW_DOUBLES, "a rank's mailbox row holds the moments of orders <= 4");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     __syncthreads();  // sm_mom is complete
     if (wave == 0 && lane < NM) {
-        double* slot = a.mbox + (size_t)round * SHM_MAX_RANKS * SHM_ROW_DOUBLES;
-        lsm_st_node(slot + a.mb_rank * SHM_ROW_DOUBLES + lane, sm_mom[lane]);
+        const size_t slot_off = (size_t)round * SHM_MAX_RANKS * SHM_ROW_DOUBLES;
+        double* slot = a.mbox + slot_off;
+        if (a.mb_push) {
+#pragma unroll
+            for (int r = 0; r < SHM_MAX_RANKS; ++r)
+                if (r < a.mb_ranks) lsm_st_node(a.mb_peer[r] + slot_off + a.mb_rank * SHM_ROW_DOUBLES + lane, sm_mom[lane]);
+        } else {
+            lsm_st_node(slot + a.mb_rank * SHM_ROW_DOUBLES + lane, sm_mom[lane]);
+        }
         double v[SHM_MAX_RANKS];
         unsigned spins = 0;
         bool missing = !gave_up;
@@ -458,16 +511,19 @@ __device__ __forceinline__ void lsm_reduce_solve_publish(const LsmCoopArgs& a, u
         }
     }
     LSM_TRACE(round, 3);  // workgroup 0: this wave's moments are in
-    // All partials of a regular round are in: every workgroup is past every earlier coefficient block -- the previous
-    // regular round's and, if that date was re-fitted, the refinement round's.  (A refinement round recycles nothing:
-    // the blocks it could recycle are the ones the next regular round takes care of.)
+    if (a.mbox) lsm_node_allreduce<NM>(a, round, gave_up, sm_mom);  // (uniform) local -> node-wide moments
+    __syncthreads();
+    LSM_TRACE(round, 4);  // everybody's
+    // ALL partials of a regular round are in -- behind the barrier: every wave's moments, the cross sums included, which
+    // a workgroup sends only after it has read the previous coefficient block (k_lsm_coop sends a date's power sums a
+    // round ahead, so the moments wave 0 polls prove nothing on their own).  Every workgroup is therefore past every
+    // earlier coefficient block -- the previous regular round's and, if that date was re-fitted, the refinement
+    // round's -- and they can be re-armed.  (A refinement round recycles nothing: the blocks it could recycle are the
+    // ones the next regular round takes care of.)
     if (area != LSM_AREA_REFINE && threadIdx.x < 2 * LSM_COEF_DOUBLES) {
         const int blk = threadIdx.x < LSM_COEF_DOUBLES ? (area ^ 1) : LSM_AREA_REFINE;
         lsm_st_shared(a.coef + 16 * blk + threadIdx.x % LSM_COEF_DOUBLES, lsm_sentinel());
     }
-    if (a.mbox) lsm_node_allreduce<NM>(a, round, gave_up, sm_mom);  // (uniform) local -> node-wide moments
-    __syncthreads();
-    LSM_TRACE(round, 4);  // everybody's
     if (threadIdx.x == 0) {
         if (centered) lsm_solve_centered(sm_mom, NB, mu, a.K, sm_coef, ws);
         else lsm_solve_nb<NB>(sm_mom, 1.0, a.K, sm_coef);
@@ -481,6 +537,9 @@ __device__ __forceinline__ void lsm_reduce_solve_publish(const LsmCoopArgs& a, u
 // every other workgroup: the first LSM_COEF_DOUBLES lanes poll one entry of the coefficient block each into sm_coef
 __device__ __forceinline__ void lsm_poll_coefficients(const LsmCoopArgs& a, int area, bool& gave_up, double* sm_coef) {
     double* coef_now = a.coef + 16 * area;
+    // test hook (mcg_debug_lsm_hooks): workgroups other than 0 arrive late at their poll, ~4 us per unit -- the
+    // re-arming of a coefficient block must not depend on how quickly it was read
+    for (unsigned d = 0; d < a.poll_delay; ++d) __builtin_amdgcn_s_sleep(127);
     if (threadIdx.x < LSM_COEF_DOUBLES) {
         double cv = lsm_ld_shared(coef_now + threadIdx.x);
         unsigned spins = 0;
@@ -1028,8 +1087,8 @@ const CoopVariant* coop_variants_for(int nb) {
 
 // Returns MCG_OK with *done = true when the one-launch sweep ran; *done = false when this shape has to take the
 // per-date kernels (too many paths for the register file, order too high, or a time-out earlier on this context).
-static int run_lsm_coop(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double maturity, double dt, int is_call,
-                        int nb, double* sums3, bool* done) {
+static int run_lsm_coop_impl(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double maturity, double dt, int is_call,
+                             int nb, double* sums3, bool* done) {
     *done = false;
     const CoopVariant* vars = coop_variants_for(nb);
     const int64_t N = P->n_paths;
@@ -1039,7 +1098,8 @@ static int run_lsm_coop(mcg_ctx* ctx, const mcg_paths* P, double r, double K, do
     double* mbox = shm_mailbox_device(ctx);
     const int rounds_needed = 2 * (P->n_steps + 1);
     const int nm = 3 * nb - 1;
-    // coop_launch: cleared after a hand-shake time-out
+    // coop_launch: cleared after a hand-shake time-out, for the next LSM_COOP_RETRY_AFTER prices
+    if (!ctx->coop_launch && ctx->coop_retry_in > 0 && --ctx->coop_retry_in == 0) ctx->coop_launch = true;
     bool eligible = vars && ctx->coop_launch && N > 1024 && !(mbox && (rounds_needed > SHM_MAX_ROUNDS || nm > SHM_ROW_DOUBLES));
     // Few paths per thread keep each workgroup's serial work per date short, a small grid keeps the reduction in
     // workgroup 0 short: take the fewest paths per thread that need at most two workgroups per CU, else the most.
@@ -1113,14 +1173,17 @@ static int run_lsm_coop(mcg_ctx* ctx, const mcg_paths* P, double r, double K, do
     a.partials = ctx->partials + 2 * (size_t)workers;
     a.coef = a.partials + 3 * (size_t)nm * workers;
     a.timeout = reinterpret_cast<unsigned*>(ctx->scalars + SC_BARRIER);
-    // test hook: MCG_LSM_SPIN_LIMIT=0 makes every wait give up at once and raises the time-out flag, which drives
-    // the time-out -> per-date fall-back branch below on a healthy device (read on every call: tests flip it)
     a.u_full = (int)(N / ((int64_t)workers * 512));  // (k_lsm_big: units per thread that every thread has in full)
     a.mbox = mbox;
     a.mb_ranks = shm_n_ranks(ctx);
     a.mb_rank = shm_rank(ctx);
-    a.spin_limit = LSM_SPIN_LIMIT;
-    if (const char* e = std::getenv("MCG_LSM_SPIN_LIMIT")) a.spin_limit = (unsigned)std::strtoul(e, nullptr, 10);
+    double* const* peers = shm_mailbox_peers(ctx);
+    a.mb_push = peers ? 1 : 0;
+    for (int q = 0; q < SHM_MAX_RANKS; ++q) a.mb_peer[q] = peers ? peers[q] : nullptr;
+    // test hooks (mcg_debug_lsm_hooks): spin limit 0 makes every wait give up at once and raises the time-out flag,
+    // which drives the time-out -> per-date fall-back branch below on a healthy device
+    a.spin_limit = ctx->lsm_spin_limit < 0 ? LSM_SPIN_LIMIT : (unsigned)ctx->lsm_spin_limit;
+    a.poll_delay = (unsigned)ctx->lsm_poll_delay;
     MCG_HIP(hipMemsetD32Async((hipDeviceptr_t)a.partials, (int)LSM_SENTINEL32, 2 * n_slots, ctx->stream));
     MCG_HIP(hipMemsetAsync(a.timeout, 0, sizeof(unsigned), ctx->stream));
     if (mbox) {  // this rank's mailbox rows hold the reserved NaN again, and so do everybody else's, before anyone launches
@@ -1163,23 +1226,36 @@ static int run_lsm_coop(mcg_ctx* ctx, const mcg_paths* P, double r, double K, do
     if (timed_out) {
         // A spin gave up: the grid was not co-resident after all.  The result is discarded, this context stops using
         // the one-launch sweep, and the caller runs the per-date kernels.
+        // Another process was holding part of the GPU: that passes.  The next LSM_COOP_RETRY_AFTER prices of this ctx
+        // take the per-date kernels, then the one-launch sweep is tried again (sharded: every rank counts the same
+        // prices, the time-out flag having been summed over the ranks); mcg_lsm_one_launch_reset does it at once.
         ctx->coop_launch = false;
-        std::fprintf(stderr, "mcgpu: one-launch LSM sweep timed out; using the per-date kernels from now on\n");
+        ctx->coop_retry_in = LSM_COOP_RETRY_AFTER;
+        std::fprintf(stderr, "mcgpu: one-launch LSM sweep timed out; the next %d LSM prices use the per-date kernels\n",
+                     LSM_COOP_RETRY_AFTER);
         return MCG_OK;
     }
     *done = true;
     return MCG_OK;
 }
 
+static int run_lsm_coop(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double maturity, double dt, int is_call,
+                        int nb, double* sums3, bool* done) {
+    const int rc = run_lsm_coop_impl(ctx, P, r, K, maturity, dt, is_call, nb, sums3, done);
+    // Sharded over the node segment, a rank that fails locally between two collective steps would leave its peers
+    // waiting in a barrier it never enters: poison the segment, so that they fail at once with MCG_ERR_COMM.
+    if (rc != MCG_OK) shm_poison(ctx);
+    return rc;
+}
+
 // partials[grid][nm] -> moments (fixed order) -> optional all-reduce -> coefficients in ctx->scalars.
-// Shared by the LSM sweep and the MartingaleOptimization refit.
-int lsm_reduce_allreduce_solve(mcg_ctx* ctx, int grid, int nm, int nb, double min_count, const double* refine_row,
-                               const double* refine_v, int64_t refine_n, double K, double disc, int is_call, int mo_mode,
-                               double mo_mu) {
+// MartingaleOptimization's refit (the LSM sweep has its own per-date kernel, k_lsm_date).
+// mo_mode: 1 = first pass, leave the refinement request in the coefficient block; 2 = the moments are about mo_mu,
+// solve them with lsm_solve_centered.
+int lsm_reduce_allreduce_solve(mcg_ctx* ctx, int grid, int nm, int nb, double min_count, double K, int mo_mode, double mo_mu) {
     double* moments = ctx->scalars + SC_MOMENTS;
     double* coef = ctx->scalars + SC_COEF;
-    // refinement of an ill-conditioned date (lsm_solve_nb) inside the solve kernel is single-GPU only: see LsmRefine
-    LsmRefine rf{ctx->allreduce ? nullptr : refine_row, refine_v, refine_n, K, disc, is_call, mo_mode == 1, mo_mode == 2, mo_mu};
+    LsmRefine rf{K, mo_mode == 1, mo_mode == 2, mo_mu};
     if (ctx->allreduce) {
         {
             TimedLaunch t(ctx, MCG_K_LSM_SOLVE);
@@ -1201,22 +1277,22 @@ int lsm_reduce_allreduce_solve(mcg_ctx* ctx, int grid, int nm, int nb, double mi
 }
 
 template <int NB>
-static void launch_sweep_nb(mcg_ctx* ctx, int grid, const LsmArgs& a) {
-    hipLaunchKernelGGL(k_lsm_sweep<NB>, dim3(grid), dim3(256), 0, ctx->stream, a);
+static void launch_date_nb(mcg_ctx* ctx, int grid, const LsmDateArgs& a) {
+    hipLaunchKernelGGL(k_lsm_date<NB>, dim3(grid), dim3(256), 0, ctx->stream, a);
 }
 
-static void launch_sweep(mcg_ctx* ctx, int nb, int grid, const LsmArgs& a) {
+static void launch_date(mcg_ctx* ctx, int nb, int grid, const LsmDateArgs& a) {
     TimedLaunch t(ctx, MCG_K_LSM_SWEEP);
     switch (nb) {
-        case 1: launch_sweep_nb<1>(ctx, grid, a); break;
-        case 2: launch_sweep_nb<2>(ctx, grid, a); break;
-        case 3: launch_sweep_nb<3>(ctx, grid, a); break;
-        case 4: launch_sweep_nb<4>(ctx, grid, a); break;
-        case 5: launch_sweep_nb<5>(ctx, grid, a); break;
-        case 6: launch_sweep_nb<6>(ctx, grid, a); break;
-        case 7: launch_sweep_nb<7>(ctx, grid, a); break;
-        case 8: launch_sweep_nb<8>(ctx, grid, a); break;
-        default: launch_sweep_nb<9>(ctx, grid, a); break;
+        case 1: launch_date_nb<1>(ctx, grid, a); break;
+        case 2: launch_date_nb<2>(ctx, grid, a); break;
+        case 3: launch_date_nb<3>(ctx, grid, a); break;
+        case 4: launch_date_nb<4>(ctx, grid, a); break;
+        case 5: launch_date_nb<5>(ctx, grid, a); break;
+        case 6: launch_date_nb<6>(ctx, grid, a); break;
+        case 7: launch_date_nb<7>(ctx, grid, a); break;
+        case 8: launch_date_nb<8>(ctx, grid, a); break;
+        default: launch_date_nb<9>(ctx, grid, a); break;
     }
 }
 
@@ -1278,48 +1354,52 @@ int run_lsm(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double maturit
     rc = ensure_cap(ctx, &ctx->partials, &ctx->partials_cap, (size_t)grid * (size_t)std::max(nm, 2));
     if (rc) return rc;
 
-    double* coef = ctx->scalars + SC_COEF;
     const double disc = std::exp(-r * dt);  // LSMPricer.cpp:46,:69,:92
-    auto row = [&](int j) { return P->data + (int64_t)j * P->ld; };
-    auto regress_at = [&](int j) {  // :43-44
-        const double this_time = j * dt;
-        return !(this_time > maturity);
-    };
-
-    LsmArgs a;
-    a.V = ctx->lsm_v;
+    LsmDateArgs a;
+    a.data = P->data;
+    a.ld = P->ld;
     a.n = N;
+    a.V = ctx->lsm_v;
     a.K = K;
     a.invK = 1.0 / K;
     a.disc = disc;
+    a.dt = dt;
+    a.maturity = maturity;
     a.is_call = is_call;
-    a.coef = coef;
+    a.msg = ctx->scalars + SC_LSM_MSG;
+    a.state = ctx->scalars + SC_LSM_STATE;
     a.partials = ctx->partials;
-    // Consecutive sweeps walk the paths in opposite directions: what sweep j touched last (the tail of V and of
-    // row j-1, which sweep j-1 reads again) is what sweep j-1 touches first, while it is still in the 256 MB
-    // memory-side cache.
-    a.rev = 0;
+    a.ticket = reinterpret_cast<unsigned*>(ctx->scalars + SC_LSM_TICKET);
+    // Consecutive dates walk the paths in opposite directions (k_lsm_date: by the parity of j): what date j touched last
+    // (the tail of V and of row j-1, which date j-1 reads again) is what date j-1 touches first, while it is still in
+    // the 256 MB memory-side cache.
+    ctx->h_scalars[SC_LSM_STATE + LSM_ST_J] = (double)(M - 1);  // the terminal payoff, fused with the moments of date M-2
+    ctx->h_scalars[SC_LSM_STATE + LSM_ST_PHASE] = (double)LSM_PH_INIT;
+    ctx->h_scalars[SC_LSM_STATE + LSM_ST_MU] = 0.0;
+    MCG_HIP(hipMemcpyAsync(a.state, ctx->h_scalars + SC_LSM_STATE, 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    MCG_HIP(hipMemsetAsync(a.ticket, 0, sizeof(double), ctx->stream));
+    MCG_HIP(hipMemsetAsync(a.msg, 0, 32 * sizeof(double), ctx->stream));
 
-    // terminal payoff, fused with the moments of date M-2
-    a.upd = UPD_INIT;
-    a.S_upd = row(M - 1);
-    a.S_mom = (M >= 2 && regress_at(M - 2)) ? row(M - 2) : nullptr;
-    launch_sweep(ctx, nb, grid, a);
-    MCG_HIP(hipGetLastError());
-
-    for (int j = M - 2; j >= 0; --j) {
-        const bool reg = regress_at(j);
-        if (reg) {  // the moments of date j came from row j and the value vector as it stands now
-            int rcs = lsm_reduce_allreduce_solve(ctx, grid, nm, nb, 1.0, row(j), ctx->lsm_v, N, K, disc, is_call);
-            if (rcs) return rcs;
+    // M launches when no date asks for a re-fit, one more per date that does (orders >= 4: every date); a few spare
+    // ones are queued with the first batch, and the state tells afterwards whether the sweep got through.
+    int dates_left = M;
+    int64_t batch = nb >= 5 ? 2 * (int64_t)M : (int64_t)M + 4 + M / 32;
+    bool first = true;
+    while (dates_left > 0) {
+        for (int64_t k = 0; k < batch; ++k) {
+            if (!first && ctx->allreduce) {
+                if (ctx->allreduce(ctx->allreduce_user, a.msg, nm, (void*)ctx->stream) != 0)
+                    return fail(MCG_ERR_COMM, "all-reduce of regression moments failed");
+            }
+            first = false;
+            launch_date(ctx, nb, grid, a);
         }
-        a.upd = reg ? UPD_REGRESS : UPD_DISCOUNT;
-        a.S_upd = row(j);
-        a.S_mom = (j >= 1 && regress_at(j - 1)) ? row(j - 1) : nullptr;
-        a.rev ^= 1;
-        launch_sweep(ctx, nb, grid, a);
+        MCG_HIP(hipGetLastError());
+        MCG_HIP(hipMemcpyAsync(ctx->h_scalars + SC_LSM_STATE, a.state, 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        MCG_HIP(hipStreamSynchronize(ctx->stream));
+        dates_left = (int)ctx->h_scalars[SC_LSM_STATE + LSM_ST_J] + 1;
+        batch = 2 * (int64_t)dates_left;  // (every date takes two launches at most)
     }
-    MCG_HIP(hipGetLastError());
 
     {
         TimedLaunch t(ctx, MCG_K_LSM_SWEEP);

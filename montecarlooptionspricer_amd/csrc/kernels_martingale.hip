@@ -142,7 +142,7 @@ static int run_mo_nb(mcg_ctx* ctx, const MoArgs& a0, int grid, int64_t n_local, 
     // whose raw monomials Eigen truncates) the samples are re-accumulated about their mean and solved by
     // lsm_solve_centered.  The request is read on the host -- this driver synchronises below anyway -- so sharded runs
     // refine too (every rank sees the same all-reduced moments, hence the same request).
-    int rc = lsm_reduce_allreduce_solve(ctx, grid, NM + 1, NB, (double)NB, nullptr, nullptr, 0, a.K, 1.0, a.is_call, 1, 0.0);
+    int rc = lsm_reduce_allreduce_solve(ctx, grid, NM + 1, NB, (double)NB, a.K, 1, 0.0);
     if (rc) return rc;
     MCG_HIP(hipMemcpyAsync(ctx->h_scalars + SC_COEF, coef, LSM_COEF_DOUBLES * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     MCG_HIP(hipStreamSynchronize(ctx->stream));
@@ -153,7 +153,7 @@ static int run_mo_nb(mcg_ctx* ctx, const MoArgs& a0, int grid, int64_t n_local, 
             TimedLaunch t(ctx, MCG_K_MARTINGALE);
             hipLaunchKernelGGL(k_mo_primal<NB>, dim3(grid), dim3(256), 0, ctx->stream, a);
         }
-        rc = lsm_reduce_allreduce_solve(ctx, grid, NM + 1, NB, (double)NB, nullptr, nullptr, 0, a.K, 1.0, a.is_call, 2, a.center);
+        rc = lsm_reduce_allreduce_solve(ctx, grid, NM + 1, NB, (double)NB, a.K, 2, a.center);
         if (rc) return rc;
     }
     double s[3];

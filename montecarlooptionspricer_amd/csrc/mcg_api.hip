@@ -551,6 +551,21 @@ int mcg_lsm_one_launch_enabled(mcg_ctx* ctx, int* enabled) {
     return MCG_OK;
 }
 
+int mcg_lsm_one_launch_reset(mcg_ctx* ctx) {
+    if (!ctx) return fail(MCG_ERR_INVALID, "ctx is NULL");
+    ctx->coop_launch = true;
+    ctx->coop_retry_in = 0;
+    return MCG_OK;
+}
+
+int mcg_debug_lsm_hooks(mcg_ctx* ctx, long long spin_limit, int poll_delay) {
+    if (!ctx) return fail(MCG_ERR_INVALID, "ctx is NULL");
+    if (spin_limit > 0xffffffffLL || poll_delay < 0 || poll_delay > 1000) return fail(MCG_ERR_INVALID, "bad hook values");
+    ctx->lsm_spin_limit = spin_limit;
+    ctx->lsm_poll_delay = poll_delay;
+    return MCG_OK;
+}
+
 int mcg_price_asymptotic(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double maturity, double dt, int is_call,
                          double sigma, double dividend, double* price) {
     if (!ctx || !P || !price) return fail(MCG_ERR_INVALID, "ctx/paths/price is NULL");

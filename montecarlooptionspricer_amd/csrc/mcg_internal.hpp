@@ -47,7 +47,10 @@ struct mcg_ctx {
     hipStream_t stream = nullptr;
     bool owns_stream = false;
     int n_cus = 256;
-    bool coop_launch = false;    // the one-launch LSM sweep (k_lsm_coop) is allowed on this context
+    bool coop_launch = false;    // the one-launch LSM sweep (k_lsm_coop / k_lsm_big) is allowed on this context
+    int coop_retry_in = 0;       // after a hand-shake time-out: LSM prices left before it is allowed again (0: stays off until reset)
+    long long lsm_spin_limit = -1;  // test hooks (mcg_debug_lsm_hooks): polling rounds before a spin gives up (< 0: default)
+    int lsm_poll_delay = 0;         //   workgroups other than 0 reach their coefficient poll late
 
     // cached device buffers (path matrices are tens of GB: never hipMalloc per call in steady state)
     std::vector<mcg::PoolBuf> pool;
@@ -107,6 +110,9 @@ constexpr int SC_COEF = 40;    // [40..53) the LSM coefficient block of the curr
 constexpr int SC_FINAL = 64;   // [64..67) LSM final sums
 constexpr int SC_BARRIER = 72; // [72] 32-bit timeout flag of k_lsm_coop's hand-shake
 constexpr int SC_TICKET = 80;  // [80] 64-bit share ticket of the persistent rBergomi generator (zeroed before each launch)
+constexpr int SC_LSM_TICKET = 88;  // [88] 32-bit "workgroups done" ticket of the per-date LSM kernel (k_lsm_date)
+constexpr int SC_LSM_MSG = 96;     // [96..128) per-date LSM message: the 3p+2 moments the next launch solves (the all-reduced part)
+constexpr int SC_LSM_STATE = 128;  // [128..131) per-date LSM state: date, phase, centre (kernels_lsm.hip: LSM_ST_*)
 
 int pool_alloc(mcg_ctx* ctx, size_t bytes, void** out);
 void pool_release(mcg_ctx* ctx, void* ptr, size_t bytes);
@@ -123,13 +129,19 @@ struct TimedLaunch {
 };
 
 void comm_release(mcg_ctx* ctx);  // comm_rccl.cpp
+int comm_rccl_count(mcg_ctx* ctx);  // ncclCommCount of the built-in communicator (0: none / not available)
 // comm_shm.cpp
 void shm_release(mcg_ctx* ctx);
 int shm_arm_mailbox(mcg_ctx* ctx, int rounds, uint64_t sentinel_bits);
 int shm_sum_flag(mcg_ctx* ctx, int flag, int* total);
-double* shm_mailbox_device(mcg_ctx* ctx);
+void shm_poison(mcg_ctx* ctx);  // a rank failed between two collective steps: every later barrier fails at once on every rank
+double* shm_mailbox_device(mcg_ctx* ctx);        // the mailbox this rank polls (host segment, or its own HBM)
+double* const* shm_mailbox_peers(mcg_ctx* ctx);  // peer-memory mode: every rank's mailbox as mapped here; else nullptr
 int shm_rank(mcg_ctx* ctx);
 int shm_n_ranks(mcg_ctx* ctx);
+int shm_attached(mcg_ctx* ctx);
+bool shm_peer_active(mcg_ctx* ctx);
+int peer_ping(mcg_ctx* ctx, double* const* peers, int n, int rank);  // comm_peer.hip
 
 int paths_new(mcg_ctx* ctx, int64_t n_paths, int n_steps, uint64_t path_begin, mcg_paths** out);
 
@@ -143,12 +155,9 @@ int finish_sums(mcg_ctx* ctx, int64_t n_blocks, int64_t n_local, double out3[3])
 int run_lsm(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double maturity, double dt, int is_call,
             int poly_order, double* mean, double* std_err);
 
-// refine_row: the row the moments came from (LSM: a date that asks for it is re-fitted inside the solve kernel).
-// mo_mode (MartingaleOptimization, whose driver re-accumulates on request): 1 = first pass, leave the refinement
+// MartingaleOptimization's refit (its driver re-accumulates on request): mo_mode 1 = first pass, leave the refinement
 // request in the coefficient block; 2 = the moments are about mo_mu, solve them with lsm_solve_centered.
-int lsm_reduce_allreduce_solve(mcg_ctx* ctx, int grid, int nm, int nb, double min_count, const double* refine_row = nullptr,
-                               const double* refine_v = nullptr, int64_t refine_n = 0, double K = 0.0, double disc = 1.0,
-                               int is_call = 0, int mo_mode = 0, double mo_mu = 0.0);
+int lsm_reduce_allreduce_solve(mcg_ctx* ctx, int grid, int nm, int nb, double min_count, double K, int mo_mode, double mo_mu);
 int run_martingale(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double maturity, double dt, int is_call,
                    int poly_order, int max_iterations, double* price, double* lower, double* upper);
 int run_branching(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double maturity, double dt, int is_call,

@@ -163,11 +163,20 @@ class PathEngine:
         uid = broadcast_bytes(uid)
         check(self._L.mcg_comm_init_rank(self._ctx, uid, int(world), int(rank)))
 
-    def init_shm(self, name: str, rank: int, world: int) -> None:
+    def init_shm(self, name: str, rank: int, world: int, peer_mailbox: bool = False) -> bool:
         """Node-local shared-memory collective (mcg_comm_init_shm): `name` starts with '/', is the same on every rank
         and unique to the job.  Host all-reduce for the sums; the one-launch LSM sweeps exchange their per-date moments
-        between the GPUs inside the kernel."""
+        between the GPUs inside the kernel.  peer_mailbox: ask for the in-kernel mailbox in the GPUs' own HBM, mapped
+        into the peers by HIP IPC (mcg_comm_shm_peer_mailbox; every rank or none); returns whether it is in use."""
         check(self._L.mcg_comm_init_shm(self._ctx, name.encode(), int(world), int(rank)))
+        return self.shm_peer_mailbox(True) if peer_mailbox else False
+
+    def shm_peer_mailbox(self, enable: bool = True) -> bool:
+        """Collective over the ranks of the segment: switch the in-kernel mailbox between peer-mapped device memory and
+        the host segment.  True when the peer-memory mailbox is in use afterwards (all ranks agree)."""
+        active = C.c_int()
+        check(self._L.mcg_comm_shm_peer_mailbox(self._ctx, int(bool(enable)), C.byref(active)))
+        return bool(active.value)
 
     # -- generation -----------------------------------------------------------------------------
     def gbm(self, seed: int, S0: float, r: float, sigma: float, dt: float, n_steps: int, n_paths: int,
@@ -224,6 +233,21 @@ class PathEngine:
         v = C.c_int()
         check(self._L.mcg_lsm_one_launch_enabled(self._ctx, C.byref(v)))
         return bool(v.value)
+
+    def lsm_one_launch_reset(self) -> None:
+        """Allow the one-launch sweep again at once after a time-out (mcg_lsm_one_launch_reset)."""
+        check(self._L.mcg_lsm_one_launch_reset(self._ctx))
+
+    def debug_lsm_hooks(self, spin_limit: int = -1, poll_delay: int = 0) -> None:
+        """Test hooks of the one-launch sweeps' hand-shake (mcg_debug_lsm_hooks)."""
+        check(self._L.mcg_debug_lsm_hooks(self._ctx, int(spin_limit), int(poll_delay)))
+
+    def comm_info(self) -> dict:
+        """Collective held by this ctx and the ranks it has seen (mcg_comm_info)."""
+        k, n, r, seen = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        check(self._L.mcg_comm_info(self._ctx, C.byref(k), C.byref(n), C.byref(r), C.byref(seen)))
+        kinds = {0: "none", 1: "callback", 2: "rccl", 3: "shm", 4: "shm+peer-memory mailbox"}
+        return {"kind": kinds.get(k.value, str(k.value)), "n_ranks": n.value, "rank": r.value, "seen_ranks": seen.value}
 
     def price_asymptotic(self, paths: PathMatrix, r: float, K: float, maturity: float, dt: float, is_call: bool,
                          sigma: float, dividend: float) -> float:

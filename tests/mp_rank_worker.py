@@ -52,9 +52,9 @@ def main() -> None:
 
         eng.set_allreduce(allreduce)
     else:
-        if mode == "shm_timeout":       # every hand-shake gives up at once: the ranks must agree to fall back together
-            os.environ["MCG_LSM_SPIN_LIMIT"] = "0"
         eng = mc.PathEngine(0)
+        if mode == "shm_timeout":       # every hand-shake gives up at once: the ranks must agree to fall back together
+            eng.debug_lsm_hooks(spin_limit=0)
         eng.init_shm(f"/mcg_test_{port}", rank, world)
     eng.timing_enable(True)
     res = {}

@@ -343,9 +343,10 @@ def test_lsm_single_launch_sweep_from_concurrent_host_threads():
     assert all(o == want for o in out), (out, want)
 
 
-def test_lsm_one_launch_timeout_falls_back_to_per_date_kernels(monkeypatch):
-    """The hand-shake of the one-launch sweep gives up (forced: MCG_LSM_SPIN_LIMIT=0): the void result is discarded,
-    the call answers from the per-date kernels, the ctx stops using the one-launch sweep, nothing hangs."""
+def test_lsm_one_launch_timeout_falls_back_to_per_date_kernels():
+    """The hand-shake of the one-launch sweep gives up (forced: spin limit 0 through mcg_debug_lsm_hooks): the void
+    result is discarded, the call answers from the per-date kernels, the ctx stays on them for the next eight prices and
+    then tries the one-launch sweep again (or at once after mcg_lsm_one_launch_reset); nothing hangs."""
     base = mc.PathEngine(0)
     base.set_allreduce(lambda ptr, count, stream: None)     # a collective (identity) forces the per-date kernels
     P = base.gbm(SEED, 100.0, 0.04, 0.2, 0.02, 20, 300_000)
@@ -357,12 +358,19 @@ def test_lsm_one_launch_timeout_falls_back_to_per_date_kernels(monkeypatch):
     assert e.lsm_one_launch_enabled()
     one = e.price_lsm(Q, 0.04, 100.0, 0.4, 0.02, False, 2)   # healthy: the one-launch sweep answers
     assert e.lsm_one_launch_enabled() and one == pytest.approx(want, rel=1e-11)
-    monkeypatch.setenv("MCG_LSM_SPIN_LIMIT", "0")
+    e.debug_lsm_hooks(spin_limit=0)
     got = e.price_lsm(Q, 0.04, 100.0, 0.4, 0.02, False, 2)
     assert not e.lsm_one_launch_enabled()
     assert got == want                                       # identical kernels, identical summation order
-    monkeypatch.delenv("MCG_LSM_SPIN_LIMIT")
-    assert e.price_lsm(Q, 0.04, 100.0, 0.4, 0.02, False, 2) == want and not e.lsm_one_launch_enabled()   # sticky
+    e.debug_lsm_hooks()
+    for _ in range(7):                                       # the next prices stay on the per-date kernels ...
+        assert e.price_lsm(Q, 0.04, 100.0, 0.4, 0.02, False, 2) == want and not e.lsm_one_launch_enabled()
+    assert e.price_lsm(Q, 0.04, 100.0, 0.4, 0.02, False, 2) == one and e.lsm_one_launch_enabled()   # ... then it is back
+    e.debug_lsm_hooks(spin_limit=0)
+    assert e.price_lsm(Q, 0.04, 100.0, 0.4, 0.02, False, 2) == want and not e.lsm_one_launch_enabled()
+    e.debug_lsm_hooks()
+    e.lsm_one_launch_reset()                                 # or at once, on request
+    assert e.price_lsm(Q, 0.04, 100.0, 0.4, 0.02, False, 2) == one and e.lsm_one_launch_enabled()
     Q.free()
     e.close()
 
@@ -455,19 +463,18 @@ def test_lsm_near_degenerate_itm_sets_follow_the_reference_rank_rule(eng, orc, n
                 err = abs(got - want) / abs(want)
                 worst = max(worst, err)
                 assert err <= 1e-6, (n_total, base, n_itm, spread, got, want)
-    # the same through the per-date kernels (a collective, here the identity, selects them)
+    # the same through the per-date kernels (a collective, here the identity, selects them): they re-fit such a date
+    # from the one set of moments they carry (taken about the previous date's mean) -- same rule, same price
     other = mc.PathEngine(0)
     try:
         other.set_allreduce(lambda ptr, count, stream: None)
-        m = _near_degenerate_matrix(rs, n_total, 3, 90.0, 1e-4)
-        P = eng.from_host(m)
-        Q = other.from_host(m)
-        a = eng.price_lsm(P, 0.04, 100.0, 1.0, 0.5, False, 2)[0]
-        b = other.price_lsm(Q, 0.04, 100.0, 1.0, 0.5, False, 2)[0]
-        P.free()
-        Q.free()
-        # sharded runs do not refine (documented in lsm_device.hpp): only finite and close to the discounted payoffs
-        assert math.isfinite(b) and abs(a - b) <= 0.05 * abs(a)
+        for base, n_itm, spread in ((90.0, 3, 1e-4), (99.9, 2, 1e-6), (60.0, 5, 1e-3), (90.0, 4, 1e-7), (99.9, 3, 1e-5)):
+            m = _near_degenerate_matrix(rs, n_total, n_itm, base, spread)
+            Q = other.from_host(m)
+            b = other.price_lsm(Q, 0.04, 100.0, 1.0, 0.5, False, 2)[0]
+            Q.free()
+            want = orc.lsm_price(m, 0.04, 100.0, 1.0, 0.5, False, 2, step_major=False)
+            assert abs(b - want) <= 1e-6 * abs(want), ("per-date kernels", n_total, base, n_itm, spread, b, want)
     finally:
         other.close()
 
@@ -490,9 +497,8 @@ def test_lsm_near_degenerate_large_shards(eng, orc):
     got = eng.price_lsm(P, 0.04, 100.0, 1.0, 0.5, False, 2)[0]
     P.free()
     assert abs(got - want_big) <= 1e-6 * abs(want_big), ("one launch, 5M", got, want_big)
-    import os
     e = mc.PathEngine(0)
-    os.environ["MCG_LSM_SPIN_LIMIT"] = "0"                    # first call times out -> per-date kernels from then on
+    e.debug_lsm_hooks(spin_limit=0)                           # first call times out -> per-date kernels answer
     try:
         P = e.from_host(m)
         got = e.price_lsm(P, 0.04, 100.0, 1.0, 0.5, False, 2)[0]
@@ -500,7 +506,6 @@ def test_lsm_near_degenerate_large_shards(eng, orc):
         assert abs(got - want) <= 1e-6 * abs(want), ("per-date", got, want)
         P.free()
     finally:
-        del os.environ["MCG_LSM_SPIN_LIMIT"]
         e.close()
 
 
