@@ -19,8 +19,13 @@ Weak scaling: every rank owns `--paths` global path ids [rank*paths, (rank+1)*pa
 stream; no data-path collective except the payoff / moment all-reduces.  The collective is the library's built-in RCCL
 communicator (mcg_comm_init_rank: issued from C on the ctx's stream, nothing on the host waits per date); `--collective
 torch` routes it through torch.distributed instead.  Prints ONE JSON line on rank 0 with the driver's contract fields
-plus "roofline", "cpu_baseline" (N=1 only) and, for the default run at N=1, "extra.configs": C3, C4 and the C5 shard
-timed once each after the headline loop.
+plus "roofline", "cpu_baseline" (N=1 only) and "extra.configs":
+  * N = 1 (default run): C3, C4 and the C5 shard timed once each after the headline loop, the three other pricers of
+    the driver on the C3 matrix and the batched driver rows (SURVEY 8f), the cold first launch of C2;
+  * N > 1: BASELINE.json configs[4] (C5: rBergomi American put LSM, 8M paths per GPU -- N = 8 is the 64M-path job)
+    timed after the C2 loop through each collective in turn -- the node mailbox in host memory ("shm"), the same in
+    peer-mapped device memory ("ipc") and the built-in RCCL communicator ("rccl") -- with the slowest and the fastest
+    rank's ms per pass, the collective that actually ran and the number of ranks its communicator has SEEN.
 """
 from __future__ import annotations
 
@@ -233,6 +238,170 @@ def extra_configs(eng, N) -> list:
     return out
 
 
+def widening_configs(eng, N) -> list:
+    """SURVEY 8(f) rows in this round's terms: the three other pricers of the reference's driver on the C3 matrix
+    (GBM, 1M paths x 50 dates, device-resident) and the batched driver rows (20 000 option rows x 250 rBergomi paths, four
+    prices each), once each after one untimed pass: device ms of the pricer's kernels (HIP events), the bytes its
+    streams move by construction and the HBM fraction that makes."""
+    import numpy as np
+    out, reps = [], 3
+    n, steps, dt = 1_000_000, 50, 0.02
+    mat = 8.0 * (steps + 1) * n   # one read of the matrix
+    P = eng.gbm(SEED, 100.0, 0.04, 0.2, dt, steps, n)
+    ex = list(range(steps))       # the driver passes 0..steps-1 (PredictionGen.cpp:780-783)
+    specs = [
+        ("AsymptoticAnalysis::PredictOptionPrice (put, sigma 0.2, dividend 0) on the C3 matrix", N.K_ASYM,
+         lambda: eng.price_asymptotic(P, 0.04, 100.0, 1.0, dt, False, 0.2, 0.0), mat,
+         "one read of the matrix (k_asym_scan)"),
+        ("MartingaleOptimization::PredictOptionPrice (put, order 2, 5 iterations) on the C3 matrix", N.K_MARTINGALE,
+         lambda: eng.price_martingale(P, 0.04, 100.0, 1.0, dt, False, 2, 5)[0], 2.0 * mat + 8.0 * n,
+         "two reads of the matrix (primal + moments, dual) and one of row 0"),
+        ("BranchingProcesses::PredictOptionPrice (put, 10 branches, 50 exercise dates) on the C3 matrix", N.K_BRANCHING,
+         lambda: eng.price_branching(P, 0.04, 100.0, 1.0, dt, False, 10, ex, SEED)[0], 3.0 * mat + 8.0 * 10 * steps * n,
+         "suffix maxima: read S, write F; bounds: read S + 10 random 8-byte gathers in F per path and date (rows of F are 8 MB: L2 / MALL hits, counted as moved)"),
+    ]
+    for name, kid, fn, moved, what in specs:
+        fn()
+        eng.synchronize()
+        eng.timing_reset()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            price = fn()
+        eng.synchronize()
+        wall = (time.perf_counter() - t0) / reps * 1e3
+        ms, cnt = eng.timing_get(kid)
+        out.append({"config": name, "paths": n, "ms_per_call": wall, "price": price,
+                    "kernel_ms_per_call": ms / reps, "launches_per_call": cnt // reps, "bytes_moved_per_call": moved,
+                    "bytes_moved": what, "hbm_frac": moved / (ms / reps * 1e-3) / 1e9 / HBM_PEAK_GBS})
+    P.free()
+    rs = np.random.RandomState(0)   # the row mix of tools/bench_rows.py: 5..126 steps, calls and puts around the money
+    rows = []
+    for _ in range(20_000):
+        st = int(rs.randint(5, 127))
+        S0 = float(rs.uniform(20, 400))
+        rows.append(dict(S0=S0, xi=float(rs.uniform(0.01, 0.3)), H=float(rs.uniform(0.3, 0.6)), eta=float(rs.uniform(0.01, 0.06)),
+                         rho=-0.3, strike=S0 * float(rs.uniform(0.9, 1.1)), maturity=st / 252.0, sigma=float(rs.uniform(0.1, 0.6)),
+                         dividend=0.08, n_steps=st, is_call=int(rs.randint(0, 2))))
+    eng.batch_price_rows(rows[:64])
+    eng.timing_reset()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        pr = eng.batch_price_rows(rows, seed=1)
+    wall = (time.perf_counter() - t0) / reps * 1e3
+    ms, cnt = eng.timing_get(N.K_BATCH)
+    cols = sum(r["n_steps"] + 1 for r in rows)
+    # paths written once and read by each of the four pricers; branching additionally writes and re-reads F
+    moved = 8.0 * 250 * cols * (1 + 4 + 2)
+    out.append({"config": "mcg_batch_price_rows: 20 000 driver rows x 250 rBergomi paths (5-126 steps), four prices per row",
+                "rows": len(rows), "ms_per_call": wall, "rows_per_s": len(rows) / wall * 1e3, "kernel_ms_per_call": ms / max(cnt, 1),
+                "launches_per_call": 6, "bytes_moved_per_call": moved,
+                "bytes_moved": "row matrices written once, read by the four pricers, F of the branching rows written and read",
+                "hbm_frac": moved / (ms / max(cnt, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "note": "latency- and issue-bound small-row work: the HBM fraction is reported, not the bound",
+                "mean_prices": [float(x) for x in pr.mean(axis=0)]})
+    return out
+
+
+def install_collective(eng, mc, want: str, dist, torch, rank: int, world: int) -> str:
+    """Give `eng` the collective `want` ("shm", "ipc", "rccl", "torch") -- every rank ends up on the SAME one: a set-up
+    that fails on any rank sends all of them one step down (ipc -> shm -> rccl -> torch).  Returns what is installed."""
+    def everyone(ok: bool) -> bool:
+        t = torch.tensor([1 if ok else 0], device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return int(t.item()) == 1
+
+    got = want
+    if want in ("shm", "ipc"):
+        box = [f"/mcg_bench_{os.getpid()}_{time.time_ns()}" if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        ok = True
+        try:
+            eng.init_shm(box[0], rank, world)
+        except mc.McgError as e:
+            print(f"bench: shared-memory communicator unavailable ({e}); using RCCL", file=sys.stderr)
+            ok = False
+        if not everyone(ok):
+            eng.set_allreduce(None)
+            got = f"rccl ({want} init failed" + ("" if not ok else " on a peer") + ")"
+        elif want == "ipc" and not eng.shm_peer_mailbox(True):   # (collective over the segment: the ranks agree inside)
+            got = "shm (peer-memory mailbox unavailable: export, open or in-kernel ping failed on some rank)"
+    if got.startswith("rccl"):
+        def bcast(uid):
+            box = [uid]
+            dist.broadcast_object_list(box, src=0)
+            return box[0]
+        ok = True
+        try:
+            eng.init_rccl(rank, world, bcast)
+        except mc.McgError as e:           # communicator set-up failed on this node: use torch's, and say so
+            print(f"bench: built-in RCCL communicator unavailable ({e}); using torch.distributed", file=sys.stderr)
+            ok = False
+        if not everyone(ok):               # all ranks take the same route
+            got = "torch (built-in RCCL init failed" + ("" if not ok else " on a peer") + ")"
+            eng.use_torch_distributed()
+    elif got == "torch":
+        eng.use_torch_distributed()
+    return got
+
+
+def c5_sharded_rows(args, mc, N, dist, torch, device, stream, rank, world) -> list:
+    """BASELINE.json configs[4] on this run's N ranks, after the headline loop: rBergomi (H = 0.1, eta = 1.9) American put,
+    LSM order 2, 252 steps, --c5-paths (8M) paths per GPU of ONE Philox stream, timed through each collective of
+    --c5-collectives in turn on a fresh context.  One untimed pass, then 3 timed between barriers; per row: the slowest
+    and the fastest rank's ms per pass, the collective that ran, what its communicator has seen (mcg_comm_info), the
+    launches of the LSM sweep per pass (1 = the one-launch sweep exchanged inside the kernel) and the global price."""
+    from montecarlooptionspricer_amd.sharding import shard_range
+    rows, reps, steps = [], 3, 252
+    total = args.c5_paths * world
+    begin, count = shard_range(total, rank, world, align=2)
+    for want in [c for c in args.c5_collectives.split(",") if c]:
+        e5 = mc.PathEngine(device, stream=stream)
+        try:
+            got = install_collective(e5, mc, want, dist, torch, rank, world)
+            info = e5.comm_info()
+
+            def one_pass():
+                P = e5.rbergomi(SEED, RB["S0"], RB["r"], RB["xi"], RB["H"], RB["eta"], RB["rho"], DT, steps, count, path_begin=begin)
+                r = e5.price_lsm(P, RB["r"], 100.0, steps * DT, DT, False, 2)
+                P.free()
+                return r
+
+            one_pass()
+            e5.synchronize()
+            torch.cuda.synchronize()
+            dist.barrier()
+            e5.timing_enable(True)
+            e5.timing_reset()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                price, se = one_pass()
+            e5.synchronize()
+            torch.cuda.synchronize()
+            mine = (time.perf_counter() - t0) / reps * 1e3
+            dist.barrier()
+            t = torch.tensor([mine, -mine], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ms_max, ms_min = float(t[0].item()), -float(t[1].item())
+            gen_ms, _ = e5.timing_get(N.K_RBERGOMI)
+            sw_ms, sw_n = e5.timing_get(N.K_LSM_SWEEP)
+            seen = torch.tensor([info["seen_ranks"]], device="cuda")
+            dist.all_reduce(seen, op=dist.ReduceOp.MIN)
+            rows.append({
+                "config": f"C5: rBergomi American put LSM order 2, {args.c5_paths} paths x {steps} steps per GPU, {world} rank(s) "
+                          f"= {total} paths of one Philox stream",
+                "collective_requested": want, "collective": got, "comm": dict(info, seen_ranks_min_over_ranks=int(seen.item())),
+                "paths_per_gpu": args.c5_paths, "global_paths": total,
+                "ms_per_pass_slowest_rank": ms_max, "ms_per_pass_fastest_rank": ms_min,
+                "Mpaths_per_s": total / ms_max / 1e3, "price": price, "std_err": se,
+                "rank0_generator_ms_per_pass": gen_ms / reps, "rank0_lsm_sweep_ms_per_pass": sw_ms / reps,
+                "rank0_lsm_sweep_launches_per_pass": sw_n // reps, "lsm_one_launch": e5.lsm_one_launch_enabled() and sw_n // reps <= 2})
+        except Exception as ex:   # a row that fails is reported, the others still run
+            rows.append({"config": "C5", "collective_requested": want, "error": str(ex)})
+        finally:
+            e5.close()
+    return rows
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -243,8 +412,11 @@ def main() -> None:
     ap.add_argument("--time-steps", type=int, default=252)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the C3/C4/C5-shard timings after the headline loop")
-    ap.add_argument("--collective", default=os.environ.get("MCG_COLLECTIVE", "auto"), choices=["auto", "shm", "rccl", "torch"],
-                    help="auto: shm (node-local shared memory; the LSM sweeps exchange inside the kernel) for c5, rccl for c2")
+    ap.add_argument("--collective", default=os.environ.get("MCG_COLLECTIVE", "auto"), choices=["auto", "shm", "ipc", "rccl", "torch"],
+                    help="auto: shm (node-local shared memory; the LSM sweeps exchange inside the kernel) for c5, rccl for c2; "
+                         "ipc: shm with the in-kernel mailbox in peer-mapped device memory")
+    ap.add_argument("--c5-paths", type=int, default=8_000_000, help="paths per GPU of the C5 rows under extra.configs at N > 1")
+    ap.add_argument("--c5-collectives", default="shm,ipc,rccl", help="collectives the C5 rows at N > 1 are timed through")
     ap.add_argument("--backend", default=os.environ.get("MCG_DIST_BACKEND", "nccl"), choices=["nccl", "gloo"],
                     help="torch.distributed backend; gloo lets several ranks share one GPU (rehearsal only)")
     args = ap.parse_args()
@@ -277,10 +449,12 @@ def main() -> None:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29577")
+        from datetime import timedelta
+        limit = timedelta(seconds=300)   # a rank that dies must not leave the others waiting for half an hour
         if args.backend == "nccl":
-            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device), timeout=limit)
         else:
-            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world, timeout=limit)
 
     S0, K, r, sigma, dt = 100.0, 100.0, 0.04, 0.2, DT
     n_steps, seed = args.time_steps, SEED
@@ -295,37 +469,7 @@ def main() -> None:
         collective = args.collective
         if collective == "auto":
             collective = "shm" if args.config == "c5" else "rccl"
-        if collective == "shm":
-            box = [f"/mcg_bench_{os.getpid()}_{int(time.time())}" if rank == 0 else None]
-            dist.broadcast_object_list(box, src=0)
-            try:
-                eng.init_shm(box[0], rank, world)
-            except mc.McgError as e:
-                print(f"bench: shared-memory communicator unavailable ({e}); using RCCL", file=sys.stderr)
-                collective = "rccl (shm init failed)"
-            ok = torch.tensor([1 if collective == "shm" else 0], device="cuda")
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if int(ok.item()) == 0 and collective == "shm":
-                collective = "rccl (shm init failed on a peer)"
-            if collective != "shm":
-                eng.set_allreduce(None)
-        if collective.startswith("rccl"):
-            def bcast(uid):
-                box = [uid]
-                dist.broadcast_object_list(box, src=0)
-                return box[0]
-            try:
-                eng.init_rccl(rank, world, bcast)
-            except mc.McgError as e:           # communicator set-up failed on this node: use torch's, and say so
-                print(f"bench: built-in RCCL communicator unavailable ({e}); using torch.distributed", file=sys.stderr)
-                collective = "torch (built-in RCCL init failed)"
-            ok = torch.tensor([0 if collective.startswith("torch") else 1], device="cuda")
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)    # all ranks take the same route
-            if int(ok.item()) == 0:
-                collective = collective if collective.startswith("torch") else "torch (built-in RCCL init failed on a peer)"
-                eng.use_torch_distributed()
-        elif collective == "torch":
-            eng.use_torch_distributed()
+        collective = install_collective(eng, mc, collective, dist, torch, rank, world)
 
     if args.config == "c2":
         k_main = N.K_GBM
@@ -376,6 +520,13 @@ def main() -> None:
         eng.synchronize()
         torch.cuda.synchronize()
 
+    # the very first launch of the measured kernel in this process, on a device that has been idle: reported, not timed
+    eng.timing_enable(True)
+    eng.timing_reset()
+    ramp_launch()
+    eng.synchronize()
+    cold_ms = eng.timing_get(k_main)[0]
+    eng.timing_enable(False)
     run_ramp()  # also ahead of the W warm-up steps: every launch of the measured kernel variant runs at the steady clock,
     #             so the rocprofv3 average over all of them agrees with the average over the K timed ones
     for _ in range(args.warmup):
@@ -480,9 +631,19 @@ def main() -> None:
         if world == 1 and dist is None and args.config == "c2" and not args.no_extra:
             try:
                 out["parity"]["rough_regime_vs_reference_sample"] = rough_regime_parity(eng)
-                out["extra"] = {"configs": extra_configs(eng, N)}
+                out["extra"] = {"configs": extra_configs(eng, N) + widening_configs(eng, N)}
+                out["extra"]["c2_cold_first_launch_ms"] = cold_ms
             except Exception as e:
                 out["extra"] = {"configs": [], "error": str(e)}
+    # BASELINE.json configs[4] at this N, through every collective in turn (all ranks take part; rank 0 reports)
+    c5_rows = None
+    if dist is not None and args.config == "c2" and not args.no_extra:
+        eng.trim()
+        c5_rows = c5_sharded_rows(args, mc, N, dist, torch, device, stream, rank, world)
+    if rank == 0:
+        if c5_rows is not None:
+            out.setdefault("extra", {})["configs"] = c5_rows
+        out["config"]["comm"] = eng.comm_info()
         print(json.dumps(out), file=json_out, flush=True)
     eng.timing_enable(False)
     eng.close()

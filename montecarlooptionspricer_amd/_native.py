@@ -70,11 +70,23 @@ def load_library():
     L.mcg_comm_unique_id.argtypes = [C.c_char_p]
     L.mcg_comm_init_rank.argtypes = [vp, C.c_char_p, C.c_int, C.c_int]
     L.mcg_comm_init_shm.argtypes = [vp, C.c_char_p, C.c_int, C.c_int]
-    L.mcg_comm_shm_peer_mailbox.argtypes = [vp, C.c_int, C.POINTER(C.c_int)]
-    L.mcg_debug_shm_attach.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_double, C.POINTER(vp)]
-    L.mcg_debug_shm_barrier.argtypes = [vp]
-    L.mcg_debug_shm_poison.argtypes = [vp]
-    L.mcg_debug_shm_detach.argtypes = [vp]
+
+    def newer(name, argtypes):
+        """Entry points added after round 2: an older build loaded through MCG_LIB for an A/B run lacks them."""
+        try:
+            getattr(L, name).argtypes = argtypes
+        except AttributeError:
+            if not os.environ.get("MCG_LIB"):
+                raise
+
+    newer("mcg_comm_shm_peer_mailbox", [vp, C.c_int, C.POINTER(C.c_int)])
+    newer("mcg_debug_shm_attach", [C.c_char_p, C.c_int, C.c_int, C.c_double, C.POINTER(vp)])
+    newer("mcg_debug_shm_barrier", [vp])
+    newer("mcg_debug_shm_poison", [vp])
+    newer("mcg_debug_shm_detach", [vp])
+    newer("mcg_lsm_one_launch_reset", [vp])
+    newer("mcg_debug_lsm_hooks", [vp, C.c_longlong, C.c_int])
+    newer("mcg_comm_info", [vp] + [C.POINTER(C.c_int)] * 4)
     L.mcg_paths_gbm.argtypes = [vp, C.c_uint64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int,
                                 C.c_uint64, C.c_int64, C.POINTER(vp)]
     L.mcg_paths_gbm_payoff.argtypes = [vp, C.c_uint64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int,
@@ -91,9 +103,6 @@ def load_library():
     L.mcg_price_european.argtypes = [vp, vp, C.c_double, C.c_double, C.c_double, C.c_int, dp, dp]
     L.mcg_price_lsm.argtypes = [vp, vp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, dp, dp]
     L.mcg_lsm_one_launch_enabled.argtypes = [vp, C.POINTER(C.c_int)]
-    L.mcg_lsm_one_launch_reset.argtypes = [vp]
-    L.mcg_debug_lsm_hooks.argtypes = [vp, C.c_longlong, C.c_int]
-    L.mcg_comm_info.argtypes = [vp] + [C.POINTER(C.c_int)] * 4
     L.mcg_price_asymptotic.argtypes = [vp, vp] + [C.c_double] * 4 + [C.c_int, C.c_double, C.c_double, dp]
     L.mcg_compat_asymptotic_price.argtypes = [dp, C.c_int64, C.c_int] + [C.c_double] * 4 + [C.c_int, C.c_double, C.c_double, dp]
     L.mcg_price_martingale.argtypes = [vp, vp] + [C.c_double] * 4 + [C.c_int, C.c_int, C.c_int, dp, dp, dp]

@@ -101,9 +101,17 @@ __device__ __forceinline__ bool lsm_date_tail(const LsmDateArgs& a, bool have, d
 }
 
 // NB = poly_order + 1 basis functions; NM = (2p+1) power sums + (p+1) cross sums = 3*NB - 1.
+// The grid is one resident wave of workgroups (run_lsm sizes it by the occupancy query).  A thread works on UNITS of two
+// adjacent paths (16-byte loads and stores; rows and V are 16-byte aligned, the path count is padded to a unit) and walks
+// its grid-stride units through a ring of LSM_DATE_DEPTH register slots: the loads of the next DEPTH units are always in
+// flight, and the first DEPTH are issued BEFORE the head's solve, so HBM stays busy while thread 0 of every workgroup
+// solves (a quarter of the launch's bytes are on their way by the time the coefficients exist).
+constexpr int LSM_DATE_DEPTH = 3;
+
 template <int NB>
 __global__ __launch_bounds__(256) void k_lsm_date(LsmDateArgs a) {
     constexpr int NM = 3 * NB - 1;
+    constexpr int D = LSM_DATE_DEPTH;
     __shared__ double red[NM * 4];
     __shared__ double sm_mom[32];
     __shared__ double sm_coef[16];
@@ -113,16 +121,38 @@ __global__ __launch_bounds__(256) void k_lsm_date(LsmDateArgs a) {
     if (j < 0) return;  // the sweep is over: a spare launch
     const int phase = (int)a.state[LSM_ST_PHASE];
     const bool call = a.is_call != 0;
-    const bool reg = phase != LSM_PH_INIT && !(j * a.dt > a.maturity);  // LSMPricer.cpp:43-44
-    const double* S_j = a.data + (int64_t)j * a.ld;
+    const bool reg = phase != LSM_PH_INIT && !(j * a.dt > a.maturity);          // LSMPricer.cpp:43-44
+    const bool have = j >= 1 && !((j - 1) * a.dt > a.maturity);                 // date j-1 regresses: its inputs are formed here (:51-74)
+    const bool need_v = phase != LSM_PH_INIT;
+    const double2* S_j = reinterpret_cast<const double2*>(a.data + (int64_t)j * a.ld);
+    const double2* S_mom = reinterpret_cast<const double2*>(a.data + (int64_t)(have ? j - 1 : j) * a.ld);
+    double2* V2 = reinterpret_cast<double2*>(a.V);
+    const int64_t n_units = (a.n + 1) / 2;
+    const int64_t chunk = (int64_t)gridDim.x * 256;
+    const int64_t n_chunks = (n_units + chunk - 1) / chunk;
+    const bool rev = (j & 1) != 0;  // consecutive dates walk the paths in opposite directions (see run_lsm)
+    const int64_t lane_unit = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    auto unit_of = [&](int64_t k) { return k < n_chunks ? (rev ? n_chunks - 1 - k : k) * chunk + lane_unit : n_units; };
+    int64_t u[D];
+    double2 s[D], v[D], sm[D];
+    auto fetch = [&](int d, int64_t k, bool with_mom) {
+        u[d] = unit_of(k);
+        s[d] = make_double2(0.0, 0.0);
+        v[d] = make_double2(0.0, 0.0);
+        sm[d] = make_double2(0.0, 0.0);
+        if (u[d] < n_units) {
+            s[d] = S_j[u[d]];
+            if (need_v) v[d] = V2[u[d]];
+            if (with_mom) sm[d] = S_mom[u[d]];
+        }
+    };
+#pragma unroll
+    for (int d = 0; d < D; ++d) fetch(d, d, have);  // (row j-1 is not needed by a refinement launch: wasted loads on those rare ones)
     double c[NB];
     double n_itm = 0.0, center = 0.0;
     double m[NM];
 #pragma unroll
     for (int q = 0; q < NM; ++q) m[q] = 0.0;
-    const int64_t chunk = (int64_t)gridDim.x * 256;
-    const int64_t n_chunks = (a.n + chunk - 1) / chunk;
-    const bool rev = (j & 1) != 0;  // consecutive dates walk the paths in opposite directions (see run_lsm)
     if (reg) {
         if (threadIdx.x == 0) {
 #pragma unroll
@@ -134,11 +164,16 @@ __global__ __launch_bounds__(256) void k_lsm_date(LsmDateArgs a) {
         if (phase == LSM_PH_REGULAR && sm_coef[LSM_C_REFINE] != 0.0) {  // (uniform over the grid and over the ranks)
             // The date is re-fitted about the mean of its regressor: this launch only forms those moments.
             const double mu = sm_coef[LSM_C_HINT];
-            for (int64_t k = 0; k < n_chunks; ++k) {
-                const int64_t i = (rev ? n_chunks - 1 - k : k) * chunk + (int64_t)blockIdx.x * 256 + threadIdx.x;
-                if (i >= a.n) continue;
-                const double s = S_j[i];
-                lsm_accumulate_centered<NB>(m, payoff_of(call, s, a.K) > 1e-14, s, a.V[i], a.invK, mu, a.disc);
+            for (int64_t k0 = 0; k0 < n_chunks; k0 += D) {
+#pragma unroll
+                for (int d = 0; d < D; ++d) {
+                    if (u[d] < n_units) {
+                        lsm_accumulate_centered<NB>(m, payoff_of(call, s[d].x, a.K) > 1e-14, s[d].x, v[d].x, a.invK, mu, a.disc);
+                        lsm_accumulate_centered<NB>(m, 2 * u[d] + 1 < a.n && payoff_of(call, s[d].y, a.K) > 1e-14, s[d].y, v[d].y,
+                                                    a.invK, mu, a.disc);
+                    }
+                    fetch(d, k0 + d + D, false);
+                }
             }
             if (lsm_date_tail<NM>(a, true, m, red, &sm_last) && threadIdx.x == 0) {
                 a.state[LSM_ST_PHASE] = (double)LSM_PH_REFINED;
@@ -151,42 +186,42 @@ __global__ __launch_bounds__(256) void k_lsm_date(LsmDateArgs a) {
         n_itm = sm_coef[LSM_C_COUNT];
         center = sm_coef[LSM_C_CENTER];
     }
-    const bool have = j >= 1 && !((j - 1) * a.dt > a.maturity);  // date j-1 regresses: its inputs are formed here (:51-74)
-    const double* S_mom = a.data + (int64_t)(have ? j - 1 : j) * a.ld;
-    for (int64_t k = 0; k < n_chunks; ++k) {
-        const int64_t i = (rev ? n_chunks - 1 - k : k) * chunk + (int64_t)blockIdx.x * 256 + threadIdx.x;
-        if (i >= a.n) continue;
-        double v;
-        if (phase == LSM_PH_INIT) {
-            v = payoff_of(call, S_j[i], a.K);  // LSMPricer.cpp:37-40
-        } else if (!reg) {
-            v = a.V[i] * a.disc;  // :43-49
-        } else {
-            const double s = S_j[i];
-            const double pay = payoff_of(call, s, a.K);
-            const double vn = a.V[i] * a.disc;
-            if (pay > 1e-14 && n_itm > 0.0) {  // :78-86
-                v = fmax(pay, lsm_continuation<NB>(c, center, fma(s, a.invK, -1.0)));
-            } else if (pay < 1e-14) {  // :89-94
-                v = vn;
-            } else {
-                v = 0.0;  // payoff == 1e-14 exactly falls through both branches (:55 vs :91)
+    auto update = [&](double s_now, double v_old) {
+        if (phase == LSM_PH_INIT) return payoff_of(call, s_now, a.K);  // LSMPricer.cpp:37-40
+        if (!reg) return v_old * a.disc;                                // :43-49
+        const double pay = payoff_of(call, s_now, a.K);
+        if (pay > 1e-14 && n_itm > 0.0)                                 // :78-86
+            return fmax(pay, lsm_continuation<NB>(c, center, fma(s_now, a.invK, -1.0)));
+        if (pay < 1e-14) return v_old * a.disc;                         // :89-94
+        return 0.0;  // payoff == 1e-14 exactly falls through both branches (:55 vs :91)
+    };
+    auto accumulate = [&](bool live, double s_prev, double v_new) {  // regression inputs of date j-1
+        if (live && payoff_of(call, s_prev, a.K) > 1e-14) {
+            const double x = fma(s_prev, a.invK, -1.0);
+            const double y = v_new * a.disc;
+            double pw = 1.0;
+#pragma unroll
+            for (int q = 0; q < 2 * NB - 1; ++q) {
+                m[q] += pw;
+                if (q < NB) m[2 * NB - 1 + q] = fma(pw, y, m[2 * NB - 1 + q]);
+                pw *= x;
             }
         }
-        a.V[i] = v;
-        if (have) {
-            const double s = S_mom[i];
-            if (payoff_of(call, s, a.K) > 1e-14) {
-                const double x = fma(s, a.invK, -1.0);
-                const double y = v * a.disc;
-                double pw = 1.0;
+    };
+    for (int64_t k0 = 0; k0 < n_chunks; k0 += D) {
 #pragma unroll
-                for (int q = 0; q < 2 * NB - 1; ++q) {
-                    m[q] += pw;
-                    if (q < NB) m[2 * NB - 1 + q] = fma(pw, y, m[2 * NB - 1 + q]);
-                    pw *= x;
+        for (int d = 0; d < D; ++d) {
+            if (u[d] < n_units) {
+                // (the second path of the last unit may lie beyond the shard: computed from whatever the padding holds,
+                // stored into V's slack, never counted)
+                const double2 vn = make_double2(update(s[d].x, v[d].x), update(s[d].y, v[d].y));
+                V2[u[d]] = vn;
+                if (have) {
+                    accumulate(true, sm[d].x, vn.x);
+                    accumulate(2 * u[d] + 1 < a.n, sm[d].y, vn.y);
                 }
             }
+            fetch(d, k0 + d + D, have);
         }
     }
     if (lsm_date_tail<NM>(a, have, m, red, &sm_last) && threadIdx.x == 0) {
@@ -1276,6 +1311,32 @@ int lsm_reduce_allreduce_solve(mcg_ctx* ctx, int grid, int nm, int nb, double mi
     return MCG_OK;
 }
 
+// Workgroups of k_lsm_date<nb> a CU holds at once: the per-date route launches exactly one resident wave of them.
+static int date_kernel_occupancy(int nb) {
+    static std::atomic<int> cache[10];
+    int occ = cache[nb].load(std::memory_order_relaxed);
+    if (occ > 0) return occ;
+    const void* fn = nullptr;
+    switch (nb) {
+        case 1: fn = (const void*)k_lsm_date<1>; break;
+        case 2: fn = (const void*)k_lsm_date<2>; break;
+        case 3: fn = (const void*)k_lsm_date<3>; break;
+        case 4: fn = (const void*)k_lsm_date<4>; break;
+        case 5: fn = (const void*)k_lsm_date<5>; break;
+        case 6: fn = (const void*)k_lsm_date<6>; break;
+        case 7: fn = (const void*)k_lsm_date<7>; break;
+        case 8: fn = (const void*)k_lsm_date<8>; break;
+        default: fn = (const void*)k_lsm_date<9>; break;
+    }
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, 256, 0) != hipSuccess || occ < 1) {
+        (void)hipGetLastError();
+        occ = 2;
+    }
+    occ = std::min(occ, 8);
+    cache[nb].store(occ, std::memory_order_relaxed);
+    return occ;
+}
+
 template <int NB>
 static void launch_date_nb(mcg_ctx* ctx, int grid, const LsmDateArgs& a) {
     hipLaunchKernelGGL(k_lsm_date<NB>, dim3(grid), dim3(256), 0, ctx->stream, a);
@@ -1302,7 +1363,7 @@ int run_lsm(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double maturit
     const int nm = 3 * nb - 1;
     const int64_t N = P->n_paths;
     const int M = P->n_steps + 1;
-    int grid = (int)std::min<int64_t>((N + 255) / 256, (int64_t)ctx->n_cus * 8);
+    int grid = (int)std::min<int64_t>((N + 511) / 512, (int64_t)ctx->n_cus * date_kernel_occupancy(nb));  // 512 paths per workgroup and trip
     if (grid < 1) grid = 1;
 
     if (N >= 1 && N <= 1024 && !ctx->allreduce) {  // one launch for the whole sweep
@@ -1349,7 +1410,7 @@ int run_lsm(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double maturit
             return MCG_OK;
         }
     }
-    rc = ensure_cap(ctx, &ctx->lsm_v, &ctx->lsm_v_cap, (size_t)std::max<int64_t>(N, 1));
+    rc = ensure_cap(ctx, &ctx->lsm_v, &ctx->lsm_v_cap, (size_t)std::max<int64_t>(N, 1) + 1);  // (a whole two-path unit at the end)
     if (rc) return rc;
     rc = ensure_cap(ctx, &ctx->partials, &ctx->partials_cap, (size_t)grid * (size_t)std::max(nm, 2));
     if (rc) return rc;

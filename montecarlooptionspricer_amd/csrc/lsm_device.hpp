@@ -29,70 +29,12 @@ __host__ __device__ constexpr int lsm_ws_doubles(int nb) { return 7 * nb * nb + 
 //     of that spread -- exceeds Eigen's threshold by four orders of magnitude, so Eigen sees full rank as well.
 // Otherwise (few or nearly coincident in-the-money prices, all paths equal at j = 0, high orders whose raw monomials
 // Eigen itself truncates) the date is REFINED: coef[LSM_C_REFINE] = 1 asks the caller to re-accumulate the moments
-// about the mean coef[LSM_C_HINT] and to call lsm_solve_centered, which reproduces Eigen's truncated solve.  The
-// coefficients written here are then the fall-back for callers that cannot refine (sharded runs: a second,
-// data-dependent all-reduce per date cannot be scheduled from the host): cyclic Jacobi eigen-decomposition and a
-// pseudo-inverse with relative eigenvalue cut 1e-12, the projection on the numerical range of the scaled basis.
-// K <= 0 switches the refinement request off.
+// about the mean coef[LSM_C_HINT] and to call lsm_solve_centered, which reproduces Eigen's truncated solve; every
+// caller does (the per-date kernels by spending a second launch on the date).  The coefficients written here are
+// then provisional (the LDL^T solution when it exists, else zeros).
+// K <= 0 switches the refinement request off (no in-the-money path can exist for a put then; a call degenerates).
 // NB is a template parameter so that every loop unrolls and G, Q live in registers: with a run-time size the
 // arrays go to scratch memory and the (serial, one-thread) solve takes ~20 us instead of ~2.
-// Fallback of lsm_solve_nb for a date whose equilibrated Gram matrix has no LDL^T factorisation (a pivot <= 1e-10:
-// fewer distinct in-the-money prices than basis functions): cyclic Jacobi, pseudo-inverse with relative eigenvalue cut
-// 1e-12.  buf = G[nb][nb] (equilibrated) | rhs[nb] (scaled) | d[nb] (the scaling); run-time nb, matrices in memory.  A
-// rare path -- and with refinement on (K > 0) its result is replaced by lsm_solve_centered's anyway -- kept out of line
-// so that its arrays do not count against the registers of the kernels that inline the fast path.
-__device__ __noinline__ void lsm_solve_jacobi(int nb, double* buf, double* coef) {
-    double* G = buf;
-    const double* rhs = buf + nb * nb;
-    const double* d = rhs + nb;
-    double Q[9 * 9], sol[9];
-    for (int a = 0; a < nb; ++a)
-        for (int b = 0; b < nb; ++b) Q[a * nb + b] = a == b ? 1.0 : 0.0;
-    for (int sweep = 0; sweep < 50; ++sweep) {
-        double off = 0.0;
-        for (int p = 0; p < nb; ++p)
-            for (int q = p + 1; q < nb; ++q) off += G[p * nb + q] * G[p * nb + q];
-        if (off < 1e-60) break;
-        for (int p = 0; p < nb - 1; ++p) {
-            for (int q = p + 1; q < nb; ++q) {
-                const double apq = G[p * nb + q];
-                if (apq == 0.0) continue;
-                const double theta = (G[q * nb + q] - G[p * nb + p]) / (2.0 * apq);
-                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                const double cs = 1.0 / sqrt(t * t + 1.0), sn = t * cs;
-                for (int k = 0; k < nb; ++k) {
-                    const double gkp = G[k * nb + p], gkq = G[k * nb + q];
-                    G[k * nb + p] = cs * gkp - sn * gkq;
-                    G[k * nb + q] = sn * gkp + cs * gkq;
-                }
-                for (int k = 0; k < nb; ++k) {
-                    const double gpk = G[p * nb + k], gqk = G[q * nb + k];
-                    G[p * nb + k] = cs * gpk - sn * gqk;
-                    G[q * nb + k] = sn * gpk + cs * gqk;
-                }
-                for (int k = 0; k < nb; ++k) {
-                    const double qkp = Q[k * nb + p], qkq = Q[k * nb + q];
-                    Q[k * nb + p] = cs * qkp - sn * qkq;
-                    Q[k * nb + q] = sn * qkp + cs * qkq;
-                }
-            }
-        }
-    }
-    double lmax = 0.0;
-    for (int a = 0; a < nb; ++a) lmax = fmax(lmax, G[a * nb + a]);
-    const double cut = lmax * 1e-12;
-    for (int a = 0; a < nb; ++a) sol[a] = 0.0;
-    for (int e = 0; e < nb; ++e) {
-        const double lam = G[e * nb + e];
-        if (!(lam > cut)) continue;
-        double proj = 0.0;
-        for (int a = 0; a < nb; ++a) proj += Q[a * nb + e] * rhs[a];
-        const double w = proj / lam;
-        for (int a = 0; a < nb; ++a) sol[a] += w * Q[a * nb + e];
-    }
-    for (int a = 0; a < nb; ++a) coef[a] = sol[a] * d[a];
-}
-
 // 1/x and x^(-1/2) for positive normal x from the hardware seeds (v_rcp_f64, v_rsq_f64) and two Newton steps (one
 // second-order step), <= 1 ulp: the solve runs on ONE thread between two grid-wide hand-shakes of the one-launch
 // sweeps, where the ~35 dependent instructions of a correctly rounded fp64 division (a dozen of them per date) were a
@@ -193,14 +135,11 @@ __device__ __forceinline__ void lsm_solve_nb(const double* moments, double min_c
         for (int a = 0; a < nb; ++a) coef[a] = sol[a] * d[a];
         return;
     }
-    // ---- rank-deficient / ill-conditioned date: Jacobi pseudo-inverse, out of line (lsm_solve_jacobi) ----
-    double buf[NB * NB + 2 * NB];
-    for (int a = 0; a < nb; ++a) {
-        for (int b = 0; b < nb; ++b) buf[a * nb + b] = G[a][b];
-        buf[nb * nb + a] = rhs[a];
-        buf[nb * nb + nb + a] = d[a];
-    }
-    lsm_solve_jacobi(nb, buf, coef);
+    // ---- no LDL^T factorisation (fewer distinct in-the-money prices than basis functions): the coefficients stay 0 and
+    // the refinement request above (always set here: !ok implies !trusted) has the caller re-fit the date with
+    // lsm_solve_centered, which handles rank deficiency by the reference's own rule.  (Until round 3 a Jacobi
+    // pseudo-inverse stood here as a fall-back for callers that could not refine; every caller refines now, and its
+    // 720 bytes of private arrays were the scratch memory of every kernel that inlines this solve.)
 }
 
 // The refined solve: Eigen's bdcSvd().solve(b) on the raw monomials (LSMPricer.cpp:76), reproduced from the moments

@@ -1,7 +1,7 @@
 """One rank of a sharded pricing job on the PRODUCT path (libmcgpu through the C ABI): started as a fresh child
 process by tests/test_gpu_multirank.py, once per rank, all ranks on GPU 0.
 
-    python tests/mp_rank_worker.py <rank> <world> <port> <out.json> [gloo|shm|shm_timeout]
+    python tests/mp_rank_worker.py <rank> <world> <port> <out.json> [gloo|shm|shm_timeout|ipc]
 
 gloo (two ranks cannot share one device under RCCL): the callback installed with mcg_set_allreduce copies the handful
 of doubles to the host, all-reduces there and copies back, stream-ordered on the ctx's stream (= torch's current
@@ -10,6 +10,8 @@ csrc/kernels_lsm.hip -- is exactly what an N-GPU run executes.
 shm: the library's node-local shared-memory communicator (mcg_comm_init_shm; no torch.distributed at all): host
 all-reduce of the sums, and the LSM sweeps run as ONE launch per rank whose reducing workgroups exchange the per-date
 moments through the device-mapped mailbox -- here with both ranks' persistent kernels resident on the same GPU.
+ipc: the same with the mailbox in device memory, each rank's copy mapped into the peers by HIP IPC
+(mcg_comm_shm_peer_mailbox): a rank pushes its moments into every copy and polls its own.
 """
 import json
 import os
@@ -55,7 +57,7 @@ def main() -> None:
         eng = mc.PathEngine(0)
         if mode == "shm_timeout":       # every hand-shake gives up at once: the ranks must agree to fall back together
             eng.debug_lsm_hooks(spin_limit=0)
-        eng.init_shm(f"/mcg_test_{port}", rank, world)
+        peer = eng.init_shm(f"/mcg_test_{port}", rank, world, peer_mailbox=(mode == "ipc"))
     eng.timing_enable(True)
     res = {}
 
@@ -82,6 +84,8 @@ def main() -> None:
     P.free()
 
     res["allreduce_calls"] = {"3": calls.count(3), "8": calls.count(8)}
+    res["comm"] = eng.comm_info()
+    res["peer_mailbox"] = bool(peer) if mode != "gloo" else False
     res["shard"] = [b, c]
     eng.close()
     with open(f"{out_path}.{rank}", "w") as f:

@@ -52,7 +52,15 @@ def test_c5_shard_full_size():
     a.close()
     assert eu2 == eu and ese2 == ese
     assert abs(am2 - am) <= 1e-9 * am and abs(ase2 - ase) <= 1e-9 * ase
-    assert calls.count(8) == steps and calls.count(3) == 2   # 3p+2 moments on each of the 252 dates; payoff + final sums
+    # 3p+2 moments between two launches of the per-date kernel (one per date + the spare ones); payoff + final sums
+    assert calls.count(8) == per_date_launches(steps) - 1 and calls.count(3) == 2
+
+
+def per_date_launches(steps):
+    """k_lsm_date launches the host queues for a sweep of `steps` + 1 columns when no date asks for a re-fit: one per
+    column plus a few spare ones that return at once (kernels_lsm.hip: run_lsm)."""
+    m = steps + 1
+    return m + 4 + m // 32
 
 
 def _free_port():
@@ -61,20 +69,8 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("mode", ["gloo", "shm", "shm_timeout", "shm4"])
-def test_two_rank_processes_equal_single_rank(tmp_path, mode):
-    """mode "gloo": a host all-reduce callback, the per-date LSM kernels (what RCCL runs use).  mode "shm": the
-    library's node-local shared-memory communicator -- each rank's LSM sweep is ONE launch, and the two persistent
-    kernels exchange their per-date moments through the device-mapped mailbox while both are resident on the GPU.
-    mode "shm_timeout": the same with every hand-shake forced to give up: the ranks agree (sum of their time-out flags)
-    to discard the sweep and answer from the per-date kernels over the segment's host all-reduce.  mode "shm4": FOUR ranks
-    on the one GPU through the shared-memory communicator (four mailbox rows per round, four persistent grids resident
-    together), unequal shards."""
-    sys.path.insert(0, HERE)
-    from mp_rank_worker import JOBS
-
-    world, port, out = (4 if mode == "shm4" else 2), _free_port(), str(tmp_path / "res.json")
-    worker_mode = "shm" if mode == "shm4" else mode
+def _run_ranks(tmp_path, world, worker_mode, tag="res"):
+    port, out = _free_port(), str(tmp_path / f"{tag}.json")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "mp_rank_worker.py"), str(r), str(world), str(port), out, worker_mode],
                               env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
@@ -88,7 +84,25 @@ def test_two_rank_processes_equal_single_rank(tmp_path, mode):
             raise
         logs.append(o)
     assert all(p.returncode == 0 for p in procs), "\n".join(logs)
-    ranks = [json.load(open(f"{out}.{r}")) for r in range(world)]
+    return [json.load(open(f"{out}.{r}")) for r in range(world)], logs
+
+
+@pytest.mark.parametrize("mode", ["gloo", "shm", "shm_timeout", "shm4", "ipc", "ipc4"])
+def test_two_rank_processes_equal_single_rank(tmp_path, mode):
+    """mode "gloo": a host all-reduce callback, the per-date LSM kernels (what RCCL runs use).  mode "shm": the
+    library's node-local shared-memory communicator -- each rank's LSM sweep is ONE launch, and the two persistent
+    kernels exchange their per-date moments through the device-mapped mailbox while both are resident on the GPU.
+    mode "shm_timeout": the same with every hand-shake forced to give up: the ranks agree (sum of their time-out flags)
+    to discard the sweep and answer from the per-date kernels over the segment's host all-reduce.  mode "shm4": FOUR ranks
+    on the one GPU through the shared-memory communicator (four mailbox rows per round, four persistent grids resident
+    together), unequal shards.  modes "ipc" / "ipc4": the mailbox in device memory, every rank's copy mapped into the
+    peers by HIP IPC (on this one-GPU box the peers' copies are the same HBM; on a node they are reached over xGMI)."""
+    sys.path.insert(0, HERE)
+    from mp_rank_worker import JOBS
+
+    world = 4 if mode in ("shm4", "ipc4") else 2
+    worker_mode = {"shm4": "shm", "ipc4": "ipc"}.get(mode, mode)
+    ranks, logs = _run_ranks(tmp_path, world, worker_mode)
 
     e = mc.PathEngine(0)
     P = e.gbm(SEED, 100.0, 0.04, 0.2, DT, 252, JOBS["euro_paths"], payoff=(100.0, True))
@@ -110,14 +124,83 @@ def test_two_rank_processes_equal_single_rank(tmp_path, mode):
             assert abs(got[0] - want[0]) <= tol * abs(want[0]), (r, got, want)
             assert abs(got[1] - want[1]) <= max(tol, 1e-9) * abs(want[1]), (r, got, want)
         if mode == "gloo":
-            assert res["allreduce_calls"] == {"3": 4, "8": JOBS["lsm_steps"] + JOBS["rb_steps"]}
-            assert res["gbm_lsm_sweep_launches"] == JOBS["lsm_steps"] + 2          # one per date + terminal + final sums
-        elif mode in ("shm", "shm4"):
+            # one all-reduce BETWEEN two launches of the per-date kernel, nothing else per date
+            assert res["allreduce_calls"] == {"3": 4, "8": per_date_launches(JOBS["lsm_steps"]) + per_date_launches(JOBS["rb_steps"]) - 2}
+            assert res["gbm_lsm_sweep_launches"] == per_date_launches(JOBS["lsm_steps"]) + 1   # + the final sums
+            assert res["comm"]["kind"] == "callback"
+        elif mode in ("shm", "shm4", "ipc", "ipc4"):
             assert res["one_launch_enabled"], "\n".join(logs)                       # no hand-shake ever timed out
             assert res["gbm_lsm_sweep_launches"] == 1 and res["rb_lsm_sweep_launches"] == 1
+            assert res["comm"]["n_ranks"] == world and res["comm"]["seen_ranks"] == world and res["comm"]["rank"] == r
+            if mode.startswith("ipc"):   # every rank exported, opened and pinged: the mailbox is in device memory
+                assert res["peer_mailbox"] and res["comm"]["kind"] == "shm+peer-memory mailbox", "\n".join(logs)
+            else:
+                assert res["comm"]["kind"] == "shm"
         else:   # forced time-out: the void sweep (1 launch) is discarded on BOTH ranks, the per-date kernels answer
             assert not res["one_launch_enabled"]
-            assert res["gbm_lsm_sweep_launches"] == 1 + JOBS["lsm_steps"] + 2
-            assert res["rb_lsm_sweep_launches"] == JOBS["rb_steps"] + 2              # sticky: no second attempt
+            assert res["gbm_lsm_sweep_launches"] == 1 + per_date_launches(JOBS["lsm_steps"]) + 1
+            assert res["rb_lsm_sweep_launches"] == per_date_launches(JOBS["rb_steps"]) + 1   # no second attempt straight away
     assert ranks[0]["shard"][0] == 0 and all(r["shard"][0] % 2 == 0 for r in ranks)
     assert sum(r["shard"][1] for r in ranks) == JOBS["rb_paths"]
+
+
+def test_peer_memory_mailbox_equals_host_mailbox_bit_for_bit(tmp_path):
+    """The same two-rank job once through the host mailbox and once through the peer-memory mailbox: the exchange
+    carries the same doubles and sums them in the same rank order, so every price is the same to the last bit."""
+    host, _ = _run_ranks(tmp_path, 2, "shm", "host")
+    peer, logs = _run_ranks(tmp_path, 2, "ipc", "peer")
+    assert all(p["peer_mailbox"] for p in peer), "\n".join(logs)
+    for a, b in zip(host, peer):
+        for key in ("euro", "gbm_lsm", "rb_lsm", "rb_euro_put"):
+            assert a[key] == b[key], (key, a[key], b[key])
+
+
+def test_bench_two_ranks_carries_c2_and_c5_with_the_ranks_seen(tmp_path):
+    """The driver's N > 1 command, rehearsed with two ranks on GPU 0 (gloo between them: two RCCL ranks cannot share a
+    device): ONE JSON line that carries the C2 headline AND BASELINE.json configs[4] (C5) through the host mailbox, the
+    peer-memory mailbox and the RCCL route (here: its torch fall-back, the same per-date kernels), each row with the
+    slowest and the fastest rank's time, the collective that actually ran and the ranks its communicator has seen -- and
+    every price equal to the single-rank run on the same global path ids."""
+    root = os.path.dirname(HERE)
+    c2_paths, c5_paths = 1_000_000, 300_000
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--backend", "gloo", "--paths", str(c2_paths), "--c5-paths", str(c5_paths)]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-4000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["global_paths"] == 2 * c2_paths
+    assert out["config"]["comm"]["kind"] == "callback"      # C2's collective here: torch.distributed behind mcg_set_allreduce
+    rows = out["extra"]["configs"]
+    assert [r["collective_requested"] for r in rows] == ["shm", "ipc", "rccl"], rows
+    for r in rows:
+        assert "error" not in r, r
+        assert r["global_paths"] == 2 * c5_paths
+        assert r["ms_per_pass_slowest_rank"] >= r["ms_per_pass_fastest_rank"] > 0
+    shm, ipc, rccl = rows
+    assert shm["collective"] == "shm" and shm["comm"]["kind"] == "shm" and shm["comm"]["seen_ranks_min_over_ranks"] == 2
+    assert ipc["collective"] == "ipc" and ipc["comm"]["kind"] == "shm+peer-memory mailbox" and ipc["comm"]["seen_ranks_min_over_ranks"] == 2
+    assert shm["comm"]["n_ranks"] == 2 and ipc["comm"]["n_ranks"] == 2
+    assert shm["lsm_one_launch"] and ipc["lsm_one_launch"]
+    assert shm["rank0_lsm_sweep_launches_per_pass"] == 1 and ipc["rank0_lsm_sweep_launches_per_pass"] == 1
+    # two ranks on one device: the built-in RCCL communicator cannot form, the row says so and runs the same per-date
+    # kernels over torch.distributed -- one launch per exercise date (+ spare + final sums), one all-reduce between two
+    assert rccl["collective"].startswith("torch (built-in RCCL init failed") and rccl["comm"]["kind"] == "callback"
+    assert not rccl["lsm_one_launch"] and rccl["rank0_lsm_sweep_launches_per_pass"] == per_date_launches(252) + 1
+    assert ipc["price"] == shm["price"] and ipc["std_err"] == shm["std_err"]
+
+    e = mc.PathEngine(0)
+    P = e.gbm(SEED, 100.0, 0.04, 0.2, DT, 252, 2 * c2_paths, payoff=(100.0, True))
+    want_c2 = e.price_european(P, 100.0, 0.04, 1.0, True)
+    P.free()
+    P = e.rbergomi(SEED, RB["S0"], RB["r"], RB["xi"], RB["H"], RB["eta"], RB["rho"], DT, 252, 2 * c5_paths)
+    want_c5 = e.price_lsm(P, RB["r"], 100.0, 252 * DT, DT, False, 2)
+    P.free()
+    e.close()
+    assert abs(out["parity"]["price"] - want_c2[0]) <= 1e-12 * want_c2[0] and abs(out["parity"]["std_err"] - want_c2[1]) <= 1e-9 * want_c2[1]
+    for r in rows:
+        assert abs(r["price"] - want_c5[0]) <= 1e-9 * want_c5[0], (r["collective"], r["price"], want_c5)
+        assert abs(r["std_err"] - want_c5[1]) <= 1e-9 * want_c5[1]

@@ -15,6 +15,7 @@ import numpy as np
 import pytest
 
 import montecarlooptionspricer_amd as mc
+from montecarlooptionspricer_amd import _native as N
 from oracle.binding import Oracle, synthetic_history
 
 pytestmark = pytest.mark.gpu
@@ -375,6 +376,28 @@ def test_lsm_one_launch_timeout_falls_back_to_per_date_kernels():
     e.close()
 
 
+@pytest.mark.parametrize("poly", [0, 2])
+def test_lsm_one_launch_coefficient_blocks_survive_late_readers(poly):
+    """The reducing workgroup re-arms the previous date's coefficient block only once ALL moments of the next date are in
+    (behind its barrier), never on the strength of the power sums alone, which workgroups send a round ahead: with every
+    other workgroup arriving ~20 us late at its coefficient poll the sweep still completes in one launch, without a
+    time-out, at the price of the undelayed run.  Orders 0 and 2 are the ones whose first polling wave owns power sums
+    only."""
+    e = mc.PathEngine(0)
+    try:
+        P = e.gbm(SEED, 100.0, 0.04, 0.2, 0.02, 50, 1_000_000)
+        e.timing_enable(True)
+        want = e.price_lsm(P, 0.04, 100.0, 1.0, 0.02, False, poly)
+        e.debug_lsm_hooks(poll_delay=5)
+        e.timing_reset()
+        got = e.price_lsm(P, 0.04, 100.0, 1.0, 0.02, False, poly)
+        assert e.timing_get(N.K_LSM_SWEEP)[1] == 1 and e.lsm_one_launch_enabled()
+        assert got == want
+        P.free()
+    finally:
+        e.close()
+
+
 @pytest.mark.parametrize("n", [300_000, 1_000_000, 3_000_000])
 def test_lsm_one_launch_sweep_repeats_bit_for_bit(n):
     """The one-launch sweeps sum every moment in a fixed order (threads, waves, workgroups), whatever the timing of the
@@ -624,7 +647,8 @@ def test_allreduce_callback_plumbing():
     l2, lse2 = e.price_lsm(P, 0.04, 100.0, 1.0, 0.02, False, 2)
     assert abs(m2 - m1) <= 1e-13 * m1 and abs(se2 * math.sqrt(2.0) - se1) <= 1e-4 * se1
     assert abs(l2 - l1) <= 1e-12 * l1 and abs(lse2 * math.sqrt(2.0) - lse1) <= 1e-4 * lse1
-    assert calls.count(3) == 2 and calls.count(8) == 50       # 3p+2 = 8 moments on each of 50 dates
+    # 3p+2 = 8 moments between two launches of the per-date kernel: 51 columns + 5 spare launches that return at once
+    assert calls.count(3) == 2 and calls.count(8) == 51 + 4 + 51 // 32 - 1
     e.set_allreduce(None)
     m3, _ = e.price_european(P, 100.0, 0.04, 1.0, False)
     assert m3 == m1

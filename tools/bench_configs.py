@@ -78,4 +78,15 @@ for c in args.configs.split(","):
             P.free()
             return r
         run("C5 shard: rBergomi american put LSM 8Mx252", f, n, 8 * 253 + 32 * 252)
+    elif c == "c5pd":   # the same through the per-date route (an identity collective selects it)
+        n = int(8_000_000 * args.scale)
+        eng.set_allreduce(lambda ptr, count, stream: None)
+
+        def f():
+            P = eng.rbergomi(20251031, 100.0, 0.04, RB["xi"], RB["H"], RB["eta"], RB["rho"], DT, 252, n)
+            r = eng.price_lsm(P, 0.04, 100.0, 1.0, DT, False, 2)
+            P.free()
+            return r
+        run("C5pd shard, per-date route: rBergomi american put LSM 8Mx252", f, n, 8 * 253 + 32 * 252)
+        eng.set_allreduce(None)
 eng.close()
