@@ -150,7 +150,7 @@ int mcg_price_european(mcg_ctx* ctx, const mcg_paths* paths, double K, double r,
 
 /* LSM::PredictOptionPrice (src/models/LSMPricer.cpp:19-102) on a device-resident matrix.
  * Returns mean_i V[i][0]; std_err is an addition (the reference returns a bare mean).
- * poly_order in [0, 8]. */
+ * poly_order in [0, 15] (orders above 8 take one launch per exercise date whatever the path count). */
 int mcg_price_lsm(mcg_ctx* ctx, const mcg_paths* paths, double r, double K, double maturity,
                   double dt, int is_call, int poly_order, double* mean, double* std_err);
 
@@ -193,7 +193,7 @@ int mcg_price_branching(mcg_ctx* ctx, const mcg_paths* paths, double r, double K
 typedef struct mcg_row {
     double S0, xi, H, eta, rho;                  /* RoughVolatility.cpp:327-331                          */
     double strike, maturity, sigma, dividend;    /* PredictionGen.cpp:701-709                            */
-    int n_steps;                                 /* floor(maturity*252), :718; <= 1020                   */
+    int n_steps;                                 /* floor(maturity*252), :718                            */
     int is_call;
 } mcg_row;
 
@@ -203,7 +203,8 @@ typedef struct mcg_row {
  * in the driver's column order (asymPrice, branchPrice, lsmPriceVal, martinPrice, :809-814).  Rows the driver
  * would answer with zeros (no steps, degenerate estimates, sigma <= 0, strike <= 0) get zeros.
  * Row i uses Philox path ids (i << 32) + p of `seed`: its prices equal the single-contract entry points
- * called with path_begin = i << 32.  poly_order in [0, 4]. */
+ * called with path_begin = i << 32 -- and a row of more than 1020 steps (four years of trading days) IS priced through
+ * them, after the batch, one row at a time.  poly_order in [0, 4]. */
 int mcg_batch_price_rows(mcg_ctx* ctx, const mcg_row* rows, int64_t n_rows, int n_paths, double r, double dt,
                          int num_branches, int poly_order, int max_iterations, uint64_t seed, double* out);
 

@@ -18,6 +18,10 @@
 
 namespace mcg {
 
+// steps of a row the row kernels serve (their transforms go up to Mz = 1024, their per-row LDS tables with them); longer
+// rows take the single-contract entry points (run_batch_rows)
+constexpr int BATCH_MAX_STEPS = 1020;
+
 struct BatchRow {  // device image of one option row
     double S0, logS0, xi, H, eta, strike, maturity, sigma, dividend;
     int n_steps, M, is_call, valid;
@@ -272,7 +276,7 @@ __global__ __launch_bounds__(256) void k_batch_martingale(BatchArgs a) {
     extern __shared__ double sm[];  // disc[n_cols] with the maturity clamp
     __shared__ double red[(NM + 1) * 4];
     __shared__ double sm_mom[32];
-    __shared__ double sm_coef[16];
+    __shared__ double sm_coef[LSM_COEF_STRIDE];
     __shared__ double sm_off, sm_primal;
     __shared__ double sm_ws[lsm_ws_doubles(NB)];
     const BatchRow row = a.rows[blockIdx.x];
@@ -388,6 +392,7 @@ static void launch_row_regressions(mcg_ctx* ctx, const BatchArgs& a, size_t smem
 int run_batch_rows(mcg_ctx* ctx, const mcg_row* rows, int64_t n_rows, int n_paths, double r, double dt, int num_branches,
                    int poly_order, int max_iterations, uint64_t seed, double* out) {
     std::vector<BatchRow> h((size_t)n_rows);
+    std::vector<int64_t> long_rows;
     int max_steps = 1, m_max = 1;
     for (int64_t i = 0; i < n_rows; ++i) {
         const mcg_row& s = rows[i];
@@ -404,10 +409,16 @@ int run_batch_rows(mcg_ctx* ctx, const mcg_row* rows, int64_t n_rows, int n_path
         d.n_steps = s.n_steps;
         d.is_call = s.is_call;
         // a row the reference's driver would answer with zeros (no steps, non-finite paths, a throwing pricer)
-        d.valid = s.n_steps >= 1 && s.n_steps <= 1020 && s.S0 > 0.0 && std::isfinite(s.S0) && s.xi >= 0.0 &&
+        d.valid = s.n_steps >= 1 && s.S0 > 0.0 && std::isfinite(s.S0) && s.xi >= 0.0 &&
                   std::isfinite(s.xi) && s.H >= 0.0 && std::isfinite(s.H) && std::isfinite(s.eta) &&
                   std::fabs(s.rho) <= 1.0 && s.strike > 0.0 && std::isfinite(s.strike) && s.sigma > 0.0 &&
                   std::isfinite(s.maturity);
+        // A row longer than the row kernels' LDS tables reach (more than four years of trading days) is priced after the
+        // batch through the single-contract entry points, on the same Philox path ids: never answered with zeros.
+        if (d.valid && s.n_steps > BATCH_MAX_STEPS) {
+            long_rows.push_back(i);
+            d.valid = 0;
+        }
         d.M = 1;
         if (d.valid) {
             while (d.M < d.n_steps) d.M <<= 1;
@@ -497,6 +508,26 @@ int run_batch_rows(mcg_ctx* ctx, const mcg_row* rows, int64_t n_rows, int n_path
     // the host vector `h` must outlive the upload: it does (synchronised above)
     release_all();
     if (e != hipSuccess) return fail(MCG_ERR_HIP, "batch run failed: %s", hipGetErrorString(e));
+    for (int64_t i : long_rows) {  // PredictionGen.cpp:718-816 for one row, through the single-contract entry points
+        const mcg_row& s = rows[i];
+        double* o = out + 4 * i;
+        o[0] = o[1] = o[2] = o[3] = 0.0;
+        mcg_paths* P = nullptr;
+        if (mcg_paths_rbergomi(ctx, seed, s.S0, r, s.xi, s.H, s.eta, s.rho, dt, s.n_steps, (uint64_t)i << 32, n_paths, &P) != MCG_OK)
+            continue;  // (the driver logs a failing row and writes zeros, :792-805)
+        std::vector<int> ex((size_t)s.n_steps);
+        for (int t = 0; t < s.n_steps; ++t) ex[(size_t)t] = t;  // :780-783
+        double v = 0.0;
+        if (mcg_price_asymptotic(ctx, P, r, s.strike, s.maturity, dt, s.is_call, s.sigma, s.dividend, &v) == MCG_OK) o[0] = v;
+        if (mcg_price_branching(ctx, P, r, s.strike, s.maturity, dt, s.is_call, num_branches, ex.data(), s.n_steps, seed, &v,
+                                nullptr, nullptr) == MCG_OK)
+            o[1] = v;
+        if (mcg_price_lsm(ctx, P, r, s.strike, s.maturity, dt, s.is_call, poly_order, &v, nullptr) == MCG_OK) o[2] = v;
+        if (mcg_price_martingale(ctx, P, r, s.strike, s.maturity, dt, s.is_call, poly_order, max_iterations, &v, nullptr,
+                                 nullptr) == MCG_OK)
+            o[3] = v;
+        mcg_paths_free(P);
+    }
     return MCG_OK;
 }
 

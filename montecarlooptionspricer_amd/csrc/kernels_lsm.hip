@@ -113,8 +113,8 @@ __global__ __launch_bounds__(256) void k_lsm_date(LsmDateArgs a) {
     constexpr int NM = 3 * NB - 1;
     constexpr int D = LSM_DATE_DEPTH;
     __shared__ double red[NM * 4];
-    __shared__ double sm_mom[32];
-    __shared__ double sm_coef[16];
+    __shared__ double sm_mom[48];
+    __shared__ double sm_coef[LSM_COEF_STRIDE];
     __shared__ double sm_ws[lsm_ws_doubles(NB)];
     __shared__ unsigned sm_last;
     const int j = (int)a.state[LSM_ST_J];
@@ -157,8 +157,20 @@ __global__ __launch_bounds__(256) void k_lsm_date(LsmDateArgs a) {
         if (threadIdx.x == 0) {
 #pragma unroll
             for (int t = 0; t < NM; ++t) sm_mom[t] = a.msg[t];
-            if (phase == LSM_PH_REFINED) lsm_solve_centered(sm_mom, NB, a.state[LSM_ST_MU], a.K, sm_coef, sm_ws);
-            else lsm_solve_nb<NB>(sm_mom, 1.0, a.K, sm_coef);
+            if (phase == LSM_PH_REFINED) {
+                lsm_solve_centered(sm_mom, NB, a.state[LSM_ST_MU], a.K, sm_coef, sm_ws);
+            } else if constexpr (NB <= 9) {
+                lsm_solve_nb<NB>(sm_mom, 1.0, a.K, sm_coef);
+            } else {
+                // Orders >= 9: raw monomials up to S^9 and beyond are truncated by the reference's rank rule on every
+                // date, so there is no fast path to try -- every date with an in-the-money path is re-fitted.
+                for (int t = 0; t < LSM_COEF_DOUBLES; ++t) sm_coef[t] = 0.0;
+                sm_coef[LSM_C_COUNT] = sm_mom[0];
+                if (sm_mom[0] > 0.0) {
+                    sm_coef[LSM_C_REFINE] = 1.0;
+                    sm_coef[LSM_C_HINT] = sm_mom[1] / sm_mom[0];
+                }
+            }
         }
         __syncthreads();
         if (phase == LSM_PH_REGULAR && sm_coef[LSM_C_REFINE] != 0.0) {  // (uniform over the grid and over the ranks)
@@ -247,7 +259,7 @@ __global__ __launch_bounds__(256) void k_lsm_reduce_solve(const double* partials
                                                           double* moments, double* coef, int do_reduce, int do_solve,
                                                           double min_count, LsmRefine rf) {
     __shared__ double sm[32];
-    __shared__ double sm_c[16];
+    __shared__ double sm_c[LSM_COEF_STRIDE];
     __shared__ double sm_ws[lsm_ws_doubles(9)];
     if (do_reduce) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -367,7 +379,7 @@ struct LsmCoopArgs {
     double K, invK, maturity, dt, disc;
     int is_call;
     double* partials;  // [3][NM][gridDim.x], sentinel-filled: slot sets 0 / 1 of the regular rounds, 2 of refinement rounds
-    double* coef;      // [3][16], sentinel-filled: coefficients, [9] = ITM count
+    double* coef;      // [3][LSM_COEF_STRIDE], sentinel-filled: the coefficient blocks (lsm_device.hpp: LSM_C_*)
     unsigned* timeout; // set when a spin gives up
     unsigned spin_limit; // polling rounds before a spin gives up (LSM_SPIN_LIMIT; mcg_debug_lsm_hooks in tests)
     unsigned poll_delay; // test hook: see lsm_poll_coefficients
@@ -498,7 +510,7 @@ __device__ __forceinline__ void lsm_reduce_solve_publish(const LsmCoopArgs& a, u
     constexpr int NM = 3 * NB - 1;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double* part = a.partials + (int64_t)area * NM * G;
-    double* coef_now = a.coef + 16 * area;
+    double* coef_now = a.coef + LSM_COEF_STRIDE * area;
     for (int t0 = wave; t0 < NM; t0 += 8) {
         const int t1 = t0 + 4;
         const bool two = t1 < NM;
@@ -557,7 +569,7 @@ __device__ __forceinline__ void lsm_reduce_solve_publish(const LsmCoopArgs& a, u
     // ones the next regular round takes care of.)
     if (area != LSM_AREA_REFINE && threadIdx.x < 2 * LSM_COEF_DOUBLES) {
         const int blk = threadIdx.x < LSM_COEF_DOUBLES ? (area ^ 1) : LSM_AREA_REFINE;
-        lsm_st_shared(a.coef + 16 * blk + threadIdx.x % LSM_COEF_DOUBLES, lsm_sentinel());
+        lsm_st_shared(a.coef + LSM_COEF_STRIDE * blk + threadIdx.x % LSM_COEF_DOUBLES, lsm_sentinel());
     }
     if (threadIdx.x == 0) {
         if (centered) lsm_solve_centered(sm_mom, NB, mu, a.K, sm_coef, ws);
@@ -571,7 +583,7 @@ __device__ __forceinline__ void lsm_reduce_solve_publish(const LsmCoopArgs& a, u
 
 // every other workgroup: the first LSM_COEF_DOUBLES lanes poll one entry of the coefficient block each into sm_coef
 __device__ __forceinline__ void lsm_poll_coefficients(const LsmCoopArgs& a, int area, bool& gave_up, double* sm_coef) {
-    double* coef_now = a.coef + 16 * area;
+    double* coef_now = a.coef + LSM_COEF_STRIDE * area;
     // test hook (mcg_debug_lsm_hooks): workgroups other than 0 arrive late at their poll, ~4 us per unit -- the
     // re-arming of a coefficient block must not depend on how quickly it was read
     for (unsigned d = 0; d < a.poll_delay; ++d) __builtin_amdgcn_s_sleep(127);
@@ -660,7 +672,7 @@ __global__ __launch_bounds__(256, (PPT >= 8 ? 2 : 3)) void k_lsm_coop(LsmCoopArg
     constexpr int NM = 3 * NB - 1;
     __shared__ double red[NM * 4];
     __shared__ double sm_mom[32];
-    __shared__ double sm_coef[16];
+    __shared__ double sm_coef[LSM_COEF_STRIDE];
     __shared__ double sm_ws[lsm_ws_doubles(NB)];
     const bool call = a.is_call != 0;
     const unsigned G = gridDim.x;
@@ -911,7 +923,7 @@ __global__ __launch_bounds__(256, 2) void k_lsm_big(LsmCoopArgs a) {
     extern __shared__ double2 ring[];  // [LSM_RING_SLOTS][256]; unit u: S_j in slot 2u mod 16, S_{j-1} in the next
     __shared__ double red[NM * 4];
     __shared__ double sm_mom[32];
-    __shared__ double sm_coef[16];
+    __shared__ double sm_coef[LSM_COEF_STRIDE];
     __shared__ double sm_ws[lsm_ws_doubles(NB)];
     const bool call = a.is_call != 0;
     const int tid = threadIdx.x, wave = tid >> 6;
@@ -1186,11 +1198,11 @@ static int run_lsm_coop_impl(mcg_ctx* ctx, const mcg_paths* P, double r, double 
         if (all != shm_n_ranks(ctx)) return MCG_OK;
     }
     if (!use) return MCG_OK;
-    // buffer: {sum, sum^2} per contributing workgroup | [3][nm][workers] moment slots | [3][16] coefficient slots
+    // buffer: {sum, sum^2} per contributing workgroup | [3][nm][workers] moment slots | [3][LSM_COEF_STRIDE] coefficient slots
     // (Until the per-date solve left scratch memory, workgroups of small grids gathered ALL partial moments themselves and
     // solved redundantly -- one trip per date instead of two.  With a 1-us solve the single reducer is as fast at 244
     // workgroups and twice as fast at 488, where the gathering workgroups' polls crowd out the stores they wait for.)
-    const size_t n_slots = 3 * (size_t)nm * workers + 48;  // three slot sets (two alternating + the refinement rounds'), three coefficient blocks
+    const size_t n_slots = 3 * (size_t)nm * workers + 3 * LSM_COEF_STRIDE;  // three slot sets (two alternating + the refinement rounds'), three coefficient blocks
     int rc = ensure_cap(ctx, &ctx->partials, &ctx->partials_cap, 2 * (size_t)workers + n_slots);
     if (rc) return rc;
     LsmCoopArgs a;
@@ -1311,50 +1323,33 @@ int lsm_reduce_allreduce_solve(mcg_ctx* ctx, int grid, int nm, int nb, double mi
     return MCG_OK;
 }
 
+// k_lsm_date<nb> for nb = 1 .. LSM_MAX_NB (poly_order 0 .. 15)
+typedef void (*LsmDateKernel)(LsmDateArgs);
+static LsmDateKernel date_kernel(int nb) {
+    static const LsmDateKernel k[LSM_MAX_NB] = {k_lsm_date<1>,  k_lsm_date<2>,  k_lsm_date<3>,  k_lsm_date<4>,
+                                                k_lsm_date<5>,  k_lsm_date<6>,  k_lsm_date<7>,  k_lsm_date<8>,
+                                                k_lsm_date<9>,  k_lsm_date<10>, k_lsm_date<11>, k_lsm_date<12>,
+                                                k_lsm_date<13>, k_lsm_date<14>, k_lsm_date<15>, k_lsm_date<16>};
+    return k[nb - 1];
+}
+
 // Workgroups of k_lsm_date<nb> a CU holds at once: the per-date route launches exactly one resident wave of them.
 static int date_kernel_occupancy(int nb) {
-    static std::atomic<int> cache[10];
+    static std::atomic<int> cache[LSM_MAX_NB + 1];
     int occ = cache[nb].load(std::memory_order_relaxed);
     if (occ > 0) return occ;
-    const void* fn = nullptr;
-    switch (nb) {
-        case 1: fn = (const void*)k_lsm_date<1>; break;
-        case 2: fn = (const void*)k_lsm_date<2>; break;
-        case 3: fn = (const void*)k_lsm_date<3>; break;
-        case 4: fn = (const void*)k_lsm_date<4>; break;
-        case 5: fn = (const void*)k_lsm_date<5>; break;
-        case 6: fn = (const void*)k_lsm_date<6>; break;
-        case 7: fn = (const void*)k_lsm_date<7>; break;
-        case 8: fn = (const void*)k_lsm_date<8>; break;
-        default: fn = (const void*)k_lsm_date<9>; break;
-    }
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, 256, 0) != hipSuccess || occ < 1) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)date_kernel(nb), 256, 0) != hipSuccess || occ < 1) {
         (void)hipGetLastError();
-        occ = 2;
+        occ = 1;
     }
     occ = std::min(occ, 8);
     cache[nb].store(occ, std::memory_order_relaxed);
     return occ;
 }
 
-template <int NB>
-static void launch_date_nb(mcg_ctx* ctx, int grid, const LsmDateArgs& a) {
-    hipLaunchKernelGGL(k_lsm_date<NB>, dim3(grid), dim3(256), 0, ctx->stream, a);
-}
-
 static void launch_date(mcg_ctx* ctx, int nb, int grid, const LsmDateArgs& a) {
     TimedLaunch t(ctx, MCG_K_LSM_SWEEP);
-    switch (nb) {
-        case 1: launch_date_nb<1>(ctx, grid, a); break;
-        case 2: launch_date_nb<2>(ctx, grid, a); break;
-        case 3: launch_date_nb<3>(ctx, grid, a); break;
-        case 4: launch_date_nb<4>(ctx, grid, a); break;
-        case 5: launch_date_nb<5>(ctx, grid, a); break;
-        case 6: launch_date_nb<6>(ctx, grid, a); break;
-        case 7: launch_date_nb<7>(ctx, grid, a); break;
-        case 8: launch_date_nb<8>(ctx, grid, a); break;
-        default: launch_date_nb<9>(ctx, grid, a); break;
-    }
+    hipLaunchKernelGGL(date_kernel(nb), dim3(grid), dim3(256), 0, ctx->stream, a);
 }
 
 int run_lsm(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double maturity, double dt, int is_call,
@@ -1366,7 +1361,7 @@ int run_lsm(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double maturit
     int grid = (int)std::min<int64_t>((N + 511) / 512, (int64_t)ctx->n_cus * date_kernel_occupancy(nb));  // 512 paths per workgroup and trip
     if (grid < 1) grid = 1;
 
-    if (N >= 1 && N <= 1024 && !ctx->allreduce) {  // one launch for the whole sweep
+    if (N >= 1 && N <= 1024 && !ctx->allreduce && nb <= 9) {  // one launch for the whole sweep
         const double disc_s = std::exp(-r * dt);
         double* d3 = ctx->scalars + SC_SUMS;
         {
@@ -1439,12 +1434,12 @@ int run_lsm(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double maturit
     ctx->h_scalars[SC_LSM_STATE + LSM_ST_MU] = 0.0;
     MCG_HIP(hipMemcpyAsync(a.state, ctx->h_scalars + SC_LSM_STATE, 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     MCG_HIP(hipMemsetAsync(a.ticket, 0, sizeof(double), ctx->stream));
-    MCG_HIP(hipMemsetAsync(a.msg, 0, 32 * sizeof(double), ctx->stream));
+    MCG_HIP(hipMemsetAsync(a.msg, 0, 48 * sizeof(double), ctx->stream));
 
     // M launches when no date asks for a re-fit, one more per date that does (orders >= 4: every date); a few spare
     // ones are queued with the first batch, and the state tells afterwards whether the sweep got through.
     int dates_left = M;
-    int64_t batch = nb >= 5 ? 2 * (int64_t)M : (int64_t)M + 4 + M / 32;
+    int64_t batch = nb >= 5 ? 2 * (int64_t)M : (int64_t)M + 4 + M / 32;  // (orders >= 4: the reference's rank rule truncates on every date)
     bool first = true;
     while (dates_left > 0) {
         for (int64_t k = 0; k < batch; ++k) {

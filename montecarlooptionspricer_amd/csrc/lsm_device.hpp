@@ -7,11 +7,13 @@ namespace mcg {
 
 // Layout of the coefficient block every solve writes (doubles): the fitted continuation value at price S is
 //   sum_t coef[t] y^t,  y = (S/K - 1) - coef[LSM_C_CENTER].
-constexpr int LSM_C_COUNT = 9;    // number of regression rows (in-the-money paths; global when sharded)
-constexpr int LSM_C_CENTER = 10;  // centre of the regressor (0 unless the date was refined)
-constexpr int LSM_C_REFINE = 11;  // 1: the caller should re-accumulate the moments about coef[LSM_C_HINT] and call
-constexpr int LSM_C_HINT = 12;    //    lsm_solve_centered; the coefficients already written are the fall-back
-constexpr int LSM_COEF_DOUBLES = 13;
+constexpr int LSM_MAX_NB = 16;     // basis functions a coefficient block has room for (poly_order <= 15)
+constexpr int LSM_C_COUNT = 16;    // number of regression rows (in-the-money paths; global when sharded)
+constexpr int LSM_C_CENTER = 17;   // centre of the regressor (0 unless the date was refined)
+constexpr int LSM_C_REFINE = 18;   // 1: the caller should re-accumulate the moments about coef[LSM_C_HINT] and call
+constexpr int LSM_C_HINT = 19;     //    lsm_solve_centered; the coefficients already written are provisional
+constexpr int LSM_COEF_DOUBLES = 20;
+constexpr int LSM_COEF_STRIDE = 24;  // doubles between two coefficient blocks in memory / size of one in LDS
 
 // LDS workspace of lsm_solve_centered for basis size nb (doubles)
 __host__ __device__ constexpr int lsm_ws_doubles(int nb) { return 7 * nb * nb + 8 * nb; }
@@ -56,7 +58,7 @@ __device__ __forceinline__ void lsm_solve_nb(const double* moments, double min_c
     double G[NB][NB], Q[NB][NB], rhs[NB], d[NB], sol[NB], inv_piv[NB];
     const double count = moments[0];
     coef[LSM_C_COUNT] = count;
-    for (int a = 0; a < 9; ++a) coef[a] = 0.0;
+    for (int a = 0; a < LSM_MAX_NB; ++a) coef[a] = 0.0;
     coef[LSM_C_CENTER] = 0.0;
     coef[LSM_C_REFINE] = 0.0;
     coef[LSM_C_HINT] = 0.0;
@@ -171,7 +173,7 @@ __device__ __noinline__ void lsm_solve_centered(const double* mc, int nb, double
     double* sig = z + nb;           // [nb]
     double* pz = sig + nb;          // [nb]
     const double count = mc[0];
-    for (int a = 0; a < 9; ++a) coef[a] = 0.0;
+    for (int a = 0; a < LSM_MAX_NB; ++a) coef[a] = 0.0;
     coef[LSM_C_COUNT] = count;
     coef[LSM_C_CENTER] = mu;
     coef[LSM_C_REFINE] = 0.0;
@@ -359,7 +361,7 @@ __device__ __forceinline__ void lsm_small_body(const double* data, int64_t ld, i
     constexpr int NM = 3 * NB - 1;
     __shared__ double red[NM * 4];
     __shared__ double sm_mom[32];
-    __shared__ double sm_coef[16];
+    __shared__ double sm_coef[LSM_COEF_STRIDE];
     __shared__ double sm_ws[lsm_ws_doubles(NB)];
     const bool call = is_call != 0;
     const double invK = 1.0 / K;

@@ -375,7 +375,7 @@ static int gen_rb(mcg_ctx* ctx, uint64_t seed, double S0, double r, double xi, d
     if (!(H >= 0.0) || !std::isfinite(H)) return fail(MCG_ERR_INVALID, "H must be >= 0");
     if (!std::isfinite(eta)) return fail(MCG_ERR_INVALID, "eta must be finite");
     if (!(std::fabs(rho) <= 1.0)) return fail(MCG_ERR_INVALID, "|rho| must be <= 1");
-    if (n_steps > 2048) return fail(MCG_ERR_INVALID, "rBergomi n_steps must be <= 2048 (got %d)", n_steps);
+    if (n_steps > (1 << 24)) return fail(MCG_ERR_INVALID, "rBergomi n_steps must be <= 2^24 (got %d)", n_steps);  // (66 000 years of trading days)
     mcg_paths* P = nullptr;
     rc = paths_new(ctx, n_paths, n_steps, path_begin, &P);
     if (rc) return rc;
@@ -539,7 +539,7 @@ int mcg_price_lsm(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double m
                   int poly_order, double* mean, double* std_err) {
     if (!ctx || !P || !mean) return fail(MCG_ERR_INVALID, "ctx/paths/mean is NULL");
     if (P->ctx != ctx) return fail(MCG_ERR_INVALID, "paths belong to a different ctx");
-    if (poly_order < 0 || poly_order > 8) return fail(MCG_ERR_INVALID, "poly_order must be in [0,8] (got %d)", poly_order);
+    if (poly_order < 0 || poly_order > 15) return fail(MCG_ERR_INVALID, "poly_order must be in [0,15] (got %d)", poly_order);
     if (P->n_paths < 1 && !ctx->allreduce) return fail(MCG_ERR_EMPTY_PATHS, "LSM::PredictOptionPrice: Empty pricePaths.");
     MCG_HIP(hipSetDevice(ctx->device));
     return run_lsm(ctx, P, r, K, maturity, dt, is_call, poly_order, mean, std_err);

@@ -106,13 +106,13 @@ constexpr int SCALARS_DOUBLES = 256;
 // layout of ctx->scalars (doubles)
 constexpr int SC_SUMS = 0;     // [0..3)  sum, sumsq, n
 constexpr int SC_MOMENTS = 8;  // [8..8+26) LSM moments (<= 3*8+2)
-constexpr int SC_COEF = 40;    // [40..53) the LSM coefficient block of the current date (lsm_device.hpp: LSM_C_*)
+constexpr int SC_COEF = 40;    // [40..60) the LSM coefficient block of the current date (lsm_device.hpp: LSM_C_*)
 constexpr int SC_FINAL = 64;   // [64..67) LSM final sums
 constexpr int SC_BARRIER = 72; // [72] 32-bit timeout flag of k_lsm_coop's hand-shake
 constexpr int SC_TICKET = 80;  // [80] 64-bit share ticket of the persistent rBergomi generator (zeroed before each launch)
 constexpr int SC_LSM_TICKET = 88;  // [88] 32-bit "workgroups done" ticket of the per-date LSM kernel (k_lsm_date)
-constexpr int SC_LSM_MSG = 96;     // [96..128) per-date LSM message: the 3p+2 moments the next launch solves (the all-reduced part)
-constexpr int SC_LSM_STATE = 128;  // [128..131) per-date LSM state: date, phase, centre (kernels_lsm.hip: LSM_ST_*)
+constexpr int SC_LSM_MSG = 96;     // [96..144) per-date LSM message: the 3p+2 <= 47 moments the next launch solves (the all-reduced part)
+constexpr int SC_LSM_STATE = 144;  // [144..147) per-date LSM state: date, phase, centre (kernels_lsm.hip: LSM_ST_*)
 
 int pool_alloc(mcg_ctx* ctx, size_t bytes, void** out);
 void pool_release(mcg_ctx* ctx, void* ptr, size_t bytes);

@@ -162,7 +162,9 @@ double LSM::PredictOptionPrice(const std::vector<std::vector<double>>& pricePath
                                double maturity, double dt, bool isCall, int polyOrder) {
     if (pricePaths.empty() || pricePaths[0].empty())
         throw std::runtime_error("LSM::PredictOptionPrice: Empty pricePaths.");
-    if (polyOrder < 0 || polyOrder > 8) throw std::invalid_argument("LSM: polyOrder must be in [0, 8]");
+    // (raw monomials beyond S^15 at S ~ 100 span more than thirty orders of magnitude: the reference's own solve keeps a
+    // handful of singular directions of them; orders up to 15 are served and checked against the restated reference)
+    if (polyOrder < 0 || polyOrder > 15) throw std::invalid_argument("LSM: polyOrder must be in [0, 15]");
     PathsGuard own;
     mcg_paths* P = device_matrix(pricePaths, "LSM: Invalid path index in regression", own);
     double price = 0.0;

@@ -228,6 +228,23 @@ def test_rbergomi_persistent_shares_match_oracle(eng, orc, n_paths, n_steps):
     P.free()
 
 
+@pytest.mark.parametrize("n_paths,n_steps", [(6, 2500), (3, 4100)])
+def test_rbergomi_beyond_2048_steps_matches_oracle(eng, orc, n_paths, n_steps):
+    """The reference has no size limit (RoughVolatility.cpp:337-344): transforms longer than a wavefront holds (Mz = 4096,
+    8192) take the direct-summation route -- same Philox draws, same matrix to rounding, and the payoff sums the fused
+    entry point leaves agree with a pricing pass over the stored matrix."""
+    P = eng.rbergomi(SEED, RB["S0"], RB["r"], RB["xi"], RB["H"], RB["eta"], RB["rho"], DT, n_steps, n_paths, path_begin=10,
+                     payoff=(90.0, True))
+    got = P.to_host_step_major()
+    want = orc.paths_rbergomi(SEED, RB["S0"], RB["r"], RB["xi"], RB["H"], RB["eta"], RB["rho"], DT, n_steps, 10, n_paths)
+    assert np.isfinite(got).all() and rel_err(got, want) < 1e-9
+    T = n_steps * DT
+    m, se = eng.price_european(P, 90.0, RB["r"], T, True)
+    om, ose = orc.price_european(want, 90.0, RB["r"], T, True)
+    assert abs(m - om) <= 1e-9 * abs(om) + 1e-12 and abs(se - ose) <= 1e-8 * abs(ose) + 1e-12
+    P.free()
+
+
 def test_rbergomi_spectrum_matches_oracle(orc):
     from montecarlooptionspricer_amd.engine import rbergomi_spectrum
     for steps, H, eta in [(252, 0.1, 1.9), (512, 0.1, 1.9), (7, 0.57, 0.03), (1, 0.3, 1.0)]:
@@ -448,7 +465,7 @@ def test_lsm_edge_cases_match_oracle(eng, orc):
         P.free()
     with pytest.raises(mc.McgError, match="poly_order"):
         P = eng.from_host(mixed)
-        eng.price_lsm(P, 0.04, 100.0, 1.0, 0.1, False, 9)
+        eng.price_lsm(P, 0.04, 100.0, 1.0, 0.1, False, 16)
 
 
 def _near_degenerate_matrix(rs, n_total, n_itm, base, spread, K=100.0):
@@ -544,6 +561,25 @@ def test_lsm_high_orders_follow_the_reference_rank_rule(eng, orc, poly):
     P.free()
     want = orc.lsm_price(host, 0.04, 100.0, 1.0, dt, False, poly)
     assert abs(got - want) <= 2e-6 * abs(want), (poly, got, want)
+
+
+@pytest.mark.parametrize("poly", [9, 12, 15])
+def test_lsm_orders_beyond_eight_are_served(eng, orc, poly):
+    """LSM::PredictOptionPrice takes any polyOrder (LSMPricer.cpp:9-17).  Orders above 8 run one launch per exercise date
+    (k_lsm_date) whatever the path count, every date re-fitted by the reference's rank rule -- here also through the class
+    API (mcg_compat_lsm_price), which used to refuse them."""
+    n, steps, dt = 3000, 12, 1.0 / 12
+    P = eng.gbm(SEED + 5, 100.0, 0.04, 0.3, dt, steps, n)
+    host = P.to_host_step_major()
+    got, _ = eng.price_lsm(P, 0.04, 100.0, 1.0, dt, False, poly)
+    P.free()
+    want = orc.lsm_price(host, 0.04, 100.0, 1.0, dt, False, poly)
+    assert abs(got - want) <= 5e-6 * abs(want), (poly, got, want)
+    from montecarlooptionspricer_amd import compat
+    small = np.ascontiguousarray(host[:, :300].T)
+    got_c = compat.LSM().PredictOptionPrice(small.tolist(), 0.04, 100.0, 1.0, dt, False, poly)
+    want_c = orc.lsm_price(small, 0.04, 100.0, 1.0, dt, False, poly, step_major=False)
+    assert abs(got_c - want_c) <= 5e-6 * abs(want_c), (poly, got_c, want_c)
 
 
 def test_from_host_roundtrip_is_exact(eng):
@@ -897,6 +933,28 @@ def test_batch_rows_match_oracle_row_by_row(eng, orc):
                   eng.price_martingale(P, 0.04, d["strike"], d["maturity"], DT, call, 2, 5)[0]]
         P.free()
         assert np.allclose(got[i], single, rtol=1e-7, atol=1e-9), (i, d, got[i], single)
+
+
+def test_batch_rows_longer_than_the_row_kernels_are_priced_not_zeroed(eng):
+    """A row of more than 1020 steps (PredictionGen.cpp:718 sets steps = floor(maturity * 252) with no cap) does not fit
+    the row kernels' tables: it is priced through the single-contract entry points on the same Philox ids -- four real
+    prices, equal to calling those entry points by hand -- while its neighbours still take the batch kernels."""
+    rows = _driver_rows(3, np.random.RandomState(9))
+    rows[1].update(n_steps=1100, maturity=1100 / 252.0, is_call=0)
+    rows[1]["strike"] = rows[1]["S0"] * 1.05
+    got = eng.batch_price_rows(rows, n_paths=250, r=0.04, dt=DT, num_branches=10, poly_order=2, max_iterations=5, seed=31)
+    assert (got[1][1:] > 0.0).all() and np.isfinite(got).all()
+    d = rows[1]
+    P = eng.rbergomi(31, d["S0"], 0.04, d["xi"], d["H"], d["eta"], d["rho"], DT, d["n_steps"], 250, path_begin=1 << 32)
+    ex = np.arange(d["n_steps"], dtype=np.int32)
+    single = [eng.price_asymptotic(P, 0.04, d["strike"], d["maturity"], DT, False, d["sigma"], d["dividend"]),
+              eng.price_branching(P, 0.04, d["strike"], d["maturity"], DT, False, 10, ex, 31)[0],
+              eng.price_lsm(P, 0.04, d["strike"], d["maturity"], DT, False, 2)[0],
+              eng.price_martingale(P, 0.04, d["strike"], d["maturity"], DT, False, 2, 5)[0]]
+    P.free()
+    assert np.array_equal(got[1], single), (got[1], single)
+    alone = eng.batch_price_rows([rows[0], rows[2]], n_paths=250, r=0.04, dt=DT, num_branches=10, poly_order=2, max_iterations=5, seed=31)
+    assert np.array_equal(got[0], alone[0])      # (row 2's Philox ids depend on its index: only row 0 is comparable)
 
 
 def test_batch_rows_arguments(eng):
