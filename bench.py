@@ -607,15 +607,17 @@ def main() -> None:
                 "hbm_frac_of_design_bytes": design / max(sweep_ms / per_pass * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS,
                 "shape": "one launch (V in registers; beyond 2.09M paths the matrix streams through an LDS-DMA ring)" if one_launch
                          else "per-date kernels (one all-reduce of 8 moments per exercise date)"}
-            pmc5 = os.path.join(ROOT, "profiles", "r02_c5_pmc_traffic.json")
+            pmc5 = os.path.join(ROOT, "profiles", "r03_c5_pmc_traffic.json")
             if os.path.exists(pmc5) and count == 8_000_000 and n_steps == 252:
                 try:
                     j5 = json.load(open(pmc5))
                     out["roofline"]["traffic"] = j5["generator"]["hbm_bytes_per_launch"]
-                    out["roofline"]["traffic_source"] = ("profiles/r02_c5_pmc_traffic.json (committed: rocprofv3 --pmc WRITE_SIZE / "
-                                                         "FETCH_SIZE passes of this command, tools/profile_r02.sh; not re-measured here)")
+                    out["roofline"]["traffic_source"] = ("profiles/r03_c5_pmc_traffic.json (committed: rocprofv3 --pmc WRITE_SIZE / "
+                                                         "FETCH_SIZE passes of this command, tools/profile_r03.sh; not re-measured here)")
                     if one_launch:
                         out["roofline"]["lsm"]["traffic"] = j5["lsm_one_launch"]["hbm_bytes_per_launch"]
+                    elif "lsm_per_date_launch" in j5:
+                        out["roofline"]["lsm"]["traffic_per_launch"] = j5["lsm_per_date_launch"]["hbm_bytes_per_launch"]
                 except Exception:
                     pass
         if world == 1 and not args.no_cpu_baseline:

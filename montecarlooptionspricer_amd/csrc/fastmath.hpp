@@ -8,7 +8,7 @@
 //   scaled_exp(S, a)        S * e^a           any finite a (overflow -> inf, underflow -> 0)
 //   neg2log(u, tab)         -2 ln u           u in (0, 1); 1024-entry {1/c, -2 ln c} table in LDS
 //   sqrt_pos(x)             sqrt(x)           x in [1e-300, 1e300], no denormal/negative handling
-//   sincos_table(wb, tab)   cos/sin(2 pi f)   f = ((wb >> 8) + 1/2) 2^-24, from the raw Philox word; 512-entry table
+//   sincos_table(wb, tab)   cos/sin(2 pi f)   f = ((wb >> 8) + 1/2) 2^-24, from the raw Philox word; 1024-entry table
 //   normal_quad_fast(...)   the four normals of one Philox block (philox.hpp's contract)
 //
 // Polynomials: interpolation at Chebyshev nodes in 60-digit arithmetic, rounded to binary64
@@ -23,16 +23,17 @@ namespace mcg {
 namespace fm {
 
 constexpr int LOG_TAB_ENTRIES = 1024;    // x 16 B = 16 KiB of LDS per workgroup
-constexpr int SINCOS_TAB_ENTRIES = 512;  // x 16 B = 8 KiB
-constexpr int EXP2_TAB_ENTRIES = 64;     // x 8 B = 512 B
+constexpr int SINCOS_BITS = 10;
+constexpr int SINCOS_TAB_ENTRIES = 1 << SINCOS_BITS;  // x 16 B = 16 KiB
+constexpr int EXP2_TAB_ENTRIES = 256;     // x 8 B = 2 KiB
 constexpr int TABLE_UNITS = LOG_TAB_ENTRIES + SINCOS_TAB_ENTRIES + EXP2_TAB_ENTRIES / 2;  // 16-byte units of all three
 
 // The lookup tables as they sit in LDS (and, back to back, in the device buffer they are staged from:
 // fm::LOG_TAB_HOST, fm::SINCOS_TAB_HOST, fm::EXP2_TAB_HOST).
 struct Tables {
     double2 log[LOG_TAB_ENTRIES];        // {1/c_i, -2 ln c_i}
-    double2 sincos[SINCOS_TAB_ENTRIES];  // {cos, sin}(2 pi i / 512)
-    double exp2[EXP2_TAB_ENTRIES];       // 2^(j/64)
+    double2 sincos[SINCOS_TAB_ENTRIES];  // {cos, sin}(2 pi i / 1024)
+    double exp2[EXP2_TAB_ENTRIES];       // 2^(j/256)
 };
 
 __device__ __forceinline__ double from_words(uint32_t hi, uint32_t lo) { return __hiloint2double((int)hi, (int)lo); }
@@ -149,21 +150,21 @@ __device__ __forceinline__ void exp_full2(double a, double b, double& ea, double
     eb = __builtin_ldexp(1.0 + __builtin_fma(rb * rb, qb, rb), (int)kb);
 }
 
-// 2^(ta/64), 2^(tb/64) for arguments that are ALREADY in units of (ln 2)/64 (the caller folds 64 log2(e) into whatever
-// produces them: the rBergomi variance factor is 2^((c X + table)/64)): n = rint(t) = 64 k + j, g = t - n exactly,
-// 2^(t/64) = 2^k * 2^(j/64) * 2^(g/64), the middle factor from a 64-entry LDS table, the last as 1 + g h(g) with h of
-// degree 4 on |g| <= 1/2 (max rel err 2^-58.6, tools/gen_coeffs.py).  10 fp64 instructions per value (+3 integer, one
-// LDS read) against the 15 of a degree-10 polynomial on the whole octave and the 20 of exp_full2 -- and fp64 instructions
-// are what the generator's clock pays for.
+// 2^(ta/256), 2^(tb/256) for arguments that are ALREADY in units of (ln 2)/256 (the caller folds 256 log2(e) into whatever
+// produces them: the rBergomi variance factor is 2^((c X + table)/256)): n = rint(t) = 256 k + j, g = t - n exactly,
+// 2^(t/256) = 2^k * 2^(j/256) * 2^(g/256), the middle factor from a 256-entry LDS table, the last as 1 + g h(g) with h of
+// degree 3 on |g| <= 1/2 (max rel err 2^-57.5, tools/gen_coeffs.py).  9 fp64 instructions per value (+3 integer, one
+// LDS read) against the 10 of the 64-entry table this replaced in round 3, the 15 of a degree-10 polynomial on the whole
+// octave and the 20 of exp_full2 -- and fp64 instructions are what the generator's clock pays for.
 __device__ __forceinline__ void exp2_pair(double ta, double tb, const Tables* tab, double& ea, double& eb) {
     const double na = __builtin_rint(ta), nb = __builtin_rint(tb);
     const int ia = (int)na, ib = (int)nb;  // v_cvt_i32_f64 saturates: |t| beyond 2^31 ends in ldexp's clamp either way
-    const double Ta = tab->exp2[ia & 63], Tb = tab->exp2[ib & 63];
+    const double Ta = tab->exp2[ia & 255], Tb = tab->exp2[ib & 255];
     const double ga = ta - na, gb = tb - nb;
-    double qa = 0x1.5d881278aaf92p-40, qb = 0x1.5d881278aaf92p-40;
-    horner2x4(qa, qb, ga, gb, 0x1.3b2ad03af0e55p-31, 0x1.c6b08d70496bfp-23, 0x1.ebfbdff82ac4dp-15, 0x1.62e42fefa39efp-7);
-    ea = __builtin_ldexp(__builtin_fma(Ta * ga, qa, Ta), ia >> 6);
-    eb = __builtin_ldexp(__builtin_fma(Tb * gb, qb, Tb), ib >> 6);
+    double qa = 0x1.3b2ab83ecf101p-39, qb = 0x1.3b2ab83ecf101p-39;
+    horner2x3(qa, qb, ga, gb, 0x1.c6b0902ba1a20p-29, 0x1.ebfbdff82c585p-19, 0x1.62e42fefa39d9p-9);
+    ea = __builtin_ldexp(__builtin_fma(Ta * ga, qa, Ta), ia >> 8);
+    eb = __builtin_ldexp(__builtin_fma(Tb * gb, qb, Tb), ib >> 8);
 }
 
 // e^a - 1, e^b - 1 for |a|, |b| <= 0.1 (the polynomial of scaled_exp_small6) and for <= 0.34 (that of scaled_exp
@@ -300,33 +301,28 @@ __device__ __forceinline__ double sqrt_pos(double x) {
 }
 
 // cos(2 pi f), sin(2 pi f) with f = ((wb >> 8) + 1/2) * 2^-24, straight from the Philox word:
-// 2 pi f = 2 pi i/512 + delta with i the top 9 angle bits and delta = 2 pi (low15 + 1/2) 2^-24 in
-// (0, 0.01228).  (cos, sin)(2 pi i/512) come from a 512-entry LDS table (correctly rounded),
-// sin/cos(delta) from 3-term series (truncation 8e-18 / 1e-20), combined by the angle-addition
-// formulas: 13 fp64 instructions and no octant logic.
+// 2 pi f = 2 pi i/1024 + delta with i the top 10 angle bits and delta = 2 pi (low14 + 1/2) 2^-24 in
+// (0, 0.006136).  (cos, sin)(2 pi i/1024) come from a 1024-entry LDS table (correctly rounded),
+// sin(delta) from a 3-term and cos(delta) from a 3-term series (1 - d^2/2 + d^4/24: truncation 7.4e-17; 6.5e-20 for the
+// sine), combined by the angle-addition formulas: 12 fp64 instructions and no octant logic.  (512 entries and one more
+// cosine term until round 3.)
 // the table-independent half: (cos, sin)(delta)
 __device__ __forceinline__ void sincos_small(uint32_t wb, double& cd_out, double& sd_out) {
-    const double delta = __builtin_fma((double)((wb >> 8) & 0x7FFFu), 0x1.921fb54442d18p-22, 0x1.921fb54442d18p-23);
+    const double delta = __builtin_fma((double)((wb >> 8) & ((1u << (24 - SINCOS_BITS)) - 1u)), 0x1.921fb54442d18p-22, 0x1.921fb54442d18p-23);
     const double d2 = delta * delta;
     const double ts = __builtin_fma(d2, 0x1.1111111111111p-7, -0x1.5555555555555p-3);  // 1/120, -1/6
     sd_out = __builtin_fma(delta * d2, ts, delta);
-    double tc = __builtin_fma(d2, -0x1.6c16c16c16c17p-10, 0x1.5555555555555p-5);        // -1/720, 1/24
-    tc = __builtin_fma(tc, d2, -0.5);
+    const double tc = __builtin_fma(d2, 0x1.5555555555555p-5, -0.5);                    // 1/24, -1/2
     cd_out = __builtin_fma(tc, d2, 1.0);
 }
 __device__ __forceinline__ void sincos_entry(uint32_t wb, const double2 e, double& c_out, double& s_out) {
-    const double delta = __builtin_fma((double)((wb >> 8) & 0x7FFFu), 0x1.921fb54442d18p-22, 0x1.921fb54442d18p-23);
-    const double d2 = delta * delta;
-    const double ts = __builtin_fma(d2, 0x1.1111111111111p-7, -0x1.5555555555555p-3);  // 1/120, -1/6
-    const double sd = __builtin_fma(delta * d2, ts, delta);
-    double tc = __builtin_fma(d2, -0x1.6c16c16c16c17p-10, 0x1.5555555555555p-5);        // -1/720, 1/24
-    tc = __builtin_fma(tc, d2, -0.5);
-    const double cd = __builtin_fma(tc, d2, 1.0);
+    double cd, sd;
+    sincos_small(wb, cd, sd);
     c_out = __builtin_fma(e.x, cd, -(e.y * sd));
     s_out = __builtin_fma(e.y, cd, e.x * sd);
 }
 __device__ __forceinline__ void sincos_table(uint32_t wb, const double2* sc_tab, double& c_out, double& s_out) {
-    sincos_entry(wb, sc_tab[wb >> 23], c_out, s_out);
+    sincos_entry(wb, sc_tab[wb >> (32 - SINCOS_BITS)], c_out, s_out);
 }
 
 // One Box-Muller pair from 64 Philox bits (philox.hpp contract).
@@ -377,7 +373,7 @@ __device__ __forceinline__ void normal_quad_fast(uint32_t k0, uint32_t k1, uint6
     // All four table entries are requested before any of them is used: a lookup is ~100 cycles of LDS latency, and a
     // kernel at two waves per SIMD has little else to issue meanwhile (requested one by one, each was waited for).
     const LogSplit s0 = log_split(radius_u01(w.w0, w.w1)), s1 = log_split(radius_u01(w.w2, w.w3));
-    double2 a0 = tab->sincos[w.w1 >> 23], a1 = tab->sincos[w.w3 >> 23], l0 = tab->log[s0.idx], l1 = tab->log[s1.idx];
+    double2 a0 = tab->sincos[w.w1 >> (32 - SINCOS_BITS)], a1 = tab->sincos[w.w3 >> (32 - SINCOS_BITS)], l0 = tab->log[s0.idx], l1 = tab->log[s1.idx];
     double cd0, sd0, cd1, sd1;  // meanwhile: the halves that need no table
     sincos_small(w.w1, cd0, sd0);
     sincos_small(w.w3, cd1, sd1);
@@ -391,7 +387,7 @@ __device__ __forceinline__ void normal_quad_fast(uint32_t k0, uint32_t k1, uint6
     z[3] = r1 * __builtin_fma(a1.y, cd1, a1.x * sd1);
 }
 
-// Cooperative copy of the tables (global, 24.5 KiB) into LDS; call before the first normal and
+// Cooperative copy of the tables (global, 34 KiB) into LDS; call before the first normal and
 // follow with __syncthreads().
 __device__ __forceinline__ void load_tables(Tables* lds, const double2* __restrict__ gtab) {
     double2* dst = reinterpret_cast<double2*>(lds);

@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256) void k_debug_eval(int fn, const double* x, dou
         case 4: fm::normal_quad_fast(1u, 0u, (uint64_t)v, 0u, STREAM_PRICE, tab, z); break;
         case 6: a = fm::scaled_exp_small(1.0, v); break;
         case 7: a = fm::scaled_exp_small6(1.0, v); break;
-        case 8: fm::exp2_pair(v, v + 24.0, tab, a, b); break;  // 2^(v/64), 2^((v+24)/64)
+        case 8: fm::exp2_pair(v, v + 96.0, tab, a, b); break;  // 2^(v/256), 2^((v+96)/256)
         case 9: fm::normal_quad_fast<true>(1u, 0u, (uint64_t)v, 0u, STREAM_PRICE, tab, z); break;
         default: normal_quad_ref(1u, 0u, (uint64_t)v, 0u, STREAM_PRICE, z); break;
     }

@@ -68,7 +68,7 @@ struct mcg_ctx {
     size_t weights_cap = 0;
     double* lsm_v = nullptr;     // LSM value vector
     size_t lsm_v_cap = 0;
-    double* log_tab = nullptr;   // device copy of fm::LOG_TAB_HOST + fm::SINCOS_TAB_HOST (24 KiB), staged to LDS
+    double* log_tab = nullptr;   // device copy of fm::LOG_TAB_HOST + fm::SINCOS_TAB_HOST + fm::EXP2_TAB_HOST (34 KiB), staged to LDS
 
     // collective
     mcg_allreduce_fn allreduce = nullptr;

@@ -70,8 +70,11 @@ __host__ __device__ inline int rb_pairs_per_block(int M) { return M < 32 ? 256 :
 #ifndef RB_EAGER_PRICE
 #define RB_EAGER_PRICE true
 #endif
-// (one buffer from Mz = 1024 on: with the 24 KiB of generator tables next to it, two would leave room for one workgroup per CU only)
-__host__ __device__ inline int rb_stage_bufs(int M) { return rb_log_tiles(M) == 2 && M < 1024 ? RB_NBUF : 1; }
+// (one buffer from Mz = 512 on: with the 34 KiB of generator tables next to it, two would leave room for one workgroup
+// per CU only -- since round 3, when the sin/cos table went from 512 to 1024 entries; A/B on one box: C4 9.48 -> 9.31 ms
+// with the larger tables and one buffer, 9.33 with the exponential's larger table alone and two buffers)
+#define RB_NBUF_MAX_M 512
+__host__ __device__ inline int rb_stage_bufs(int M) { return rb_log_tiles(M) == 2 && M < RB_NBUF_MAX_M ? RB_NBUF : 1; }
 __host__ __device__ inline size_t rb_stage_units(int M) {  // double2 units per buffer
     return M < 32 ? 0 : (size_t)(M >> rb_log_tiles(M)) * (size_t)(rb_pairs_per_block(M) + 1);
 }
@@ -90,9 +93,9 @@ struct RbLds {
     double2* stage;
 };
 
-// comp_scale: the FFT variants keep the compensator as 32 log2(e) comp -- their variance factor is
-// e^{(X + comp)/2} = 2^{(32 log2(e) X + table)/64} (fm::exp2_pair) --, the direct variant as it is.
-constexpr double RB_HALF_LOG2E = 0x1.71547652b82fep+5;  // 64 log2(e) / 2: fm::exp2_pair takes its argument in units of (ln 2)/64
+// comp_scale: the FFT variants keep the compensator as 128 log2(e) comp -- their variance factor is
+// e^{(X + comp)/2} = 2^{(128 log2(e) X + table)/256} (fm::exp2_pair) --, the direct variant as it is.
+constexpr double RB_HALF_LOG2E = 0x1.71547652b82fep+7;  // 256 log2(e) / 2: fm::exp2_pair takes its argument in units of (ln 2)/256
 __device__ __forceinline__ RbLds rb_stage_lds(const RbArgs& a, double* smem, fm::Tables* tabs, double comp_scale) {
     const int M = a.M;
     double* amp = smem;
@@ -222,7 +225,7 @@ __device__ __forceinline__ void rb_fft_block(const RbArgs& a, const RbLds& L, in
     constexpr int NT = 1 << LT;  // 4-step tiles per lane
     constexpr int PW = 4 * P;    // pairs per workgroup
     constexpr int RS = PW + 1;   // staging row stride in 16-byte units (one unit of padding)
-    constexpr int NBUF = (LT == 2 && LG < 6) ? RB_NBUF : 1;  // = rb_stage_bufs(Mz)
+    constexpr int NBUF = (LT == 2 && (16 << LG) < RB_NBUF_MAX_M) ? RB_NBUF : 1;  // = rb_stage_bufs(Mz), Mz = 16 G
     const int lane = tid & 63, wave = tid >> 6;
     const int g = lane >> (6 - LG), c = lane & (P - 1);
     const int64_t q = block_index * (4 * P) + wave * P + c;  // pair index within the launch
@@ -382,7 +385,7 @@ __device__ __forceinline__ void rb_fft_block(const RbArgs& a, const RbLds& L, in
             double* const ib = xi + t * 4;
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
-                const double cmp = L.comp[nl + v];  // 32 log2(e) comp_n
+                const double cmp = L.comp[nl + v];  // 128 log2(e) comp_n
                 fm::exp2_pair(fma(ia[v], RB_HALF_LOG2E, cmp), fma(ib[v], RB_HALF_LOG2E, cmp), tabs, ia[v], ib[v]);
                 __builtin_amdgcn_sched_barrier(0);  // one step's pair of chains at a time: more of them cost registers, not time
             }

@@ -55,16 +55,16 @@ def test_scaled_exp_small_variants(eng):
 
 
 def test_exp2_pair(eng):
-    """2^(t/64) for arguments already in units of (ln 2)/64 (the rBergomi variance factor: 64-entry table of 2^(j/64)
-    times a degree-5 polynomial): both chains of the pair, <= 1.5 ulp."""
+    """2^(t/256) for arguments already in units of (ln 2)/256 (the rBergomi variance factor: 256-entry table of 2^(j/256)
+    times a degree-4 polynomial): both chains of the pair, <= 1.5 ulp."""
     rs = np.random.RandomState(11)
-    t = np.concatenate([rs.uniform(-32, 32, 3000), rs.uniform(-2000, 2000, 2000), rs.normal(0, 100, 2000),
-                        np.arange(-70.0, 70.0, 0.5), [0.0, 0.5, -0.5, 31.5, 32.5, 63.5, 64.5, -63.5, 1e-300, 64000.0, -68000.0,
-                                                      66000.0, -77000.0]])
+    t = np.concatenate([rs.uniform(-128, 128, 3000), rs.uniform(-8000, 8000, 2000), rs.normal(0, 400, 2000),
+                        np.arange(-280.0, 280.0, 0.5), [0.0, 0.5, -0.5, 127.5, 128.5, 255.5, 256.5, -255.5, 1e-300, 256000.0,
+                                                        -272000.0, 264000.0, -308000.0]])
     y = eng.debug_eval(8, t)
     worst = 0.0
     for ti, (ya, yb) in zip(t[:-2], y[:-2, :2]):
-        worst = max(worst, ulp_err(ya, mp.mpf(2) ** (mp.mpf(ti) / 64)), ulp_err(yb, mp.mpf(2) ** (mp.mpf(float(ti + 24.0)) / 64)))
+        worst = max(worst, ulp_err(ya, mp.mpf(2) ** (mp.mpf(ti) / 256)), ulp_err(yb, mp.mpf(2) ** (mp.mpf(float(ti + 96.0)) / 256)))
     assert worst <= 1.5, worst
     assert y[-2, 0] == np.inf and y[-1, 0] == 0.0
 

@@ -37,7 +37,7 @@ def test_c5_shard_full_size():
     assert eu - 3.0 * ese < am < 100.0                      # American put >= European put on the same paths
     c, cse = a.price_european(P, 100.0, RB["r"], T, True)    # martingale through put-call parity on the same paths
     fwd = math.exp(RB["r"] * T) * (c - eu) + 100.0
-    assert abs(fwd - 100.0 * math.exp(RB["r"] * T)) <= 2.5 * math.exp(RB["r"] * T) * math.hypot(cse, ese)
+    assert abs(fwd - 100.0 * math.exp(RB["r"] * T)) <= 2.0 * math.exp(RB["r"] * T) * math.hypot(cse, ese)
     P.free()
     a.trim()
 

@@ -166,12 +166,13 @@ def test_european_call_c1_config_vs_black_scholes_and_oracle(eng, orc):
     assert abs(mean - ref) <= 2.0 * se, (mean, se, ref)
     # same number from the stored matrix, from the put side, and from the oracle on the same paths
     mean2, se2 = eng.price_european(P, 100.0, 0.04, 1.0, False)       # different payoff -> re-reads last row
-    # (secondary statistic on the same draws: 3 sigma; seed 20251031 happens to sit at z = 2.6 here,
-    #  the oracle gives the identical number -- see test below -- so it is sampling noise, not bias)
-    assert abs(mean2 - bs_price(100.0, 100.0, 0.04, 0.2, 1.0, call=False)) <= 3.0 * se2
     host = P.to_host_step_major()
     om, ose = orc.price_european(host, 100.0, 0.04, 1.0, True)
     assert abs(om - mean) <= 1e-11 * abs(om) and abs(ose - se) <= 1e-9 * ose
+    # The put on the same draws is the oracle's number too (no separate bar here: this seed's put happens to sit 2.6 of
+    # its standard errors from Black-Scholes; calls AND puts are judged over 24 seeds in tests/test_gpu_statistics.py)
+    om2, ose2 = orc.price_european(host, 100.0, 0.04, 1.0, False)
+    assert abs(om2 - mean2) <= 1e-11 * abs(om2) and abs(ose2 - se2) <= 1e-9 * ose2
     Q = eng.gbm(SEED, 100.0, 0.04, 0.2, DT, 252, n)                    # unfused path, same draws
     mean3, se3 = eng.price_european(Q, 100.0, 0.04, 1.0, True)
     assert abs(mean3 - mean) <= 1e-12 * mean and abs(se3 - se) <= 1e-9 * se
@@ -188,7 +189,7 @@ def test_gbm_martingale_property_large(eng):
     p, pse = eng.price_european(P, 100.0, 0.04, 1.0, False)
     fwd = math.exp(0.04) * (c - p) + 100.0
     se = math.exp(0.04) * math.hypot(cse, pse)
-    assert abs(fwd - 100.0 * math.exp(0.04)) <= 2.5 * se
+    assert abs(fwd - 100.0 * math.exp(0.04)) <= 2.0 * se
     P.free()
 
 
@@ -273,7 +274,7 @@ def test_rbergomi_martingale_and_mixing_price(eng, orc):
     c, cse = eng.price_european(P, 100.0, RB["r"], T, True)
     p, pse = eng.price_european(P, 100.0, RB["r"], T, False)
     fwd = math.exp(RB["r"] * T) * (c - p) + 100.0
-    assert abs(fwd - 100.0 * math.exp(RB["r"] * T)) <= 2.5 * math.exp(RB["r"] * T) * math.hypot(cse, pse)
+    assert abs(fwd - 100.0 * math.exp(RB["r"] * T)) <= 2.0 * math.exp(RB["r"] * T) * math.hypot(cse, pse)
     ref_paths = orc.generate_paths_mt(RB["S0"], RB["r"], RB["xi"], RB["H"], RB["eta"], RB["rho"], steps, 60_000, 11)
     rm, rse = orc.price_european(ref_paths, 100.0, RB["r"], T, True, step_major=False)
     z = abs(c - rm) / math.hypot(cse, rse)
@@ -981,7 +982,7 @@ def test_full_size_c2_properties(eng):
     P.free()
     assert abs(c - bs_price(100.0, 100.0, 0.04, 0.2, 1.0)) <= 2.0 * cse
     fwd = math.exp(0.04) * (c - p) + 100.0
-    assert abs(fwd - 100.0 * math.exp(0.04)) <= 2.5 * math.exp(0.04) * math.hypot(cse, pse)
+    assert abs(fwd - 100.0 * math.exp(0.04)) <= 2.0 * math.exp(0.04) * math.hypot(cse, pse)
     disc = math.exp(-0.04)
     parts = []
     for b in (0, n // 2):
@@ -1010,7 +1011,7 @@ def test_full_size_c3_c4_properties(eng):
     p, pse = eng.price_european(R, 100.0, 0.04, T, False)
     R.free()
     fwd = math.exp(0.04 * T) * (c - p) + 100.0
-    assert abs(fwd - 100.0 * math.exp(0.04 * T)) <= 2.5 * math.exp(0.04 * T) * math.hypot(cse, pse)
+    assert abs(fwd - 100.0 * math.exp(0.04 * T)) <= 2.0 * math.exp(0.04 * T) * math.hypot(cse, pse)
     assert math.isfinite(c) and c > 0
 
 
@@ -1019,12 +1020,11 @@ def test_rough_regime_prices_and_structure_vs_compiled_reference_sample(eng, ste
     """C4 / C5 parameters (H = 0.1, eta = 1.9) against the committed sample of the COMPILED REFERENCE
     (tests/golden/rough_regime_reference.json: 2e6 / 1e6 paths through the reference's own private members,
     oracle/gen_rough_fixture.py).  North-star bar: |price - ref| <= 2 MC standard errors (combined), call and put, on
-    4M device paths.  Beyond the prices, the statistics that see the Volterra / forward-variance structure in the price
-    matrix itself -- E[S_T], realised variance, clustering of squared returns at lags 1, 8, 64 -- on 400k downloaded
-    device paths, within 3 combined standard errors each (five more comparisons per step count)."""
+    4M device paths.  (The statistics that see the Volterra / forward-variance structure in the price matrix itself --
+    E[S_T], realised variance, clustering of squared returns -- are judged over 16 seeds in tests/test_gpu_statistics.py.)"""
     import json
     import os
-    from oracle.binding import STAT_NAMES, mean_and_se, path_stats
+    from oracle.binding import STAT_NAMES
     fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "rough_regime_reference.json")))
     p, fix = fx["params"], fx["samples"][str(steps)]
     fm, fse = np.array(fix["mean"]), np.array(fix["std_err"])
@@ -1035,42 +1035,3 @@ def test_rough_regime_prices_and_structure_vs_compiled_reference_sample(eng, ste
         P.free()
         z = (m - fm[idx]) / math.hypot(se, fse[idx])
         assert abs(z) <= 2.0, (steps, STAT_NAMES[idx], m, se, fm[idx], fse[idx], z)
-    s, s2, cnt = np.zeros(7), np.zeros(7), 0
-    for c in range(4):
-        P = eng.rbergomi(SEED + 1, p["S0"], p["r"], p["xi"], p["H"], p["eta"], p["rho"], DT, steps, 100_000, path_begin=c * 100_000)
-        a, b, k = path_stats(P.to_host_step_major(), K)
-        P.free()
-        s, s2, cnt = s + a, s2 + b, cnt + k
-    m, se = mean_and_se(s, s2, cnt)
-    z = (m - fm[:7]) / np.hypot(se, fse[:7])
-    assert (np.abs(z) <= 3.0).all(), (steps, dict(zip(STAT_NAMES, np.round(z, 2))), m, se)
-
-
-def test_lsm_prices_vs_independent_reference_samples(eng, orc):
-    """SURVEY 8(d) parity statistic for the LSM configs: z = |price_gpu - price_ref| / std-err <= 2, where price_ref is
-    the CPU-restated reference LSM on INDEPENDENT samples (different generator, different draws): C3-shaped (GBM,
-    50 dates) against eight oracle samples of 1e5 paths, C5-shaped (rBergomi, reference-faithful "mt" generator:
-    fresh mt19937 streams, complex FFT per path) against six samples of 2e4 paths.  The spread BETWEEN the samples
-    is the error bar: the per-path standard error of an LSM price ignores the noise of the shared regression
-    coefficients and is about half of it at these sizes."""
-    def spread(prices):
-        a = np.asarray(prices)
-        return float(a.mean()), float(a.std(ddof=1)) / math.sqrt(len(a))
-
-    ref, ref_se = spread([orc.lsm_price(orc.paths_gbm(1000 + k, 100.0, 0.04, 0.2, 0.02, 50, 0, 100_000), 0.04, 100.0, 1.0, 0.02,
-                                        False, 2) for k in range(8)])
-    P = eng.gbm(SEED, 100.0, 0.04, 0.2, 0.02, 50, 1_000_000)
-    am, ase = eng.price_lsm(P, 0.04, 100.0, 1.0, 0.02, False, 2)
-    P.free()
-    z = abs(am - ref) / math.hypot(2.0 * ase, ref_se)
-    assert z <= 2.0, ("C3", am, ase, ref, ref_se, z)
-
-    steps, T = 64, 64 * DT
-    ref, ref_se = spread([orc.lsm_price(orc.generate_paths_mt(RB["S0"], RB["r"], RB["xi"], RB["H"], RB["eta"], RB["rho"], steps,
-                                                              20_000, 2024 + k), RB["r"], 100.0, T, DT, False, 2, step_major=False)
-                          for k in range(6)])
-    R = eng.rbergomi(SEED, RB["S0"], RB["r"], RB["xi"], RB["H"], RB["eta"], RB["rho"], DT, steps, 400_000)
-    am, ase = eng.price_lsm(R, RB["r"], 100.0, T, DT, False, 2)
-    R.free()
-    z = abs(am - ref) / math.hypot(2.0 * ase, ref_se)
-    assert z <= 2.0, ("C5-shaped", am, ase, ref, ref_se, z)

@@ -126,27 +126,36 @@ def log_table(path):
         f.write("};\n} }\n")
 
 
+SINCOS_BITS = 10
+EXP2_BITS = 8
+
+
 def sincos_table(path):
-    """512 directions (cos, sin)(2 pi i / 512) for fastmath.hpp::sincos_table."""
+    """1024 directions (cos, sin)(2 pi i / 1024) for fastmath.hpp::sincos_table.  (512 until round 3: with the remainder
+    angle below 2 pi / 1024 the cosine series needs no d^6 term -- one fp64 FMA fewer per Box-Muller pair.)"""
+    n = 1 << SINCOS_BITS
     with open(path, "a") as f:
-        f.write("\n// {cos, sin}(2 pi i / 512), i = 0..511 (correctly rounded)\n")
-        f.write("namespace mcg { namespace fm {\nstatic const double SINCOS_TAB_HOST[1024] = {\n")
-        for i in range(512):
-            th = 2 * mp.pi * i / 512
+        f.write(f"\n// {{cos, sin}}(2 pi i / {n}), i = 0..{n - 1} (correctly rounded)\n")
+        f.write(f"namespace mcg {{ namespace fm {{\nstatic const double SINCOS_TAB_HOST[{2 * n}] = {{\n")
+        for i in range(n):
+            th = 2 * mp.pi * i / n
             f.write(f"    {float(mp.cos(th)).hex()}, {float(mp.sin(th)).hex()},\n")
         f.write("};\n} }\n")
-    d = 2 * mp.pi / 512
-    print("sincos table: delta max", mp.nstr(d, 8), " sin trunc err", mp.nstr(d ** 7 / 5040, 3), " cos trunc err", mp.nstr(d ** 8 / 40320, 3))
+    d = 2 * mp.pi / n
+    print("sincos table: delta max", mp.nstr(d, 8), " sin trunc err (after d^5)", mp.nstr(d ** 7 / 5040, 3),
+          " cos trunc err (after d^4)", mp.nstr(d ** 6 / 720, 3))
     print("  2pi*2^-24 =", float(2 * mp.pi / 2 ** 24).hex(), " pi*2^-24 =", float(mp.pi / 2 ** 24).hex())
 
 
 def exp2_table(path):
-    """2^(j/64), j = 0..63 (correctly rounded) for fastmath.hpp::exp2_pair."""
+    """2^(j/256), j = 0..255 (correctly rounded) for fastmath.hpp::exp2_pair.  (64 entries until round 3: on a quarter
+    of the interval the remaining factor needs a polynomial one degree lower.)"""
+    n = 1 << EXP2_BITS
     with open(path, "a") as f:
-        f.write("\n// 2^(j/64), j = 0..63 (correctly rounded)\n")
-        f.write("namespace mcg { namespace fm {\nstatic const double EXP2_TAB_HOST[64] = {\n")
-        for j in range(64):
-            f.write(f"    {float(mp.mpf(2) ** (mp.mpf(j) / 64)).hex()},\n")
+        f.write(f"\n// 2^(j/{n}), j = 0..{n - 1} (correctly rounded)\n")
+        f.write(f"namespace mcg {{ namespace fm {{\nstatic const double EXP2_TAB_HOST[{n}] = {{\n")
+        for j in range(n):
+            f.write(f"    {float(mp.mpf(2) ** (mp.mpf(j) / n)).hex()},\n")
         f.write("};\n} }\n")
 
 
@@ -176,11 +185,11 @@ for bound, deg in ((mp.mpf("0.1"), 6), (mp.mpf("0.125"), 7)):
     print(f"exp-small q deg {deg} on |a|<={bound}: max rel err {mp.nstr(err, 5)} (2^{mp.nstr(mp.log(err, 2), 5)})")
     show(f"EXP_SMALL_Q deg {deg}", qr)
 
-# (c) 2^(g/64) = 1 + g h(g) on |g| <= 1/2 (exp2_pair: t = n/64 + g/64 with n = rint(64 t); the table supplies 2^(j/64))
+# (c) 2^(g/256) = 1 + g h(g) on |g| <= 1/2 (exp2_pair: t = n/256 + g/256 with n = rint(256 t); the table supplies 2^(j/256))
 Lg = mp.mpf("0.5") * mp.mpf("1.0002")
-for deg in (4,):
-    h = cheb_fit(lambda g: (mp.mpf(2) ** (g / 64) - 1) / g if abs(g) > mp.mpf('1e-20') else mp.log(2) / 64, -Lg, Lg, deg)
+for deg in (3,):
+    h = cheb_fit(lambda g: (mp.mpf(2) ** (g / 256) - 1) / g if abs(g) > mp.mpf('1e-20') else mp.log(2) / 256, -Lg, Lg, deg)
     hr = rounded(h)
-    err = max_err(lambda g: 1 + g * horner(hr, g), lambda g: mp.mpf(2) ** (g / 64), -Lg, Lg)
-    print(f"exp2/64 h deg {deg}: max rel err {mp.nstr(err, 5)} (2^{mp.nstr(mp.log(err, 2), 5)})")
+    err = max_err(lambda g: 1 + g * horner(hr, g), lambda g: mp.mpf(2) ** (g / 256), -Lg, Lg)
+    print(f"exp2/256 h deg {deg}: max rel err {mp.nstr(err, 5)} (2^{mp.nstr(mp.log(err, 2), 5)})")
     show(f"EXP2_H deg {deg}", hr)
