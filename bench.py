@@ -23,9 +23,10 @@ plus "roofline", "cpu_baseline" (N=1 only) and "extra.configs":
   * N = 1 (default run): C3, C4 and the C5 shard timed once each after the headline loop, the three other pricers of
     the driver on the C3 matrix and the batched driver rows (SURVEY 8f), the cold first launch of C2;
   * N > 1: BASELINE.json configs[4] (C5: rBergomi American put LSM, 8M paths per GPU -- N = 8 is the 64M-path job)
-    timed after the C2 loop through each collective in turn -- the node mailbox in host memory ("shm"), the same in
-    peer-mapped device memory ("ipc") and the built-in RCCL communicator ("rccl") -- with the slowest and the fastest
-    rank's ms per pass, the collective that actually ran and the number of ranks its communicator has SEEN.
+    timed after the C2 loop without any exchange ("none": every rank prices its own shard, the baseline) and through each
+    collective in turn -- the node mailbox in host memory ("shm"), the same in peer-mapped device memory ("ipc") and the
+    built-in RCCL communicator ("rccl") -- with the slowest and the fastest rank's ms per pass, the collective that
+    actually ran and the number of ranks its communicator has SEEN.
 """
 from __future__ import annotations
 
@@ -357,7 +358,8 @@ def c5_sharded_rows(args, mc, N, dist, torch, device, stream, rank, world) -> li
     for want in [c for c in args.c5_collectives.split(",") if c]:
         e5 = mc.PathEngine(device, stream=stream)
         try:
-            got = install_collective(e5, mc, want, dist, torch, rank, world)
+            got = "none (every rank prices its own shard alone: a local price, the baseline the routes below add their exchange to)" \
+                if want == "none" else install_collective(e5, mc, want, dist, torch, rank, world)
             info = e5.comm_info()
 
             def one_pass():
@@ -416,7 +418,9 @@ def main() -> None:
                     help="auto: shm (node-local shared memory; the LSM sweeps exchange inside the kernel) for c5, rccl for c2; "
                          "ipc: shm with the in-kernel mailbox in peer-mapped device memory")
     ap.add_argument("--c5-paths", type=int, default=8_000_000, help="paths per GPU of the C5 rows under extra.configs at N > 1")
-    ap.add_argument("--c5-collectives", default="shm,ipc,rccl", help="collectives the C5 rows at N > 1 are timed through")
+    ap.add_argument("--c5-collectives", default="none,shm,ipc,rccl",
+                    help="collectives the C5 rows at N > 1 are timed through (none: every rank prices its own shard alone -- the "
+                         "time the exchange adds nothing to)")
     ap.add_argument("--backend", default=os.environ.get("MCG_DIST_BACKEND", "nccl"), choices=["nccl", "gloo"],
                     help="torch.distributed backend; gloo lets several ranks share one GPU (rehearsal only)")
     args = ap.parse_args()

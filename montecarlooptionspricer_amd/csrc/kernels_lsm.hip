@@ -1441,7 +1441,9 @@ int run_lsm(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double maturit
     int dates_left = M;
     int64_t batch = nb >= 5 ? 2 * (int64_t)M : (int64_t)M + 4 + M / 32;  // (orders >= 4: the reference's rank rule truncates on every date)
     bool first = true;
-    while (dates_left > 0) {
+    for (int round = 0; dates_left > 0; ++round) {
+        // (two batches always suffice: the second holds two launches for every date that is left)
+        if (round >= 3) return fail(MCG_ERR_HIP, "LSM per-date sweep did not advance (%d dates left)", dates_left);
         for (int64_t k = 0; k < batch; ++k) {
             if (!first && ctx->allreduce) {
                 if (ctx->allreduce(ctx->allreduce_user, a.msg, nm, (void*)ctx->stream) != 0)

@@ -175,12 +175,14 @@ def test_bench_two_ranks_carries_c2_and_c5_with_the_ranks_seen(tmp_path):
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["global_paths"] == 2 * c2_paths
     assert out["config"]["comm"]["kind"] == "callback"      # C2's collective here: torch.distributed behind mcg_set_allreduce
     rows = out["extra"]["configs"]
-    assert [r["collective_requested"] for r in rows] == ["shm", "ipc", "rccl"], rows
+    assert [r["collective_requested"] for r in rows] == ["none", "shm", "ipc", "rccl"], rows
     for r in rows:
         assert "error" not in r, r
         assert r["global_paths"] == 2 * c5_paths
         assert r["ms_per_pass_slowest_rank"] >= r["ms_per_pass_fastest_rank"] > 0
-    shm, ipc, rccl = rows
+    alone, shm, ipc, rccl = rows
+    assert alone["comm"]["kind"] == "none" and alone["lsm_one_launch"]        # the baseline: no exchange, a local price
+    rows = rows[1:]
     assert shm["collective"] == "shm" and shm["comm"]["kind"] == "shm" and shm["comm"]["seen_ranks_min_over_ranks"] == 2
     assert ipc["collective"] == "ipc" and ipc["comm"]["kind"] == "shm+peer-memory mailbox" and ipc["comm"]["seen_ranks_min_over_ranks"] == 2
     assert shm["comm"]["n_ranks"] == 2 and ipc["comm"]["n_ranks"] == 2
