@@ -65,15 +65,25 @@ struct LsmDateArgs {
     double* msg;          // in: the moments the state's phase says (summed over the ranks); out: those of the next launch
     double* state;        // {date j the next launch works on (< 0: done), phase, centre of a refinement}
     double* partials;     // [NM][gridDim.x] (moment-major: the reducing workgroup reads contiguously)
-    unsigned* ticket;     // workgroups done; the last one resets it
+    unsigned* ticket;     // workgroups done, per group of 64 and of the groups; the last ones reset them (lsm_date_tail)
 };
 
 // Tail of a launch.  HAVE: this launch produced partial moments m.  Returns true in the last workgroup to get here,
-// after it has summed all partials into msg (fixed order: wave w the moments w, w+4, ..; lane l the workgroups l,
-// l+64, ..) -- or zeroed msg when there were none.
+// after it has left the sum of all partials in msg (or zeros when there were none).  Two levels, so that neither a
+// thousand workgroups finishing together queue up at ONE ticket nor one workgroup reads a thousand partials: workgroups
+// form groups of LSM_DATE_GROUP (by blockIdx); the last of a group sums the group's partials (lane l the l-th member,
+// then the wavefront butterfly) and draws the top ticket; the last of those sums the group sums.  The summation order is
+// fixed by blockIdx alone, whatever the order of arrival.
+constexpr int LSM_DATE_GROUP = 64;
+constexpr int LSM_DATE_MAX_GROUPS = 32;  // tickets: [0 .. 32) the groups', [32] the top one
+
 template <int NM>
 __device__ __forceinline__ bool lsm_date_tail(const LsmDateArgs& a, bool have, double (&m)[NM], double* red, unsigned* sm_last) {
-    const unsigned G = gridDim.x;
+    const unsigned G = gridDim.x, n_groups = (G + LSM_DATE_GROUP - 1) / LSM_DATE_GROUP;
+    const unsigned grp = blockIdx.x / LSM_DATE_GROUP, first = grp * LSM_DATE_GROUP;
+    const unsigned members = min((unsigned)LSM_DATE_GROUP, G - first);
+    double* gsum = a.partials + (int64_t)NM * G;  // [NM][n_groups]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (have) block_sum<NM, 4>(m, red);
     if (threadIdx.x == 0) {
         if (have) {
@@ -81,22 +91,36 @@ __device__ __forceinline__ bool lsm_date_tail(const LsmDateArgs& a, bool have, d
             for (int q = 0; q < NM; ++q) lsm_st_shared(a.partials + (int64_t)q * G + blockIdx.x, m[q]);
             __builtin_amdgcn_s_waitcnt(0);  // the write-through stores are acknowledged before this workgroup's ticket is drawn
         }
-        *sm_last = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == G - 1 ? 1u : 0u;
+        *sm_last = __hip_atomic_fetch_add(a.ticket + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1 ? 1u : 0u;
     }
     __syncthreads();
     if (*sm_last == 0) return false;
-    // every workgroup has drawn its ticket, hence sent its partials and -- long before -- read msg and the state
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // last of its group: every member has sent its partials (and, long before, read msg and the state)
+    if (have) {
+        for (int q = wave; q < NM; q += 4) {
+            double s = (unsigned)lane < members ? lsm_ld_shared(a.partials + (int64_t)q * G + first + lane) : 0.0;
+            s = wave_sum(s);
+            if (lane == 0) lsm_st_shared(gsum + (int64_t)q * n_groups + grp, s);
+        }
+        __builtin_amdgcn_s_waitcnt(0);  // every wave's group sums are acknowledged before the barrier lets thread 0 draw the top ticket
+    }
+    __syncthreads();  // (sm_last is rewritten below)
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(a.ticket + grp, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_s_waitcnt(0);
+        *sm_last = __hip_atomic_fetch_add(a.ticket + LSM_DATE_MAX_GROUPS, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_groups - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    if (*sm_last == 0) return false;
     for (int q = wave; q < NM; q += 4) {
         double s = 0.0;
         if (have) {
-#pragma unroll 8
-            for (unsigned b = lane; b < G; b += 64) s += lsm_ld_shared(a.partials + (int64_t)q * G + b);
+            s = (unsigned)lane < n_groups ? lsm_ld_shared(gsum + (int64_t)q * n_groups + lane) : 0.0;
             s = wave_sum(s);
         }
         if (lane == 0) a.msg[q] = s;
     }
-    if (threadIdx.x == 0) __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) __hip_atomic_store(a.ticket + LSM_DATE_MAX_GROUPS, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return true;
 }
 
@@ -1359,6 +1383,7 @@ int run_lsm(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double maturit
     const int64_t N = P->n_paths;
     const int M = P->n_steps + 1;
     int grid = (int)std::min<int64_t>((N + 511) / 512, (int64_t)ctx->n_cus * date_kernel_occupancy(nb));  // 512 paths per workgroup and trip
+    grid = std::min(grid, LSM_DATE_GROUP * LSM_DATE_MAX_GROUPS);
     if (grid < 1) grid = 1;
 
     if (N >= 1 && N <= 1024 && !ctx->allreduce && nb <= 9) {  // one launch for the whole sweep
@@ -1407,7 +1432,7 @@ int run_lsm(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double maturit
     }
     rc = ensure_cap(ctx, &ctx->lsm_v, &ctx->lsm_v_cap, (size_t)std::max<int64_t>(N, 1) + 1);  // (a whole two-path unit at the end)
     if (rc) return rc;
-    rc = ensure_cap(ctx, &ctx->partials, &ctx->partials_cap, (size_t)grid * (size_t)std::max(nm, 2));
+    rc = ensure_cap(ctx, &ctx->partials, &ctx->partials_cap, ((size_t)grid + LSM_DATE_MAX_GROUPS) * (size_t)std::max(nm, 2));
     if (rc) return rc;
 
     const double disc = std::exp(-r * dt);  // LSMPricer.cpp:46,:69,:92
@@ -1433,7 +1458,7 @@ int run_lsm(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double maturit
     ctx->h_scalars[SC_LSM_STATE + LSM_ST_PHASE] = (double)LSM_PH_INIT;
     ctx->h_scalars[SC_LSM_STATE + LSM_ST_MU] = 0.0;
     MCG_HIP(hipMemcpyAsync(a.state, ctx->h_scalars + SC_LSM_STATE, 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    MCG_HIP(hipMemsetAsync(a.ticket, 0, sizeof(double), ctx->stream));
+    MCG_HIP(hipMemsetAsync(a.ticket, 0, (LSM_DATE_MAX_GROUPS + 1) * sizeof(unsigned), ctx->stream));
     MCG_HIP(hipMemsetAsync(a.msg, 0, 48 * sizeof(double), ctx->stream));
 
     // M launches when no date asks for a re-fit, one more per date that does (orders >= 4: every date); a few spare
