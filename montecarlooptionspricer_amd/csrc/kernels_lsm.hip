@@ -4,13 +4,14 @@
 // continuation value is carried backwards, :85) with three MI355X-first changes that leave the
 // fitted values -- and therefore every V[i][j] -- unchanged up to rounding:
 //   * only one value vector V (n_paths doubles) is live instead of Values[N][M] (:35);
-//   * per exercise date ONE streaming kernel does "update V with date j's fit" and "accumulate the
-//     regression moments of date j-1" (reads S_j, S_{j-1}, V; writes V: 32 B/path/date);
-//   * the least-squares fit (:61-76, Eigen bdcSvd on raw monomials) is solved from the
-//     (p+1)x(p+1) moment matrix of the SCALED regressor x = S/K - 1 (same polynomial space => same
-//     fitted values; cond drops from ~1e8 to ~1e2), via a Jacobi eigen-decomposition pseudo-inverse
-//     so rank-deficient dates (one ITM path, all paths equal at j=0) still give the projection.
-//     The moments are the only cross-GPU exchange: 3p+2 doubles per date through ctx->allreduce.
+//   * the date's prices and V stay on chip wherever they fit: the whole sweep is ONE launch of co-operating workgroups
+//     up to 8.37M paths per GPU (k_lsm_coop / k_lsm_big: 8 or 16 B per path and date), else one streaming kernel per
+//     exercise date (k_lsm_date: reads S_j, S_{j-1}, V; writes V: 32 B per path and date);
+//   * the least-squares fit (:61-76, Eigen bdcSvd on raw monomials) is solved from the (p+1)x(p+1) moment matrix of the
+//     SCALED regressor x = S/K - 1 (same polynomial space => same fitted values; cond drops from ~1e8 to ~1e2) where the
+//     reference's solve is at full numerical rank, and re-fitted by the reference's own rank rule from the moments about
+//     the mean regressor where it is not (lsm_device.hpp).  The moments are the only cross-GPU exchange: 3p+2 doubles
+//     per date, inside the one launch (node mailbox) or between two launches (ctx->allreduce).
 // HBM-bound streaming; no MFMA (the "GEMM" A^T A is a (p+1)^2 moment accumulation, done in
 // registers with wavefront-shuffle reductions).
 #include <cstdio>
@@ -23,8 +24,6 @@
 #include "mcg_internal.hpp"
 
 namespace mcg {
-
-enum { UPD_INIT = 0, UPD_REGRESS = 1, UPD_DISCOUNT = 2 };
 
 // Agent-scope (sc1) accesses: through to the device's coherence point one by one, no fence (see the one-launch sweeps below).
 __device__ __forceinline__ void lsm_st_shared(double* p, double v) {

@@ -353,7 +353,7 @@ __device__ inline void lsm_solve_one(const double* moments, int nb, double min_c
 // The whole backward sweep in ONE launch for a small path count (n <= 1024: the reference's production
 // calls price 250 paths per option row, src/core/PredictionGen.cpp:719): one 256-thread block, up to four
 // paths per thread with V in registers, per date a block reduction of the regression moments, the solve on
-// thread 0, the coefficients handed over through LDS (PPT = paths per thread: 1 up to 256 paths, else 4).  Same arithmetic as k_lsm_sweep / lsm_solve_one;
+// thread 0, the coefficients handed over through LDS (PPT = paths per thread: 1 up to 256 paths, else 4).  Same arithmetic as k_lsm_date / lsm_solve_one;
 // only the summation order of the moments differs.  out3 = {sum V, sum V^2, n}.
 template <int NB, int PPT>
 __device__ __forceinline__ void lsm_small_body(const double* data, int64_t ld, int n, int n_cols, double K,
