@@ -361,10 +361,23 @@ __device__ __forceinline__ void box_muller_pair_affine_scaled(uint32_t wa, uint3
 // amp0, amp1: factors of the first and of the second pair (the rBergomi spectrum's amplitudes a_k: folded into the radius,
 // one multiply per pair instead of one per deviate); 1 for plain deviates.
 template <bool EAGER = false>
+__device__ __forceinline__ void normal_quad_words(const Philox4 w, const Tables* tab, double (&z)[4], double amp0, double amp1);
+
+template <bool EAGER = false>
 __device__ __forceinline__ void normal_quad_fast(uint32_t k0, uint32_t k1, uint64_t path, uint32_t block,
                                                  uint32_t stream, const Tables* tab, double (&z)[4], double amp0 = 1.0,
                                                  double amp1 = 1.0) {
-    const Philox4 w = philox4x32_10((uint32_t)path, (uint32_t)(path >> 32), block, stream, k0, k1);
+    normal_quad_words<EAGER>(philox4x32_10((uint32_t)path, (uint32_t)(path >> 32), block, stream, k0, k1), tab, z, amp0, amp1);
+}
+// the same from the hoisted per-path part of the block function (philox_lane_setup(path, stream, k1))
+template <bool EAGER = false>
+__device__ __forceinline__ void normal_quad_fast(uint32_t k0, uint32_t k1, const PhiloxLane& L, uint32_t block, const Tables* tab,
+                                                 double (&z)[4], double amp0 = 1.0, double amp1 = 1.0) {
+    normal_quad_words<EAGER>(philox4x32_10_path(L, block, k0, k1), tab, z, amp0, amp1);
+}
+
+template <bool EAGER>
+__device__ __forceinline__ void normal_quad_words(const Philox4 w, const Tables* tab, double (&z)[4], double amp0, double amp1) {
     if constexpr (!EAGER) {
         box_muller_pair_affine(w.w0, w.w1, tab, amp0, 0.0, z[0], z[1]);
         box_muller_pair_affine(w.w2, w.w3, tab, amp1, 0.0, z[2], z[3]);

@@ -234,6 +234,9 @@ __device__ __forceinline__ void rb_fft_block(const RbArgs& a, const RbLds& L, in
     live_b = col_a + 1 < a.n_paths;
     const uint64_t id_a = a.path_begin + (uint64_t)col_a, id_b = id_a + 1;
     const uint64_t pair_id = id_a >> 1;
+    // the parts of Philox rounds 1-2 that depend on the path and the key only (the block numbers below depend on the lane)
+    const PhiloxLane rng_vol = philox_lane_setup(pair_id, STREAM_VOL, a.k1);
+    const PhiloxLane rng_a = philox_lane_setup(id_a, STREAM_PRICE, a.k1), rng_b = philox_lane_setup(id_b, STREAM_PRICE, a.k1);
 
     // ---- spectrum, in bit-reversed order: slot (t, v) of lane g holds Y_k, k = rev(4(tG + g) + v) ----
     double xr[4 * NT], xi[4 * NT];
@@ -246,8 +249,7 @@ __device__ __forceinline__ void rb_fft_block(const RbArgs& a, const RbLds& L, in
         for (int bq = 0; bq < NT / 2; ++bq) {
             double z[4];
             const double a0 = L.amp[k_base + 2 * bq], a1 = L.amp[k_base + 2 * bq + 1];  // folded into the pairs' radii
-            fm::normal_quad_fast<RB_EAGER_SPECTRUM>(a.k0, a.k1, pair_id, (uint32_t)((k_base >> 1) + bq), STREAM_VOL, tabs, z,
-                                                    a0, a1);
+            fm::normal_quad_fast<RB_EAGER_SPECTRUM>(a.k0, a.k1, rng_vol, (uint32_t)((k_base >> 1) + bq), tabs, z, a0, a1);
             const int t0 = rb_rev<LT>(2 * bq), t1 = rb_rev<LT>(2 * bq + 1);
             xr[t0 * 4 + v] = z[0];
             xi[t0 * 4 + v] = z[1];
@@ -392,7 +394,7 @@ __device__ __forceinline__ void rb_fft_block(const RbArgs& a, const RbLds& L, in
             {
                 double z[4];
                 // (sqrt(xi dt) folded into the pairs' radii: z = sqrt(xi dt) N(0,1))
-                fm::normal_quad_fast<RB_EAGER_PRICE>(a.k0, a.k1, id_a, (uint32_t)(nl >> 2), STREAM_PRICE, tabs, z, sq_xi_dt, sq_xi_dt);
+                fm::normal_quad_fast<RB_EAGER_PRICE>(a.k0, a.k1, rng_a, (uint32_t)(nl >> 2), tabs, z, sq_xi_dt, sq_xi_dt);
 #pragma unroll
                 for (int v = 0; v < 4; ++v)  // (r - v/2) dt + sqrt(v dt) N,  v = xi e^2
                     ia[v] = fma(ia[v], z[v], fma(neg_half_xi_dt, ia[v] * ia[v], r_dt));
@@ -400,7 +402,7 @@ __device__ __forceinline__ void rb_fft_block(const RbArgs& a, const RbLds& L, in
             __builtin_amdgcn_sched_barrier(0);
             {
                 double z[4];
-                fm::normal_quad_fast<RB_EAGER_PRICE>(a.k0, a.k1, id_b, (uint32_t)(nl >> 2), STREAM_PRICE, tabs, z, sq_xi_dt, sq_xi_dt);
+                fm::normal_quad_fast<RB_EAGER_PRICE>(a.k0, a.k1, rng_b, (uint32_t)(nl >> 2), tabs, z, sq_xi_dt, sq_xi_dt);
 #pragma unroll
                 for (int v = 0; v < 4; ++v) ib[v] = fma(ib[v], z[v], fma(neg_half_xi_dt, ib[v] * ib[v], r_dt));
             }
