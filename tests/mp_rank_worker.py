@@ -83,9 +83,17 @@ def main() -> None:
     res["rb_euro_put"] = eng.price_european(P, 100.0, RB["r"], T, False)
     P.free()
 
-    res["allreduce_calls"] = {"3": calls.count(3), "8": calls.count(8)}
     res["comm"] = eng.comm_info()
     res["peer_mailbox"] = bool(peer) if mode != "gloo" else False
+    if mode == "ipc":   # back to the host mailbox (collective over the ranks) and once more: the same bits
+        assert eng.shm_peer_mailbox(False) is False
+        res["comm_after_disable"] = eng.comm_info()
+        b, c = shard_range(JOBS["lsm_paths"], rank, world)
+        P = eng.gbm(SEED, 100.0, 0.04, 0.2, 0.02, JOBS["lsm_steps"], c, path_begin=b)
+        res["gbm_lsm_host_mailbox"] = eng.price_lsm(P, 0.04, 100.0, 1.0, 0.02, False, 2)
+        P.free()
+        b, c = shard_range(JOBS["rb_paths"], rank, world, align=2)
+    res["allreduce_calls"] = {"3": calls.count(3), "8": calls.count(8)}
     res["shard"] = [b, c]
     eng.close()
     with open(f"{out_path}.{rank}", "w") as f:

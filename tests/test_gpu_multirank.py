@@ -134,6 +134,8 @@ def test_two_rank_processes_equal_single_rank(tmp_path, mode):
             assert res["comm"]["n_ranks"] == world and res["comm"]["seen_ranks"] == world and res["comm"]["rank"] == r
             if mode.startswith("ipc"):   # every rank exported, opened and pinged: the mailbox is in device memory
                 assert res["peer_mailbox"] and res["comm"]["kind"] == "shm+peer-memory mailbox", "\n".join(logs)
+                # ... and switched back to the host mailbox the same job gives the same bits
+                assert res["comm_after_disable"]["kind"] == "shm" and res["gbm_lsm_host_mailbox"] == res["gbm_lsm"]
             else:
                 assert res["comm"]["kind"] == "shm"
         else:   # forced time-out: the void sweep (1 launch) is discarded on BOTH ranks, the per-date kernels answer

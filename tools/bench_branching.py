@@ -1,0 +1,14 @@
+import sys,time
+sys.path.insert(0,'.')
+import montecarlooptionspricer_amd as mc
+from montecarlooptionspricer_amd import _native as N
+e=mc.PathEngine(0); e.timing_enable(True)
+for n,steps in ((1_000_000,50),(4_000_000,50),(250_000,252)):
+    P=e.gbm(20251031,100.0,0.04,0.2,1.0/steps,steps,n)
+    ex=list(range(steps))
+    e.price_branching(P,0.04,100.0,1.0,1.0/steps,False,10,ex,7)
+    e.timing_reset()
+    r=[e.price_branching(P,0.04,100.0,1.0,1.0/steps,False,10,ex,7) for _ in range(3)]
+    ms,c=e.timing_get(N.K_BRANCHING)
+    print(n,steps,'branching kernels ms per call',round(ms/3,3),'launches',c//3,r[0])
+    P.free()
