@@ -47,7 +47,7 @@ enum mcg_kernel {
     MCG_K_GBM = 0,        /* GBM path generation (+ fused payoff partials)  */
     MCG_K_RBERGOMI = 1,   /* rBergomi path generation                       */
     MCG_K_PAYOFF = 2,     /* terminal payoff reduction over a stored matrix */
-    MCG_K_LSM_SWEEP = 3,  /* LSM per-date update+moments kernels            */
+    MCG_K_LSM_SWEEP = 3,  /* LSM sweep: the one launch, or the queued per-date sequence (launches, gaps, collectives) */
     MCG_K_LSM_SOLVE = 4,  /* LSM per-date reduce+solve kernels              */
     MCG_K_TRANSPOSE = 5,  /* layout change for the host class API           */
     MCG_K_ASYM = 6,       /* AsymptoticAnalysis boundary scan               */

@@ -1371,7 +1371,6 @@ static int date_kernel_occupancy(int nb) {
 }
 
 static void launch_date(mcg_ctx* ctx, int nb, int grid, const LsmDateArgs& a) {
-    TimedLaunch t(ctx, MCG_K_LSM_SWEEP);
     hipLaunchKernelGGL(date_kernel(nb), dim3(grid), dim3(256), 0, ctx->stream, a);
 }
 
@@ -1468,13 +1467,17 @@ int run_lsm(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double maturit
     for (int round = 0; dates_left > 0; ++round) {
         // (two batches always suffice: the second holds two launches for every date that is left)
         if (round >= 3) return fail(MCG_ERR_HIP, "LSM per-date sweep did not advance (%d dates left)", dates_left);
-        for (int64_t k = 0; k < batch; ++k) {
-            if (!first && ctx->allreduce) {
-                if (ctx->allreduce(ctx->allreduce_user, a.msg, nm, (void*)ctx->stream) != 0)
-                    return fail(MCG_ERR_COMM, "all-reduce of regression moments failed");
+        {
+            // timing: ONE event pair around the queued sequence (launches, the gaps and the collectives between them)
+            TimedLaunch t(ctx, MCG_K_LSM_SWEEP, batch);
+            for (int64_t k = 0; k < batch; ++k) {
+                if (!first && ctx->allreduce) {
+                    if (ctx->allreduce(ctx->allreduce_user, a.msg, nm, (void*)ctx->stream) != 0)
+                        return fail(MCG_ERR_COMM, "all-reduce of regression moments failed");
+                }
+                first = false;
+                launch_date(ctx, nb, grid, a);
             }
-            first = false;
-            launch_date(ctx, nb, grid, a);
         }
         MCG_HIP(hipGetLastError());
         MCG_HIP(hipMemcpyAsync(ctx->h_scalars + SC_LSM_STATE, a.state, 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));

@@ -81,7 +81,7 @@ int ensure_cap(mcg_ctx* ctx, double** buf, size_t* cap, size_t need_doubles) {
 }
 
 // ---- timing ----------------------------------------------------------------------------------
-TimedLaunch::TimedLaunch(mcg_ctx* c, int k) : ctx(c), kernel(k), on(c->timing) {
+TimedLaunch::TimedLaunch(mcg_ctx* c, int k, int64_t launches) : ctx(c), kernel(k), on(c->timing) {
     if (!on) return;
     if (!ctx->ev_free.empty()) {
         ev = ctx->ev_free.back();
@@ -97,6 +97,7 @@ TimedLaunch::TimedLaunch(mcg_ctx* c, int k) : ctx(c), kernel(k), on(c->timing) {
             return;
         }
     }
+    ev.launches = launches;
     (void)hipEventRecord(ev.a, ctx->stream);
 }
 
@@ -113,7 +114,7 @@ static int timing_collect(mcg_ctx* ctx) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, kv.second.a, kv.second.b) == hipSuccess) {
             ctx->t_total[kv.first] += ms;
-            ctx->t_count[kv.first] += 1;
+            ctx->t_count[kv.first] += kv.second.launches;
         }
         ctx->ev_free.push_back(kv.second);
     }

@@ -33,6 +33,7 @@ struct PoolBuf {
 
 struct EventPair {
     hipEvent_t a, b;
+    int64_t launches;  // kernel launches the pair brackets (1, or a whole queued sequence: TimedLaunch)
 };
 
 struct ShmComm;  // comm_shm.cpp: node-local collective over POSIX shared memory
@@ -124,7 +125,9 @@ struct TimedLaunch {
     int kernel;
     EventPair ev{};
     bool on;
-    TimedLaunch(mcg_ctx* c, int k);
+    // launches > 1: ONE event pair around a queued sequence of that many launches (the per-date LSM route: an event
+    // pair per launch costs 9 us of the 60 a date takes); the reported time then includes what lies between them
+    TimedLaunch(mcg_ctx* c, int k, int64_t launches = 1);
     ~TimedLaunch();
 };
 
