@@ -38,6 +38,27 @@ __global__ __launch_bounds__(64) void k_peer_ping(PeerPingArgs a) {
     }
 }
 
+// Re-arm the rows of ranks 0 .. n-1 in the first `rounds` slots of a mailbox with the reserved NaN: one small launch
+// (a hipMemsetD32Async over the slots' full width -- 16 ranks' rows -- is split by the runtime into ~80 fill kernels).
+__global__ __launch_bounds__(256) void k_peer_arm(unsigned long long* mbox, int rounds, int n, unsigned long long sentinel) {
+    const int per_round = n * SHM_ROW_DOUBLES;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)rounds * per_round) return;
+    const int64_t q = i / per_round, e = i % per_round;
+    mbox[q * (SHM_MAX_RANKS * SHM_ROW_DOUBLES) + e] = sentinel;
+}
+
+int peer_arm(mcg_ctx* ctx, double* mbox, int rounds, int n, uint64_t sentinel) {
+    const int64_t total = (int64_t)rounds * n * SHM_ROW_DOUBLES;
+    hipLaunchKernelGGL(k_peer_arm, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
+                       reinterpret_cast<unsigned long long*>(mbox), rounds, n, (unsigned long long)sentinel);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) {
+        (void)hipGetLastError();
+        return 1;
+    }
+    return 0;
+}
+
 // returns 0 when every peer's token arrived, non-zero otherwise (time-out, wrong token, or a HIP error)
 int peer_ping(mcg_ctx* ctx, double* const* peers, int n, int rank) {
     PeerPingArgs a;

@@ -271,10 +271,8 @@ int shm_arm_mailbox(mcg_ctx* ctx, int rounds, uint64_t sentinel_bits) {
     ShmComm* c = ctx->shm;
     if (!c) return fail(MCG_ERR_COMM, "no shared-memory communicator");
     if (rounds > SHM_MAX_ROUNDS) return fail(MCG_ERR_INVALID, "too many exchange rounds for the mailbox");
-    if (c->peer_active) {  // the whole of this rank's own mailbox: the peers push into it
-        const size_t words = (size_t)rounds * SHM_MAX_RANKS * SHM_ROW_DOUBLES * 2;
-        if (hipMemsetD32Async((hipDeviceptr_t)c->peer_own, (int)(uint32_t)sentinel_bits, words, ctx->stream) != hipSuccess ||
-            hipStreamSynchronize(ctx->stream) != hipSuccess) {
+    if (c->peer_active) {  // every rank's rows of this rank's own mailbox: the peers push into it
+        if (peer_arm(ctx, c->peer_own, rounds, c->n_ranks, sentinel_bits) != 0) {
             shm_poison(ctx);
             return fail(MCG_ERR_HIP, "re-arming the peer-memory mailbox failed");
         }

@@ -145,6 +145,7 @@ int shm_n_ranks(mcg_ctx* ctx);
 int shm_attached(mcg_ctx* ctx);
 bool shm_peer_active(mcg_ctx* ctx);
 int peer_ping(mcg_ctx* ctx, double* const* peers, int n, int rank);  // comm_peer.hip
+int peer_arm(mcg_ctx* ctx, double* mbox, int rounds, int n, uint64_t sentinel);  // comm_peer.hip: 0 = armed and synchronised
 
 int paths_new(mcg_ctx* ctx, int64_t n_paths, int n_steps, uint64_t path_begin, mcg_paths** out);
 
