@@ -167,8 +167,8 @@ def valu_profile(name: str):
 
 
 def extra_configs(eng, N) -> list:
-    """C3, C4 and the C5 shard on this GPU, once each (one untimed pass, then 3 timed), after the headline loop:
-    ms per pass, Mpaths/s, the dominant kernel's average launch time and what it achieves against the HBM roofline
+    """C3, C4 and the C5 shard on this GPU, once each (one untimed pass, then 3 timed for the wall time and 3 more with
+    per-kernel HIP events), after the headline loop: ms per pass, Mpaths/s, the dominant kernel's average launch time and what it achieves against the HBM roofline
     (SURVEY 8d algorithmic bytes) and against the VALU issue rate (instruction count from the committed PMC profile)."""
     reps = 3
     out = []
@@ -202,12 +202,19 @@ def extra_configs(eng, N) -> list:
     for name, fn, paths, steps, alg in specs:
         fn()
         eng.synchronize()
-        eng.timing_reset()
+        # wall time WITHOUT the library's event timing (a HIP-event pair per launch costs ~9 us: 7 % of a C3 pass), then
+        # the same passes again with it, for the per-kernel breakdown
+        eng.timing_enable(False)
         t0 = time.perf_counter()
         for _ in range(reps):
             res = fn()
         eng.synchronize()
         ms = (time.perf_counter() - t0) / reps * 1e3
+        eng.timing_enable(True)
+        eng.timing_reset()
+        for _ in range(reps):
+            fn()
+        eng.synchronize()
         kernels = {}
         for k, kname in N.KERNEL_NAMES.items():
             tot, cnt = eng.timing_get(k)
