@@ -243,6 +243,9 @@ int mcg_compat_asymptotic_price(const double* row_major, int64_t n_paths, int n_
 /* ---- measurement ------------------------------------------------------------------------ */
 /* When enabled, every kernel launch is bracketed by HIP events on the ctx stream. */
 int mcg_timing_enable(mcg_ctx* ctx, int on);
+/* Which kernels are bracketed while timing is enabled: bit k = enum mcg_kernel k (default: all).  An event pair costs
+ * several microseconds on the stream, so a measurement of one kernel's duration inside a timed loop selects that one. */
+int mcg_timing_select(mcg_ctx* ctx, unsigned mask);
 int mcg_timing_reset(mcg_ctx* ctx);
 int mcg_timing_get(mcg_ctx* ctx, int kernel /* enum mcg_kernel */, double* total_ms,
                    int64_t* launches);

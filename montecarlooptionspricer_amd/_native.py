@@ -87,6 +87,7 @@ def load_library():
     newer("mcg_lsm_one_launch_reset", [vp])
     newer("mcg_debug_lsm_hooks", [vp, C.c_longlong, C.c_int])
     newer("mcg_comm_info", [vp] + [C.POINTER(C.c_int)] * 4)
+    newer("mcg_timing_select", [vp, C.c_uint])
     L.mcg_paths_gbm.argtypes = [vp, C.c_uint64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int,
                                 C.c_uint64, C.c_int64, C.POINTER(vp)]
     L.mcg_paths_gbm_payoff.argtypes = [vp, C.c_uint64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int,

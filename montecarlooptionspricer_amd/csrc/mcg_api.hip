@@ -81,7 +81,7 @@ int ensure_cap(mcg_ctx* ctx, double** buf, size_t* cap, size_t need_doubles) {
 }
 
 // ---- timing ----------------------------------------------------------------------------------
-TimedLaunch::TimedLaunch(mcg_ctx* c, int k, int64_t launches) : ctx(c), kernel(k), on(c->timing) {
+TimedLaunch::TimedLaunch(mcg_ctx* c, int k, int64_t launches) : ctx(c), kernel(k), on(c->timing && ((c->timing_mask >> k) & 1u)) {
     if (!on) return;
     if (!ctx->ev_free.empty()) {
         ev = ctx->ev_free.back();
@@ -636,6 +636,12 @@ int mcg_rbergomi_spectrum(double H, double eta, double dt, int n_steps, double* 
 int mcg_timing_enable(mcg_ctx* ctx, int on) {
     if (!ctx) return fail(MCG_ERR_INVALID, "ctx is NULL");
     ctx->timing = on != 0;
+    return MCG_OK;
+}
+
+int mcg_timing_select(mcg_ctx* ctx, unsigned mask) {
+    if (!ctx) return fail(MCG_ERR_INVALID, "ctx is NULL");
+    ctx->timing_mask = mask;
     return MCG_OK;
 }
 

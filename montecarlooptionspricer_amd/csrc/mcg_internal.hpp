@@ -80,6 +80,7 @@ struct mcg_ctx {
 
     // timing
     bool timing = false;
+    unsigned timing_mask = ~0u;  // bit k: kernel k is bracketed while timing is on (mcg_timing_select)
     std::vector<mcg::EventPair> ev_free;
     std::vector<std::pair<int, mcg::EventPair>> ev_live;
     double t_total[MCG_K_COUNT] = {0};

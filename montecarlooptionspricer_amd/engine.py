@@ -304,6 +304,11 @@ class PathEngine:
     def timing_enable(self, on: bool = True) -> None:
         check(self._L.mcg_timing_enable(self._ctx, int(on)))
 
+    def timing_select(self, kernels=None) -> None:
+        """Bracket only these kernels (_native.K_*) while timing is enabled; None: all of them (mcg_timing_select)."""
+        mask = 0xFFFFFFFF if kernels is None else sum(1 << int(k) for k in kernels)
+        check(self._L.mcg_timing_select(self._ctx, mask))
+
     def timing_reset(self) -> None:
         check(self._L.mcg_timing_reset(self._ctx))
 
