@@ -25,6 +25,24 @@ RB = dict(S0=100.0, r=0.04, xi=0.04, H=0.1, eta=1.9, rho=-0.9)
 JOBS = dict(euro_paths=300_001, lsm_paths=200_001, lsm_steps=50, rb_paths=100_003, rb_steps=64)
 
 
+def near_degenerate_matrix(seed, n_total, n_itm, base, spread, K=100.0):
+    """[n_total][3] price matrix (path-major) whose middle date has exactly n_itm in-the-money paths (put), within a
+    relative spread `spread` of `base`: the reference's rank threshold decides that date's fit (tests/test_gpu_parity.py
+    has the single-GPU versions of this case)."""
+    import numpy as np
+    rs = np.random.RandomState(seed)
+    m = np.empty((n_total, 3))
+    m[:, 0] = 1.05 * K
+    m[:, 1] = K * (1.02 + 0.2 * rs.rand(n_total))
+    m[:, 2] = K * (0.7 + 0.5 * rs.rand(n_total))
+    idx = rs.choice(n_total, n_itm, replace=False)
+    m[idx, 1] = base * (1.0 + spread * rs.uniform(-1.0, 1.0, n_itm))
+    return m
+
+
+DEGENERATE = [(11, 5000, 3, 90.0, 1e-4), (12, 5000, 4, 99.9, 1e-6), (13, 5000, 2, 60.0, 1e-3)]   # (seed, paths, itm, base, spread)
+
+
 def main() -> None:
     rank, world, port, out_path = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
     mode = sys.argv[5] if len(sys.argv) > 5 else "gloo"
@@ -82,6 +100,17 @@ def main() -> None:
     res["one_launch_enabled"] = eng.lsm_one_launch_enabled()
     res["rb_euro_put"] = eng.price_european(P, 100.0, RB["r"], T, False)
     P.free()
+
+    # dates the first solve does not trust, sharded: the re-fit needs a second, data-dependent reduction over the ranks
+    # (one more mailbox round inside the one launch; one more launch + all-reduce on the per-date route)
+    res["degenerate_lsm"] = []
+    for seed, n_total, n_itm, base, spread in DEGENERATE:
+        m = near_degenerate_matrix(seed, n_total, n_itm, base, spread)
+        b, c = shard_range(n_total, rank, world)
+        P = eng.from_host(m[b:b + c])
+        res["degenerate_lsm"].append(eng.price_lsm(P, 0.04, 100.0, 1.0, 0.5, False, 2)[0])
+        P.free()
+    b, c = shard_range(JOBS["rb_paths"], rank, world, align=2)
 
     res["comm"] = eng.comm_info()
     res["peer_mailbox"] = bool(peer) if mode != "gloo" else False

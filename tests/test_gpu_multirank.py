@@ -118,6 +118,15 @@ def test_two_rank_processes_equal_single_rank(tmp_path, mode):
     P.free()
     e.close()
 
+    # near-degenerate dates: the sharded job must reproduce the reference's rank rule (oracle, 1e-6) on every route
+    from mp_rank_worker import DEGENERATE, near_degenerate_matrix
+    from oracle.binding import Oracle
+    orc = Oracle()
+    want_deg = [orc.lsm_price(near_degenerate_matrix(*d), 0.04, 100.0, 1.0, 0.5, False, 2, step_major=False) for d in DEGENERATE]
+    for r, res in enumerate(ranks):
+        for got, want, d in zip(res["degenerate_lsm"], want_deg, DEGENERATE):
+            assert abs(got - want) <= 1e-6 * abs(want), (mode, r, d, got, want)
+
     for r, res in enumerate(ranks):                          # every rank holds the GLOBAL price
         for got, want, tol in ((res["euro"], want_euro, 1e-12), (res["rb_euro_put"], want_rb_eu, 1e-12),
                                (res["gbm_lsm"], want_lsm, 1e-9), (res["rb_lsm"], want_rb, 1e-9)):
@@ -125,7 +134,10 @@ def test_two_rank_processes_equal_single_rank(tmp_path, mode):
             assert abs(got[1] - want[1]) <= max(tol, 1e-9) * abs(want[1]), (r, got, want)
         if mode == "gloo":
             # one all-reduce BETWEEN two launches of the per-date kernel, nothing else per date
-            assert res["allreduce_calls"] == {"3": 4, "8": per_date_launches(JOBS["lsm_steps"]) + per_date_launches(JOBS["rb_steps"]) - 2}
+            # (plus the three near-degenerate matrices: two dates each, one final sum each)
+            assert res["allreduce_calls"] == {"3": 4 + len(DEGENERATE),
+                                              "8": per_date_launches(JOBS["lsm_steps"]) + per_date_launches(JOBS["rb_steps"]) - 2
+                                                   + len(DEGENERATE) * (per_date_launches(2) - 1)}
             assert res["gbm_lsm_sweep_launches"] == per_date_launches(JOBS["lsm_steps"]) + 1   # + the final sums
             assert res["comm"]["kind"] == "callback"
         elif mode in ("shm", "shm4", "ipc", "ipc4"):
