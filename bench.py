@@ -589,8 +589,9 @@ def main() -> None:
             workload = ("C5: rBergomi (H=0.1, eta=1.9) American put, Longstaff-Schwartz order 2, 8M paths x 252 steps per GPU "
                         "(8 GPUs: the 64M-path job), fp64 matrix written then swept backwards")
             sharding = (f"contiguous even-aligned path ids over {world} rank(s); per exercise date 8 regression moments are "
-                        "summed over the ranks (shm: inside the one-launch sweep through the node mailbox; rccl/torch: "
-                        "one all-reduce between the per-date kernels), then 3 doubles of final sums")
+                        "summed over the ranks (shm / ipc: inside the one-launch sweep through the node mailbox in host memory / in "
+                        "peer-mapped device memory; rccl / torch: one all-reduce between two launches of the per-date kernel), then "
+                        "3 doubles of final sums")
             parity = {"price": price, "std_err": se}
             kernel_name = "k_rbergomi_fft"
         out = {
@@ -621,7 +622,8 @@ def main() -> None:
                 "design_bytes_per_pass": design,   # what this execution shape moves: 16 B one-launch (k_lsm_big), 32 B per-date kernels
                 "hbm_frac_of_design_bytes": design / max(sweep_ms / per_pass * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS,
                 "shape": "one launch (V in registers; beyond 2.09M paths the matrix streams through an LDS-DMA ring)" if one_launch
-                         else "per-date kernels (one all-reduce of 8 moments per exercise date)"}
+                         else "per-date route: one kernel + one all-reduce of 8 moments per exercise date; sweep_ms is the span of the "
+                              "queued sequence (launches, dispatch gaps, collectives)"}
             pmc5 = os.path.join(ROOT, "profiles", "r03_c5_pmc_traffic.json")
             if os.path.exists(pmc5) and count == 8_000_000 and n_steps == 252:
                 try:
