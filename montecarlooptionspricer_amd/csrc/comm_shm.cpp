@@ -54,6 +54,7 @@ struct ShmHeader {
     std::atomic<uint64_t> hello[SHM_MAX_RANKS], ack[SHM_MAX_RANKS];
     double host_slots[SHM_MAX_RANKS][64];
     unsigned char ipc_handle[SHM_MAX_RANKS][64];  // hipIpcMemHandle_t of each rank's peer-memory mailbox
+    char pci_bus_id[SHM_MAX_RANKS][64];           // its GPU ("0000:c1:00.0"), for the peer-access check before the open
 };
 static_assert(sizeof(ShmHeader) % 64 == 0, "mailbox starts cache-line aligned");
 static_assert(sizeof(hipIpcMemHandle_t) <= 64, "IPC handle fits its slot");
@@ -424,6 +425,11 @@ extern "C" int mcg_comm_shm_peer_mailbox(mcg_ctx* ctx, int enable, int* active) 
                 continue;
             }
             std::memcpy(c->hdr->ipc_handle[c->rank], &h, sizeof h);
+            std::memset(c->hdr->pci_bus_id[c->rank], 0, sizeof c->hdr->pci_bus_id[0]);
+            if (hipDeviceGetPCIBusId(c->hdr->pci_bus_id[c->rank], (int)sizeof c->hdr->pci_bus_id[0] - 1, ctx->device) != hipSuccess) {
+                (void)hipGetLastError();
+                c->hdr->pci_bus_id[c->rank][0] = 0;
+            }
             c->peer_own = (double*)p;
             c->peer_memory_kind = names[k];
             ok = 1;
@@ -439,6 +445,18 @@ extern "C" int mcg_comm_shm_peer_mailbox(mcg_ctx* ctx, int enable, int* active) 
     c->peer_map[c->rank] = c->peer_own;
     for (int r = 0; r < c->n_ranks && ok; ++r) {
         if (r == c->rank) continue;
+        // A peer on another GPU this process can see must be reachable by peer access (a mapping that is not would fault
+        // the first kernel that touches it); a GPU this process cannot see at all is left to the open's own verdict.
+        int peer_dev = -1, can = 1;
+        if (c->hdr->pci_bus_id[r][0] && hipDeviceGetByPCIBusId(&peer_dev, c->hdr->pci_bus_id[r]) == hipSuccess) {
+            if (peer_dev != ctx->device && (hipDeviceCanAccessPeer(&can, ctx->device, peer_dev) != hipSuccess || !can)) {
+                (void)hipGetLastError();
+                ok = 0;
+                break;
+            }
+        } else {
+            (void)hipGetLastError();
+        }
         hipIpcMemHandle_t h;
         std::memcpy(&h, c->hdr->ipc_handle[r], sizeof h);
         void* p = nullptr;
