@@ -411,6 +411,40 @@ def c5_sharded_rows(args, mc, N, dist, torch, device, stream, rank, world) -> li
     return rows
 
 
+def c5_rows_in_child_job(args, dist, rank: int, world: int):
+    """Every rank of this job starts `bench.py --c5-child` as a child process (same RANK / LOCAL_RANK / WORLD_SIZE, a
+    rendezvous port of its own); rank 0 returns the rows its child printed, or one row that says what went wrong."""
+    import socket
+    import subprocess
+    box = [None]
+    if rank == 0:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            box[0] = sk.getsockname()[1]
+    dist.broadcast_object_list(box, src=0)
+    env = dict(os.environ, MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"), MASTER_PORT=str(box[0]),
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    for k in list(env):   # the child is not an elastic worker of the parent's agent
+        if k.startswith("TORCHELASTIC_") or k in ("TORCH_NCCL_ASYNC_ERROR_HANDLING",):
+            env.pop(k)
+    cmd = [sys.executable, os.path.abspath(__file__), "--c5-child", "--gpus", str(world), "--backend", args.backend,
+           "--c5-paths", str(args.c5_paths), "--c5-collectives", args.c5_collectives]
+    rows = None
+    try:
+        p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+        if rank == 0:
+            lines = [ln for ln in p.stdout.splitlines() if ln.startswith("[")]
+            if p.returncode == 0 and lines:
+                rows = json.loads(lines[-1])
+            else:
+                rows = [{"config": "C5", "error": f"child job failed (exit code {p.returncode})", "stderr_tail": p.stderr[-1500:]}]
+    except subprocess.TimeoutExpired:
+        if rank == 0:
+            rows = [{"config": "C5", "error": "child job timed out after 900 s"}]
+    dist.barrier()
+    return rows
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -430,6 +464,8 @@ def main() -> None:
                          "time the exchange adds nothing to)")
     ap.add_argument("--backend", default=os.environ.get("MCG_DIST_BACKEND", "nccl"), choices=["nccl", "gloo"],
                     help="torch.distributed backend; gloo lets several ranks share one GPU (rehearsal only)")
+    ap.add_argument("--c5-child", action="store_true",
+                    help="(internal) this process is one rank of the child job that times the C5 rows of an N > 1 run")
     args = ap.parse_args()
     if args.paths <= 0:
         args.paths = 10_000_000 if args.config == "c2" else 8_000_000
@@ -466,6 +502,17 @@ def main() -> None:
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device), timeout=limit)
         else:
             dist.init_process_group(backend="gloo", rank=rank, world_size=world, timeout=limit)
+
+    if args.c5_child:   # one rank of the child job: the C5 rows, nothing else; rank 0 prints them as one JSON list
+        if os.environ.get("MCG_BENCH_C5_CHILD_FAIL") == "1":   # test hook: the child job dies; the parent's line must survive it
+            os._exit(3)
+        stream = torch.cuda.current_stream().cuda_stream
+        rows = c5_sharded_rows(args, mc, N, dist, torch, device, stream, rank, world)
+        if rank == 0:
+            print(json.dumps(rows), file=json_out, flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
 
     S0, K, r, sigma, dt = 100.0, 100.0, 0.04, 0.2, DT
     n_steps, seed = args.time_steps, SEED
@@ -655,10 +702,13 @@ def main() -> None:
             except Exception as e:
                 out["extra"] = {"configs": [], "error": str(e)}
     # BASELINE.json configs[4] at this N, through every collective in turn (all ranks take part; rank 0 reports)
+    # They run in a CHILD job (every rank starts one child process; the children form their own process group): these
+    # routes have never run on more than one GPU, and whatever goes wrong in them -- an exception, a time-out, a device
+    # fault that takes the process with it -- must not cost the headline line, which is complete at this point.
     c5_rows = None
     if dist is not None and args.config == "c2" and not args.no_extra:
         eng.trim()
-        c5_rows = c5_sharded_rows(args, mc, N, dist, torch, device, stream, rank, world)
+        c5_rows = c5_rows_in_child_job(args, dist, rank, world)
     if rank == 0:
         if c5_rows is not None:
             out.setdefault("extra", {})["configs"] = c5_rows

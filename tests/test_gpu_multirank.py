@@ -220,3 +220,19 @@ def test_bench_two_ranks_carries_c2_and_c5_with_the_ranks_seen(tmp_path):
     for r in rows:
         assert abs(r["price"] - want_c5[0]) <= 1e-9 * want_c5[0], (r["collective"], r["price"], want_c5)
         assert abs(r["std_err"] - want_c5[1]) <= 1e-9 * want_c5[1]
+
+
+def test_bench_headline_survives_a_failing_c5_child_job():
+    """The C5 rows of an N > 1 run are timed in a child job of their own: if that job dies (forced here), the parent's JSON
+    line -- the C2 headline -- is still printed, with a row that says what happened."""
+    root = os.path.dirname(HERE)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--backend", "gloo", "--paths", "500000", "--c5-paths", "100000"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MCG_BENCH_C5_CHILD_FAIL="1")
+    p = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["parity"]["abs_err_over_std_err"] < 4
+    rows = out["extra"]["configs"]
+    assert len(rows) == 1 and "child job failed (exit code 3)" in rows[0]["error"]
