@@ -70,11 +70,16 @@ struct LsmDateArgs {
 // Tail of a launch.  HAVE: this launch produced partial moments m.  Returns true in the last workgroup to get here,
 // after it has left the sum of all partials in msg (or zeros when there were none).  Two levels, so that neither a
 // thousand workgroups finishing together queue up at ONE ticket nor one workgroup reads a thousand partials: workgroups
-// form groups of LSM_DATE_GROUP (by blockIdx); the last of a group sums the group's partials (lane l the l-th member,
-// then the wavefront butterfly) and draws the top ticket; the last of those sums the group sums.  The summation order is
+// form groups of LSM_DATE_GROUP (by blockIdx; the smaller the group, the fewer workgroups meet at one ticket within the
+// same microsecond); the last of a group sums the group's partials (lane l the l-th member, then the wavefront
+// butterfly) and draws the top ticket; the last of those sums the group sums.  The summation order is
 // fixed by blockIdx alone, whatever the order of arrival.
-constexpr int LSM_DATE_GROUP = 64;
-constexpr int LSM_DATE_MAX_GROUPS = 32;  // tickets: [0 .. 32) the groups', [32] the top one
+#ifndef LSM_DATE_GROUP_N
+#define LSM_DATE_GROUP_N 16  // A/B on one box, C5 shard, sweep span per pass: 64 -> 12.08 ms, 32 -> 11.14, 16 -> 10.88
+#endif
+constexpr int LSM_DATE_GROUP = LSM_DATE_GROUP_N;
+constexpr int LSM_DATE_MAX_GROUPS = 2048 / LSM_DATE_GROUP;  // tickets: [0 .. MAX_GROUPS) the groups', [MAX_GROUPS] the top one
+static_assert((LSM_DATE_MAX_GROUPS + 1 + 1) / 2 <= SCALARS_DOUBLES - SC_LSM_TICKET, "the tickets fit the ctx's scalar workspace");
 
 template <int NM>
 __device__ __forceinline__ bool lsm_date_tail(const LsmDateArgs& a, bool have, double (&m)[NM], double* red, unsigned* sm_last) {
@@ -97,7 +102,8 @@ __device__ __forceinline__ bool lsm_date_tail(const LsmDateArgs& a, bool have, d
     // last of its group: every member has sent its partials (and, long before, read msg and the state)
     if (have) {
         for (int q = wave; q < NM; q += 4) {
-            double s = (unsigned)lane < members ? lsm_ld_shared(a.partials + (int64_t)q * G + first + lane) : 0.0;
+            double s = 0.0;
+            for (unsigned l = lane; l < members; l += 64) s += lsm_ld_shared(a.partials + (int64_t)q * G + first + l);
             s = wave_sum(s);
             if (lane == 0) lsm_st_shared(gsum + (int64_t)q * n_groups + grp, s);
         }
@@ -114,7 +120,7 @@ __device__ __forceinline__ bool lsm_date_tail(const LsmDateArgs& a, bool have, d
     for (int q = wave; q < NM; q += 4) {
         double s = 0.0;
         if (have) {
-            s = (unsigned)lane < n_groups ? lsm_ld_shared(gsum + (int64_t)q * n_groups + lane) : 0.0;
+            for (unsigned l = lane; l < n_groups; l += 64) s += lsm_ld_shared(gsum + (int64_t)q * n_groups + l);
             s = wave_sum(s);
         }
         if (lane == 0) a.msg[q] = s;
@@ -129,7 +135,10 @@ __device__ __forceinline__ bool lsm_date_tail(const LsmDateArgs& a, bool have, d
 // its grid-stride units through a ring of LSM_DATE_DEPTH register slots: the loads of the next DEPTH units are always in
 // flight, and the first DEPTH are issued BEFORE the head's solve, so HBM stays busy while thread 0 of every workgroup
 // solves (a quarter of the launch's bytes are on their way by the time the coefficients exist).
-constexpr int LSM_DATE_DEPTH = 3;
+#ifndef LSM_DATE_DEPTH_N
+#define LSM_DATE_DEPTH_N 3
+#endif
+constexpr int LSM_DATE_DEPTH = LSM_DATE_DEPTH_N;
 
 template <int NB>
 __global__ __launch_bounds__(256) void k_lsm_date(LsmDateArgs a) {

@@ -112,7 +112,7 @@ constexpr int SC_COEF = 40;    // [40..60) the LSM coefficient block of the curr
 constexpr int SC_FINAL = 64;   // [64..67) LSM final sums
 constexpr int SC_BARRIER = 72; // [72] 32-bit timeout flag of k_lsm_coop's hand-shake
 constexpr int SC_TICKET = 80;  // [80] 64-bit share ticket of the persistent rBergomi generator (zeroed before each launch)
-constexpr int SC_LSM_TICKET = 160; // [160..177) 33 32-bit "workgroups done" tickets of the per-date LSM kernel (k_lsm_date)
+constexpr int SC_LSM_TICKET = 160; // [160..225) 129 32-bit "workgroups done" tickets of the per-date LSM kernel (k_lsm_date)
 constexpr int SC_LSM_MSG = 96;     // [96..144) per-date LSM message: the 3p+2 <= 47 moments the next launch solves (the all-reduced part)
 constexpr int SC_LSM_STATE = 144;  // [144..147) per-date LSM state: date, phase, centre (kernels_lsm.hip: LSM_ST_*)
 
