@@ -1374,7 +1374,13 @@ static int date_kernel_occupancy(int nb) {
         (void)hipGetLastError();
         occ = 1;
     }
-    occ = std::min(occ, 8);
+    // three per CU even where four fit (orders <= 3): 768 workgroups stream as fast as 1024 and leave fewer partials and
+    // tickets to the tail (C5 shard, span per pass: 10.86 ms at four, 10.69 at three and at two)
+    int want = 3;
+    if (const char* e = std::getenv("MCG_LSM_DATE_WGS_PER_CU")) {  // timing studies: another number
+        if (std::atoi(e) >= 1) want = std::atoi(e);
+    }
+    occ = std::min(occ, want);
     cache[nb].store(occ, std::memory_order_relaxed);
     return occ;
 }
