@@ -172,7 +172,7 @@ int mcg_price_asymptotic(mcg_ctx* ctx, const mcg_paths* paths, double r, double 
 
 /* MartingaleOptimization::PredictOptionPrice (src/models/MartingaleOptimizationPricer.cpp:21-189):
  * 0.5 * (primal + dual) after max_iterations iterations; lower/upper (optional) receive the two bounds.
- * poly_order in [0, 8]; max_iterations <= 0 is MCG_ERR_INVALID with the reference's message.
+ * poly_order in [0, 15]; max_iterations <= 0 is MCG_ERR_INVALID with the reference's message.
  *  */
 int mcg_price_martingale(mcg_ctx* ctx, const mcg_paths* paths, double r, double K, double maturity,
                          double dt, int is_call, int poly_order, int max_iterations, double* price,

@@ -290,9 +290,9 @@ struct LsmRefine {
 __global__ __launch_bounds__(256) void k_lsm_reduce_solve(const double* partials, int n_blocks, int nm, int nb,
                                                           double* moments, double* coef, int do_reduce, int do_solve,
                                                           double min_count, LsmRefine rf) {
-    __shared__ double sm[32];
+    __shared__ double sm[48];
     __shared__ double sm_c[LSM_COEF_STRIDE];
-    __shared__ double sm_ws[lsm_ws_doubles(9)];
+    __shared__ double sm_ws[lsm_ws_doubles(LSM_MAX_NB)];
     if (do_reduce) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         for (int q = wave; q < nm; q += 4) {
@@ -317,9 +317,16 @@ __global__ __launch_bounds__(256) void k_lsm_reduce_solve(const double* partials
                 for (int t = 0; t < LSM_COEF_DOUBLES; ++t) sm_c[t] = 0.0;
                 sm_c[LSM_C_COUNT] = mc[0];
             }
-        } else {
+        } else if (nb <= 9) {
             lsm_solve_one(mc, nb, min_count, rf.request_only ? rf.K : 0.0, sm_c);
             if (!rf.request_only) sm_c[LSM_C_REFINE] = 0.0;
+        } else {  // orders >= 9: the reference's rank rule truncates the raw monomials anyway -- always the centred re-fit
+            for (int t = 0; t < LSM_COEF_DOUBLES; ++t) sm_c[t] = 0.0;
+            sm_c[LSM_C_COUNT] = mc[0];
+            if (rf.request_only && mc[0] >= min_count && mc[0] > 0.0) {
+                sm_c[LSM_C_REFINE] = 1.0;
+                sm_c[LSM_C_HINT] = mc[1] / mc[0];
+            }
         }
     }
     __syncthreads();
@@ -1332,7 +1339,7 @@ static int run_lsm_coop(mcg_ctx* ctx, const mcg_paths* P, double r, double K, do
 // mo_mode: 1 = first pass, leave the refinement request in the coefficient block; 2 = the moments are about mo_mu,
 // solve them with lsm_solve_centered.
 int lsm_reduce_allreduce_solve(mcg_ctx* ctx, int grid, int nm, int nb, double min_count, double K, int mo_mode, double mo_mu) {
-    double* moments = ctx->scalars + SC_MOMENTS;
+    double* moments = ctx->scalars + SC_LSM_MSG;  // (room for the 3p+2 moments + the primal sum of orders up to 15)
     double* coef = ctx->scalars + SC_COEF;
     LsmRefine rf{K, mo_mode == 1, mo_mode == 2, mo_mu};
     if (ctx->allreduce) {

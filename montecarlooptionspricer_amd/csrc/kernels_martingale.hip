@@ -131,7 +131,7 @@ static int run_mo_nb(mcg_ctx* ctx, const MoArgs& a0, int grid, int64_t n_local, 
                      double* lower, double* upper) {
     constexpr int NM = 3 * NB - 1;
     MoArgs a = a0;
-    double* moments = ctx->scalars + SC_MOMENTS;  // NM moments + primal sum (<= 27 doubles)
+    double* moments = ctx->scalars + SC_LSM_MSG;  // NM moments + primal sum (<= 48 doubles)
     double* coef = ctx->scalars + SC_COEF;
     {
         TimedLaunch t(ctx, MCG_K_MARTINGALE);
@@ -174,10 +174,10 @@ static int run_mo_nb(mcg_ctx* ctx, const MoArgs& a0, int grid, int64_t n_local, 
     if (rc) return rc;
     const double dual_fitted = s[0] / n_total;
     // primal sum sits behind the moments (already all-reduced there)
-    MCG_HIP(hipMemcpyAsync(ctx->h_scalars + SC_MOMENTS, moments, (NM + 1) * sizeof(double), hipMemcpyDeviceToHost,
+    MCG_HIP(hipMemcpyAsync(ctx->h_scalars + SC_LSM_MSG, moments, (NM + 1) * sizeof(double), hipMemcpyDeviceToHost,
                            ctx->stream));
     MCG_HIP(hipStreamSynchronize(ctx->stream));
-    const double primal = ctx->h_scalars[SC_MOMENTS + NM] / n_total;
+    const double primal = ctx->h_scalars[SC_LSM_MSG + NM] / n_total;
     (void)coef;
     const double dual = max_iterations >= 2 ? dual_fitted : primal;  // iteration 1 runs with M = 0
     if (lower) *lower = primal;
@@ -204,7 +204,7 @@ int run_martingale(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double 
     if (grid < 1) grid = 1;
     int rc = ensure_cap(ctx, &ctx->weights, &ctx->weights_cap, (size_t)n_cols);
     if (rc) return rc;
-    rc = ensure_cap(ctx, &ctx->partials, &ctx->partials_cap, (size_t)grid * 32);
+    rc = ensure_cap(ctx, &ctx->partials, &ctx->partials_cap, (size_t)grid * 48);
     if (rc) return rc;
     MCG_HIP(hipMemcpyAsync(ctx->weights, disc.data(), (size_t)n_cols * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     MCG_HIP(hipStreamSynchronize(ctx->stream));
@@ -222,17 +222,11 @@ int run_martingale(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double 
     a.coef = ctx->scalars + SC_COEF;
     a.partials = ctx->partials;
     a.center = 0.0;
-    switch (poly_order + 1) {
-        case 1: return run_mo_nb<1>(ctx, a, grid, P->n_paths, max_iterations, price, lower, upper);
-        case 2: return run_mo_nb<2>(ctx, a, grid, P->n_paths, max_iterations, price, lower, upper);
-        case 3: return run_mo_nb<3>(ctx, a, grid, P->n_paths, max_iterations, price, lower, upper);
-        case 4: return run_mo_nb<4>(ctx, a, grid, P->n_paths, max_iterations, price, lower, upper);
-        case 5: return run_mo_nb<5>(ctx, a, grid, P->n_paths, max_iterations, price, lower, upper);
-        case 6: return run_mo_nb<6>(ctx, a, grid, P->n_paths, max_iterations, price, lower, upper);
-        case 7: return run_mo_nb<7>(ctx, a, grid, P->n_paths, max_iterations, price, lower, upper);
-        case 8: return run_mo_nb<8>(ctx, a, grid, P->n_paths, max_iterations, price, lower, upper);
-        default: return run_mo_nb<9>(ctx, a, grid, P->n_paths, max_iterations, price, lower, upper);
-    }
+    typedef int (*Runner)(mcg_ctx*, const MoArgs&, int, int64_t, int, double*, double*, double*);
+    static const Runner runners[LSM_MAX_NB] = {run_mo_nb<1>,  run_mo_nb<2>,  run_mo_nb<3>,  run_mo_nb<4>,  run_mo_nb<5>,  run_mo_nb<6>,
+                                               run_mo_nb<7>,  run_mo_nb<8>,  run_mo_nb<9>,  run_mo_nb<10>, run_mo_nb<11>, run_mo_nb<12>,
+                                               run_mo_nb<13>, run_mo_nb<14>, run_mo_nb<15>, run_mo_nb<16>};
+    return runners[poly_order](ctx, a, grid, P->n_paths, max_iterations, price, lower, upper);
 }
 
 }  // namespace mcg

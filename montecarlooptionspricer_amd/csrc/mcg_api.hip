@@ -584,7 +584,7 @@ int mcg_price_martingale(mcg_ctx* ctx, const mcg_paths* P, double r, double K, d
     if (P->ctx != ctx) return fail(MCG_ERR_INVALID, "paths belong to a different ctx");
     if (P->n_paths < 1 && !ctx->allreduce) return fail(MCG_ERR_EMPTY_PATHS, "MartingaleOptimization: Empty pricePaths.");
     if (max_iterations <= 0) return fail(MCG_ERR_INVALID, "MartingaleOptimization: maxIterations must be positive.");
-    if (poly_order < 0 || poly_order > 8) return fail(MCG_ERR_INVALID, "poly_order must be in [0,8] (got %d)", poly_order);
+    if (poly_order < 0 || poly_order > 15) return fail(MCG_ERR_INVALID, "poly_order must be in [0,15] (got %d)", poly_order);
     MCG_HIP(hipSetDevice(ctx->device));
     return run_martingale(ctx, P, r, K, maturity, dt, is_call, poly_order, max_iterations, price, lower, upper);
 }

@@ -107,7 +107,6 @@ namespace mcg {
 constexpr int SCALARS_DOUBLES = 256;
 // layout of ctx->scalars (doubles)
 constexpr int SC_SUMS = 0;     // [0..3)  sum, sumsq, n
-constexpr int SC_MOMENTS = 8;  // [8..8+26) LSM moments (<= 3*8+2)
 constexpr int SC_COEF = 40;    // [40..60) the LSM coefficient block of the current date (lsm_device.hpp: LSM_C_*)
 constexpr int SC_FINAL = 64;   // [64..67) LSM final sums
 constexpr int SC_BARRIER = 72; // [72] 32-bit timeout flag of k_lsm_coop's hand-shake

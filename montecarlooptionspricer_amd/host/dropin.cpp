@@ -199,7 +199,7 @@ double MartingaleOptimization::PredictOptionPrice(const std::vector<std::vector<
     if (pricePaths.empty() || pricePaths[0].empty())
         throw std::runtime_error("MartingaleOptimization: Empty pricePaths.");                      // :31-33
     if (maxIterations <= 0) throw std::runtime_error("MartingaleOptimization: maxIterations must be positive.");  // :34-36
-    if (polyOrder < 0 || polyOrder > 8) throw std::invalid_argument("MartingaleOptimization: polyOrder must be in [0, 8]");
+    if (polyOrder < 0 || polyOrder > 15) throw std::invalid_argument("MartingaleOptimization: polyOrder must be in [0, 15]");
     PathsGuard own;
     mcg_paths* P = device_matrix(pricePaths, "MartingaleOptimization: ragged pricePaths.", own);
     double price = 0.0;

@@ -763,7 +763,7 @@ def test_asymptotic_matches_reference_goldens_and_oracle(eng, orc):
 # MartingaleOptimization
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("is_call,poly,iters", [(False, 2, 5), (True, 2, 5), (False, 3, 2), (False, 2, 1), (False, 0, 4),
-                                                (False, 4, 5), (False, 6, 3), (True, 8, 5)])
+                                                (False, 4, 5), (False, 6, 3), (True, 8, 5), (False, 10, 5), (True, 15, 2)])
 def test_martingale_matches_oracle(eng, orc, is_call, poly, iters):
     """Orders >= 4: Eigen's rank threshold truncates the raw monomials of the refit (MartingaleOptimizationPricer.cpp:166);
     the device re-fits those about the samples' mean and reproduces the truncated solve (lsm_solve_centered), tolerance
@@ -773,7 +773,7 @@ def test_martingale_matches_oracle(eng, orc, is_call, poly, iters):
     for maturity in (40 * DT, 25.5 * DT):
         got = eng.price_martingale(P, 0.04, 100.0, maturity, DT, is_call, poly, iters)
         want = orc.martingale_price(host, 0.04, 100.0, maturity, DT, is_call, poly, iters)
-        assert np.allclose(got, want, rtol=1e-8 if poly < 4 else 2e-6, atol=1e-12), (got, want)
+        assert np.allclose(got, want, rtol=1e-8 if poly < 4 else (2e-6 if poly <= 8 else 5e-6), atol=1e-12), (got, want)
     P.free()
 
 
