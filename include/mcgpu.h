@@ -197,14 +197,15 @@ typedef struct mcg_row {
     int is_call;
 } mcg_row;
 
-/* Prices n_rows option rows in six launches: n_paths (<= 256; the driver uses 250) rBergomi paths per row,
+/* Prices n_rows option rows in six launches: n_paths (the driver uses 250) rBergomi paths per row,
  * then AsymptoticAnalysis, BranchingProcesses(num_branches, exercise dates 0..n_steps-1), LSM(poly_order) and
  * MartingaleOptimization(poly_order, max_iterations) on them.  out[4*i + {0,1,2,3}] = the four prices of row i
  * in the driver's column order (asymPrice, branchPrice, lsmPriceVal, martinPrice, :809-814).  Rows the driver
  * would answer with zeros (no steps, degenerate estimates, sigma <= 0, strike <= 0) get zeros.
  * Row i uses Philox path ids (i << 32) + p of `seed`: its prices equal the single-contract entry points
  * called with path_begin = i << 32 -- and a row of more than 1020 steps (four years of trading days) IS priced through
- * them, after the batch, one row at a time.  poly_order in [0, 4]. */
+ * them, after the batch, one row at a time -- as is every row of a call with n_paths > 256 or poly_order > 4 (the row
+ * kernels' limits).  poly_order in [0, 15]. */
 int mcg_batch_price_rows(mcg_ctx* ctx, const mcg_row* rows, int64_t n_rows, int n_paths, double r, double dt,
                          int num_branches, int poly_order, int max_iterations, uint64_t seed, double* out);
 

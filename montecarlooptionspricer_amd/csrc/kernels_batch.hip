@@ -414,9 +414,10 @@ int run_batch_rows(mcg_ctx* ctx, const mcg_row* rows, int64_t n_rows, int n_path
                   std::isfinite(s.xi) && s.H >= 0.0 && std::isfinite(s.H) && std::isfinite(s.eta) &&
                   std::fabs(s.rho) <= 1.0 && s.strike > 0.0 && std::isfinite(s.strike) && s.sigma > 0.0 &&
                   std::isfinite(s.maturity);
-        // A row longer than the row kernels' LDS tables reach (more than four years of trading days) is priced after the
-        // batch through the single-contract entry points, on the same Philox path ids: never answered with zeros.
-        if (d.valid && s.n_steps > BATCH_MAX_STEPS) {
+        // A row longer than the row kernels' LDS tables reach (more than four years of trading days), or any row of a call
+        // with more than 256 paths per row or an order above 4, is priced after the batch through the single-contract
+        // entry points, on the same Philox path ids: never refused, never answered with zeros.
+        if (d.valid && (s.n_steps > BATCH_MAX_STEPS || n_paths > 256 || poly_order > 4)) {
             long_rows.push_back(i);
             d.valid = 0;
         }

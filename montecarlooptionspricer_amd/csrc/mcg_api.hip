@@ -605,8 +605,10 @@ int mcg_batch_price_rows(mcg_ctx* ctx, const mcg_row* rows, int64_t n_rows, int 
                          int num_branches, int poly_order, int max_iterations, uint64_t seed, double* out) {
     if (!ctx || !out) return fail(MCG_ERR_INVALID, "ctx/out is NULL");
     if (n_rows < 0 || (n_rows > 0 && !rows)) return fail(MCG_ERR_INVALID, "bad rows");
-    if (n_paths < 1 || n_paths > 256) return fail(MCG_ERR_INVALID, "n_paths must be in [1,256] (got %d)", n_paths);
-    if (poly_order < 0 || poly_order > 4) return fail(MCG_ERR_INVALID, "poly_order must be in [0,4] (got %d)", poly_order);
+    // (the row kernels serve up to 256 paths per row and orders up to 4 -- the driver uses 250 and 2; anything beyond is
+    // priced row by row through the single-contract entry points, run_batch_rows)
+    if (n_paths < 1) return fail(MCG_ERR_INVALID, "n_paths must be >= 1 (got %d)", n_paths);
+    if (poly_order < 0 || poly_order > 15) return fail(MCG_ERR_INVALID, "poly_order must be in [0,15] (got %d)", poly_order);
     if (max_iterations <= 0) return fail(MCG_ERR_INVALID, "MartingaleOptimization: maxIterations must be positive.");
     if (!(dt > 0.0)) return fail(MCG_ERR_INVALID, "dt must be > 0");
     if (n_rows > 4000000) return fail(MCG_ERR_INVALID, "too many rows for one call");

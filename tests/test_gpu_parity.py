@@ -962,7 +962,19 @@ def test_batch_rows_arguments(eng):
     rows = _driver_rows(2, np.random.RandomState(1))
     assert eng.batch_price_rows([], n_paths=250).shape == (0, 4)
     with pytest.raises(mc.McgError, match="n_paths"):
-        eng.batch_price_rows(rows, n_paths=300)
+        eng.batch_price_rows(rows, n_paths=0)
+    # beyond the row kernels' limits (256 paths per row, order 4) every row takes the single-contract entry points
+    big = eng.batch_price_rows(rows, n_paths=300, poly_order=5, seed=5)
+    for i, d in enumerate(rows):
+        P = eng.rbergomi(5, d["S0"], 0.04, d["xi"], d["H"], d["eta"], d["rho"], DT, d["n_steps"], 300, path_begin=i << 32)
+        ex = np.arange(d["n_steps"], dtype=np.int32)
+        call = bool(d["is_call"])
+        single = [eng.price_asymptotic(P, 0.04, d["strike"], d["maturity"], DT, call, d["sigma"], d["dividend"]),
+                  eng.price_branching(P, 0.04, d["strike"], d["maturity"], DT, call, 10, ex, 5)[0],
+                  eng.price_lsm(P, 0.04, d["strike"], d["maturity"], DT, call, 5)[0],
+                  eng.price_martingale(P, 0.04, d["strike"], d["maturity"], DT, call, 5, 5)[0]]
+        P.free()
+        assert np.array_equal(big[i], single), (i, big[i], single)
     with pytest.raises(mc.McgError, match="maxIterations must be positive"):
         eng.batch_price_rows(rows, max_iterations=0)
     a = eng.batch_price_rows(rows, seed=5)
