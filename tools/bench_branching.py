@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Device time of BranchingProcesses::PredictOptionPrice (mcg_price_branching: suffix maxima + bounds kernels) on GBM
+matrices of a few shapes; dev tool (the judged rows are bench.py's extra.configs)."""
 import sys,time
 sys.path.insert(0,'.')
 import montecarlooptionspricer_amd as mc
