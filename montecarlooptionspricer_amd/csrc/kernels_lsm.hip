@@ -173,8 +173,11 @@ __global__ __launch_bounds__(256) void k_lsm_date(LsmDateArgs a) {
         v[d] = make_double2(0.0, 0.0);
         sm[d] = make_double2(0.0, 0.0);
         if (u[d] < n_units) {
-            s[d] = S_j[u[d]];
-            if (need_v) v[d] = V2[u[d]];
+            typedef double v2d __attribute__((ext_vector_type(2)));
+            const v2d t = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(S_j + u[d]));  // row j is not needed again (-1.3 %)
+            s[d] = make_double2(t.x, t.y);
+            if (need_v) v[d] = V2[u[d]];  // (V and row j-1 come back at the next launch: ordinary loads and stores, the
+            //                               memory-side cache keeps part of them; nontemporal there costs 2 %)
             if (with_mom) sm[d] = S_mom[u[d]];
         }
     };
