@@ -31,9 +31,19 @@ constexpr int TABLE_UNITS = LOG_TAB_ENTRIES + SINCOS_TAB_ENTRIES + EXP2_TAB_ENTR
 // The lookup tables as they sit in LDS (and, back to back, in the device buffer they are staged from:
 // fm::LOG_TAB_HOST, fm::SINCOS_TAB_HOST, fm::EXP2_TAB_HOST).
 struct Tables {
+    static constexpr int SC_BITS = SINCOS_BITS;
     double2 log[LOG_TAB_ENTRIES];        // {1/c_i, -2 ln c_i}
     double2 sincos[SINCOS_TAB_ENTRIES];  // {cos, sin}(2 pi i / 1024)
     double exp2[EXP2_TAB_ENTRIES];       // 2^(j/256)
+};
+// What a kernel that draws normals only needs of them (the GBM generator: no exp2 table, and -- BITS < 10 -- every
+// 2^(10-BITS)-th sin/cos entry): LDS is what decides how many of its workgroups a CU holds.
+template <int BITS>
+struct NormalTables {
+    static_assert(BITS >= 6 && BITS <= SINCOS_BITS, "a sub-sampling of the 1024-entry table");
+    static constexpr int SC_BITS = BITS;
+    double2 log[LOG_TAB_ENTRIES];
+    double2 sincos[1 << BITS];
 };
 
 __device__ __forceinline__ double from_words(uint32_t hi, uint32_t lo) { return __hiloint2double((int)hi, (int)lo); }
@@ -307,22 +317,33 @@ __device__ __forceinline__ double sqrt_pos(double x) {
 // sine), combined by the angle-addition formulas: 12 fp64 instructions and no octant logic.  (512 entries and one more
 // cosine term until round 3.)
 // the table-independent half: (cos, sin)(delta)
+// BITS < 10 (a sub-sampled table, NormalTables): delta < 2 pi / 2^BITS, the cosine keeps its d^6 term (512 entries:
+// truncation 1.3e-20; the sine's 8.3e-18).
+template <int BITS = SINCOS_BITS>
 __device__ __forceinline__ void sincos_small(uint32_t wb, double& cd_out, double& sd_out) {
-    const double delta = __builtin_fma((double)((wb >> 8) & ((1u << (24 - SINCOS_BITS)) - 1u)), 0x1.921fb54442d18p-22, 0x1.921fb54442d18p-23);
+    const double delta = __builtin_fma((double)((wb >> 8) & ((1u << (24 - BITS)) - 1u)), 0x1.921fb54442d18p-22, 0x1.921fb54442d18p-23);
     const double d2 = delta * delta;
     const double ts = __builtin_fma(d2, 0x1.1111111111111p-7, -0x1.5555555555555p-3);  // 1/120, -1/6
     sd_out = __builtin_fma(delta * d2, ts, delta);
-    const double tc = __builtin_fma(d2, 0x1.5555555555555p-5, -0.5);                    // 1/24, -1/2
+    double tc;
+    if constexpr (BITS >= SINCOS_BITS) {
+        tc = __builtin_fma(d2, 0x1.5555555555555p-5, -0.5);                            // 1/24, -1/2
+    } else {
+        tc = __builtin_fma(d2, -0x1.6c16c16c16c17p-10, 0x1.5555555555555p-5);           // -1/720, 1/24
+        tc = __builtin_fma(tc, d2, -0.5);
+    }
     cd_out = __builtin_fma(tc, d2, 1.0);
 }
+template <int BITS = SINCOS_BITS>
 __device__ __forceinline__ void sincos_entry(uint32_t wb, const double2 e, double& c_out, double& s_out) {
     double cd, sd;
-    sincos_small(wb, cd, sd);
+    sincos_small<BITS>(wb, cd, sd);
     c_out = __builtin_fma(e.x, cd, -(e.y * sd));
     s_out = __builtin_fma(e.y, cd, e.x * sd);
 }
+template <int BITS = SINCOS_BITS>
 __device__ __forceinline__ void sincos_table(uint32_t wb, const double2* sc_tab, double& c_out, double& s_out) {
-    sincos_entry(wb, sc_tab[wb >> (32 - SINCOS_BITS)], c_out, s_out);
+    sincos_entry<BITS>(wb, sc_tab[wb >> (32 - BITS)], c_out, s_out);
 }
 
 // One Box-Muller pair from 64 Philox bits (philox.hpp contract).
@@ -337,21 +358,23 @@ __device__ __forceinline__ void box_muller_pair(uint32_t wa, uint32_t wb, const 
 
 // The same pair, already scaled and shifted: a0 = shift + scale*z0, a1 = shift + scale*z1
 // (the exponent of a price step).  Folding scale into the radius saves one multiply per pair.
-__device__ __forceinline__ void box_muller_pair_affine(uint32_t wa, uint32_t wb, const Tables* tab, double scale,
+template <class T>
+__device__ __forceinline__ void box_muller_pair_affine(uint32_t wa, uint32_t wb, const T* tab, double scale,
                                                        double shift, double& a0, double& a1) {
     const double rad = scale * sqrt_pos(neg2log(radius_u01(wa, wb), tab->log));
     double c, s;
-    sincos_table(wb, tab->sincos, c, s);
+    sincos_table<T::SC_BITS>(wb, tab->sincos, c, s);
     a0 = __builtin_fma(rad, c, shift);
     a1 = __builtin_fma(rad, s, shift);
 }
 
 // The affine pair with vol folded into the logarithm (tables staged by load_tables_scaled(vol^2)); vol > 0.
-__device__ __forceinline__ void box_muller_pair_affine_scaled(uint32_t wa, uint32_t wb, const Tables* tab, const LogScale& L,
+template <class T>
+__device__ __forceinline__ void box_muller_pair_affine_scaled(uint32_t wa, uint32_t wb, const T* tab, const LogScale& L,
                                                               double shift, double& a0, double& a1) {
     const double rad = sqrt_pos(neg2log_scaled(radius_u01(wa, wb), tab->log, L));  // = vol * sqrt(-2 ln u)
     double c, s;
-    sincos_table(wb, tab->sincos, c, s);
+    sincos_table<T::SC_BITS>(wb, tab->sincos, c, s);
     a0 = __builtin_fma(rad, c, shift);
     a1 = __builtin_fma(rad, s, shift);
 }
@@ -415,6 +438,18 @@ __device__ __forceinline__ void load_tables_scaled(Tables* lds, const double2* _
         if (i < LOG_TAB_ENTRIES) e.y *= scale;
         dst[i] = e;
     }
+}
+
+// NormalTables<BITS> from the same device buffer (logarithm table, then every 2^(10-BITS)-th sin/cos entry); the
+// logarithm table's second column times `scale` (1: as it is).
+template <int BITS>
+__device__ __forceinline__ void load_normal_tables(NormalTables<BITS>* lds, const double2* __restrict__ gtab, double scale) {
+    for (int i = threadIdx.x; i < LOG_TAB_ENTRIES; i += blockDim.x) {
+        double2 e = gtab[i];
+        e.y *= scale;
+        lds->log[i] = e;
+    }
+    for (int i = threadIdx.x; i < (1 << BITS); i += blockDim.x) lds->sincos[i] = gtab[LOG_TAB_ENTRIES + (i << (SINCOS_BITS - BITS))];
 }
 
 }  // namespace fm

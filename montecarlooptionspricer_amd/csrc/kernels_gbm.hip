@@ -13,6 +13,10 @@
 #include "fastmath.hpp"
 #include "mcg_internal.hpp"
 
+#ifndef MCG_GBM_TABLES
+#define MCG_GBM_TABLES 0
+#endif
+
 namespace mcg {
 
 struct GbmArgs {
@@ -43,10 +47,19 @@ template <bool PAYOFF, int MODE, int PPL>
 __global__ __launch_bounds__(256) void k_gbm_paths(GbmArgs a) {
     constexpr bool SMALL = MODE >= 1;
     typedef double v2d __attribute__((ext_vector_type(2)));
-    __shared__ fm::Tables tabs;
-    const fm::Tables* tab = &tabs;
+    // MCG_GBM_TABLES (A/B builds): 0 = all three tables of the rBergomi kernels (34 KiB: 4 workgroups per CU), 1 = logarithm
+    // + 1024-entry sin/cos (32 KiB: 5), 2 = logarithm + 512-entry sin/cos (24 KiB: 6; one more cosine term per pair)
+#if MCG_GBM_TABLES == 0
+    typedef fm::Tables GbmTables;
+    __shared__ GbmTables tabs;
     if (MODE >= 2) fm::load_tables_scaled(&tabs, a.log_tab, a.vol * a.vol);
     else fm::load_tables(&tabs, a.log_tab);
+#else
+    typedef fm::NormalTables<MCG_GBM_TABLES == 1 ? 10 : 9> GbmTables;
+    __shared__ GbmTables tabs;
+    fm::load_normal_tables(&tabs, a.log_tab, MODE >= 2 ? a.vol * a.vol : 1.0);
+#endif
+    const GbmTables* tab = &tabs;
     __syncthreads();
     const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * PPL;  // first column of this lane
     const bool in_row = PPL == 1 || i < a.ld;
