@@ -92,6 +92,8 @@ int mcg_comm_init_rank(mcg_ctx* ctx, const unsigned char id[128], int n_ranks, i
  * American price then costs one launch per GPU instead of three launches and one collective per exercise date.
  * At most 16 ranks. */
 int mcg_comm_init_shm(mcg_ctx* ctx, const char* name, int n_ranks, int rank);
+/* The ranks may also be THREADS of one process, one ctx each (one host thread per GPU -- the shape of the reference's own
+ * OpenMP driver): every collective call then blocks until all of them have made it, so each rank needs its own thread. */
 
 /* Opt-in, after mcg_comm_init_shm, collective over its ranks: keep the in-kernel mailbox in the GPUs' own HBM instead
  * of the host segment.  Every rank allocates a mailbox in device memory, exports it (hipIpcGetMemHandle, handed over
@@ -208,6 +210,31 @@ typedef struct mcg_row {
  * kernels' limits).  poly_order in [0, 15]. */
 int mcg_batch_price_rows(mcg_ctx* ctx, const mcg_row* rows, int64_t n_rows, int n_paths, double r, double dt,
                          int num_branches, int poly_order, int max_iterations, uint64_t seed, double* out);
+/* Any number of rows: the rows are processed in chunks whose workspace (every row's own (n_steps+1) x 256 block of the
+ * path matrix, its amplitudes and compensator -- nothing is padded to the longest row) stays under a quarter of the
+ * device memory that is free at the call; a row's Philox ids, and therefore its prices, do not depend on the chunking. */
+
+/* The driver's two remaining feature columns (src/core/PredictionGen.cpp:313-347, compute20DayVolAndMomentum): annualised
+ * standard deviation and sum of the last 20 log returns of the spot history; {0, 0} for fewer than 21 prices.
+ * twenty_day_vol is also the `sigma` the driver hands to AsymptoticAnalysis (:706). */
+int mcg_row_features(const double* hist, size_t n, double* twenty_day_vol, double* twenty_day_momentum);
+
+/* One driver row from the driver's own inputs (PredictionGen.cpp:664-719): the spot history fetched for the row (the
+ * driver appends underlying_last when it holds fewer than two prices, :671-673 -- so does this), the CSV fields
+ * underlying_last, dte, strike_dist_pct, option_type (1 = call), dividend.  Fills *row (path-engine parameters by
+ * mcg_estimate_params, strike = underlying_last (1 - strike_dist_pct), maturity = dte / 365, sigma = twenty_day_vol,
+ * n_steps = floor(maturity 252)) and features2 = {twenty_day_vol, twenty_day_momentum}.  A row the driver answers with
+ * ",0,0,0,0,0,0" (empty or non-finite history, inputs it rejects at :612-620) comes back with n_steps = 0 and zero
+ * features, status MCG_OK: mcg_batch_price_rows* prices it to zeros like the driver. */
+int mcg_row_build(const double* hist, size_t n, double underlying_last, double dte, double strike_dist_pct,
+                  int option_type, double dividend, mcg_row* row, double features2[2]);
+
+/* mcg_batch_price_rows with the driver's SIX output columns (:471-477, :809-816): out6[6*i + {0..3}] = the four model
+ * prices, out6[6*i + {4,5}] = features2 of row i (mcg_row_build; NULL: zeros) -- except that a row whose pricing the
+ * driver skips (n_steps < 1) keeps all six at zero, as the driver writes it. */
+int mcg_batch_price_rows6(mcg_ctx* ctx, const mcg_row* rows, const double* features2, int64_t n_rows, int n_paths,
+                          double r, double dt, int num_branches, int poly_order, int max_iterations, uint64_t seed,
+                          double* out6);
 
 /* ---- host-side pieces of the class-level API (a2/a3 of SURVEY.md section 8) --------------- */
 /* RoughVolatility.cpp:324-331: out5 = {xi, H, eta, rho, S0}. */
@@ -251,6 +278,34 @@ int mcg_timing_reset(mcg_ctx* ctx);
 int mcg_timing_get(mcg_ctx* ctx, int kernel /* enum mcg_kernel */, double* total_ms,
                    int64_t* launches);
 
+/* What this board writes right now with the path matrix's store pattern and NO arithmetic: `reps` timed launches (after
+ * two untimed ones) of a kernel that stores an n_paths x (n_steps+1) fp64 matrix exactly as the GBM generator does (two
+ * adjacent paths per lane, one nontemporal 16-byte store per step, rows n_paths apart).  The ceiling the generator's
+ * achieved GB/s is set against, measured in the same process on the same board (boards differ by ~10 %). */
+int mcg_probe_write_ceiling(mcg_ctx* ctx, int64_t n_paths, int n_steps, int reps, double* gb_per_s, double* ms_per_launch);
+/* Shader clock of the most recent GBM generator launch on this ctx, stamped inside the kernel by a few workgroups spread
+ * over the grid (s_memtime / s_memrealtime around each one's whole life): median in GHz, number of stamps, and the
+ * lowest / highest.  The generator is power-limited; its clock under load is what separates two boards. */
+int mcg_generator_clock(mcg_ctx* ctx, double* ghz_median, int* n_stamps, double* ghz_min, double* ghz_max);
+
+/* Process-wide event counters (all contexts, all threads): what ran and what fell back. */
+typedef struct mcg_stats_t {
+    int64_t lsm_one_launch_sweeps;     /* LSM prices answered by ONE launch (k_lsm_coop / k_lsm_big)                      */
+    int64_t lsm_one_launch_timeouts;   /* one-launch sweeps whose hand-shake gave up: discarded, re-run on the per-date route */
+    int64_t lsm_per_date_sweeps;       /* LSM prices answered by the per-date route                                       */
+    int64_t lsm_per_date_launches;     /* k_lsm_date launches queued for them (one per column + one per re-fitted date)   */
+    int64_t lsm_per_date_refits;       /* ... of which second launches of a re-fitted date                                */
+    int64_t lsm_per_date_faults;       /* per-date sweeps ended because partial moments did not arrive (MCG_ERR_HIP)      */
+    int64_t shm_barrier_failures;      /* barriers of the node segment that timed out or found it poisoned                */
+    int64_t peer_mailbox_enabled;      /* mcg_comm_shm_peer_mailbox calls that ended with the mailbox in peer memory      */
+    int64_t peer_mailbox_refused;      /* ... that left all ranks on the host mailbox (export, open or ping failed)       */
+    int64_t batch_calls, batch_chunks; /* mcg_batch_price_rows*: calls, and the chunks they were processed in             */
+    int64_t batch_rows;                /* rows priced by the row kernels                                                   */
+    int64_t batch_rows_singly;         /* rows priced one by one through the single-contract entry points                 */
+    int64_t batch_peak_workspace_bytes;/* largest device workspace a chunk has used                                        */
+} mcg_stats_t;
+int mcg_stats(mcg_stats_t* out, int reset);
+
 /* Test hook: evaluate one device math routine of the path kernels elementwise (csrc/fastmath.hpp).
  * y has 4n doubles; element i's results start at y[4i].
  * fn 0: y[0] = 1*e^x          fn 1: y[0] = -2 ln x (x in (0,1])       fn 2: y[0] = sqrt(x)
@@ -263,6 +318,17 @@ int mcg_debug_eval(mcg_ctx* ctx, int fn, const double* x, double* y, int64_t n);
  * wait gives up at once, which drives the time-out -> per-date fall-back on a healthy device; < 0: the default);
  * poll_delay = units of ~4 us by which workgroups other than the reducing one reach their coefficient poll late. */
 int mcg_debug_lsm_hooks(mcg_ctx* ctx, long long spin_limit, int poll_delay);
+/* Test hooks of the per-date LSM route's exchange (k_lsm_date): mode 1 = workgroup `workgroup` withholds its partial
+ * moments at exercise date `date` (a store that never lands: mcg_price_lsm must fail with MCG_ERR_HIP, never return a
+ * price); mode 2 = it sends them `delay` x ~4 us AFTER drawing its ticket (a store that lands late: the consumer waits
+ * for it, the price is the usual one); mode 0 = off.  spin_limit = polls before a consumer gives up (< 0: default). */
+int mcg_debug_lsm_date_fault(mcg_ctx* ctx, int mode, int date, int workgroup, int delay, long long spin_limit);
+/* Test hook: workspace bytes one chunk of mcg_batch_price_rows* may use (0: the default, a quarter of free memory). */
+int mcg_debug_batch_budget(mcg_ctx* ctx, size_t bytes);
+/* Test hook, host-only: the decision whether a rank maps a peer's mailbox (1) or all ranks stay on the host mailbox (0),
+ * from what it knows about the peer: same process?, does its PCI bus id resolve to a visible device?, the same device?,
+ * is peer access available? */
+int mcg_debug_peer_decision(int same_process, int bus_id_resolves, int same_device, int can_access_peer);
 /* Test hooks, host-only (no GPU needed): the shared segment's protocol on its own -- join `name` as `rank` of
  * `n_ranks` (a stale segment of a crashed job under the same name is never joined), barrier (fails at once on every
  * rank after a time-out or a poison), poison, leave. */

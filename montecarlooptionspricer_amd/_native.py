@@ -23,6 +23,14 @@ class Row(C.Structure):
                 ("n_steps", C.c_int), ("is_call", C.c_int)]
 
 
+class Stats(C.Structure):
+    """mcg_stats_t (include/mcgpu.h): process-wide event counters."""
+    _fields_ = [(k, C.c_int64) for k in (
+        "lsm_one_launch_sweeps", "lsm_one_launch_timeouts", "lsm_per_date_sweeps", "lsm_per_date_launches",
+        "lsm_per_date_refits", "lsm_per_date_faults", "shm_barrier_failures", "peer_mailbox_enabled", "peer_mailbox_refused",
+        "batch_calls", "batch_chunks", "batch_rows", "batch_rows_singly", "batch_peak_workspace_bytes")]
+
+
 class McgError(RuntimeError):
     """A non-zero status from libmcgpu (message = mcg_last_error()) or a missing library."""
 
@@ -88,6 +96,18 @@ def load_library():
     newer("mcg_debug_lsm_hooks", [vp, C.c_longlong, C.c_int])
     newer("mcg_comm_info", [vp] + [C.POINTER(C.c_int)] * 4)
     newer("mcg_timing_select", [vp, C.c_uint])
+    # round 4
+    newer("mcg_stats", [C.POINTER(Stats), C.c_int])
+    newer("mcg_debug_lsm_date_fault", [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_longlong])
+    newer("mcg_debug_batch_budget", [vp, C.c_size_t])
+    newer("mcg_debug_peer_decision", [C.c_int] * 4)
+    newer("mcg_probe_write_ceiling", [vp, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)])
+    newer("mcg_generator_clock", [vp, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)])
+    newer("mcg_row_features", [C.POINTER(C.c_double), C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_double)])
+    newer("mcg_row_build", [C.POINTER(C.c_double), C.c_size_t, C.c_double, C.c_double, C.c_double, C.c_int, C.c_double,
+                            C.POINTER(Row), C.POINTER(C.c_double)])
+    newer("mcg_batch_price_rows6", [vp, C.POINTER(Row), C.POINTER(C.c_double), C.c_int64, C.c_int, C.c_double, C.c_double, C.c_int,
+                                    C.c_int, C.c_int, C.c_uint64, C.POINTER(C.c_double)])
     L.mcg_paths_gbm.argtypes = [vp, C.c_uint64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int,
                                 C.c_uint64, C.c_int64, C.POINTER(vp)]
     L.mcg_paths_gbm_payoff.argtypes = [vp, C.c_uint64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int,

@@ -32,6 +32,7 @@
 
 #include <atomic>
 #include <chrono>
+#include <cstdint>
 #include <cstring>
 #include <new>
 #include <random>
@@ -55,6 +56,10 @@ struct ShmHeader {
     double host_slots[SHM_MAX_RANKS][64];
     unsigned char ipc_handle[SHM_MAX_RANKS][64];  // hipIpcMemHandle_t of each rank's peer-memory mailbox
     char pci_bus_id[SHM_MAX_RANKS][64];           // its GPU ("0000:c1:00.0"), for the peer-access check before the open
+    // ranks that are THREADS of one process (one host thread per GPU, the reference's own OpenMP shape): an IPC handle
+    // cannot be opened by the process that exported it, and need not be -- the owner's pointer is valid in the peer as it
+    // stands (one address space), peer access between the two devices is all it takes
+    uint64_t owner_pid[SHM_MAX_RANKS], owner_ptr[SHM_MAX_RANKS];
 };
 static_assert(sizeof(ShmHeader) % 64 == 0, "mailbox starts cache-line aligned");
 static_assert(sizeof(hipIpcMemHandle_t) <= 64, "IPC handle fits its slot");
@@ -76,12 +81,13 @@ struct ShmComm {
     bool peer_active = false;
     double* peer_own = nullptr;                    // this rank's mailbox in its own HBM
     double* peer_map[SHM_MAX_RANKS] = {nullptr};   // every rank's mailbox as mapped here ([rank] = peer_own)
+    bool peer_borrowed[SHM_MAX_RANKS] = {false};   // [r]: peer_map[r] is rank r's own pointer (same process), not an IPC mapping
     const char* peer_memory_kind = "";
 };
 
 namespace {
 
-constexpr uint32_t SHM_MAGIC = 0x4D434754u;  // "MCGT" (layout of round 3)
+constexpr uint32_t SHM_MAGIC = 0x4D434755u;  // "MCGU" (layout of round 4)
 constexpr int SHM_FLAG_SLOT = 63;            // entry of a rank's host slot row that carries shm_sum_flag's integer
 
 size_t mailbox_bytes() { return (size_t)SHM_MAX_ROUNDS * SHM_MAX_RANKS * SHM_ROW_DOUBLES * sizeof(double); }
@@ -116,6 +122,7 @@ bool shm_barrier(ShmComm* c) {
 }
 
 const char* barrier_error(ShmComm* c) {
+    g_stats.shm_barrier_failures.fetch_add(1, std::memory_order_relaxed);
     return c->hdr->abort.load() ? "shared-memory communicator is poisoned (a rank timed out or failed between two collective steps)"
                                 : "shared-memory barrier failed";
 }
@@ -317,10 +324,23 @@ int shm_n_ranks(mcg_ctx* ctx) { return ctx->shm ? ctx->shm->n_ranks : 1; }
 int shm_attached(mcg_ctx* ctx) { return ctx->shm && ctx->shm->hdr ? (int)ctx->shm->hdr->attached.load() : 0; }
 bool shm_peer_active(mcg_ctx* ctx) { return ctx->shm && ctx->shm->peer_active; }
 
+// May this rank map a peer's mailbox?  (Pure decision, unit-tested on the CPU through mcg_debug_peer_decision.)
+//   same process      : the owner's pointer is used as it is; across devices that needs peer access;
+//   another process   : its GPU must resolve to a device THIS process can see (a rank confined to its own GPU by
+//                       HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES cannot check reachability: a mapping that is not
+//                       reachable faults the first kernel that touches it, so the answer is no and all ranks stay on the
+//                       host mailbox together), and across devices peer access must be available.
+bool peer_map_allowed(bool same_process, bool bus_id_resolves, bool same_device, bool can_access_peer) {
+    (void)same_process;
+    if (!bus_id_resolves) return false;
+    return same_device || can_access_peer;
+}
+
 static void peer_release(ShmComm* c) {
     for (int r = 0; r < SHM_MAX_RANKS; ++r) {
-        if (c->peer_map[r] && r != c->rank) (void)hipIpcCloseMemHandle(c->peer_map[r]);
+        if (c->peer_map[r] && r != c->rank && !c->peer_borrowed[r]) (void)hipIpcCloseMemHandle(c->peer_map[r]);
         c->peer_map[r] = nullptr;
+        c->peer_borrowed[r] = false;
     }
     if (c->peer_own) (void)hipFree(c->peer_own);
     c->peer_own = nullptr;
@@ -406,6 +426,7 @@ extern "C" int mcg_comm_shm_peer_mailbox(mcg_ctx* ctx, int enable, int* active) 
         if (active) *active = 1;
         return MCG_OK;
     }
+    if (c->peer_own) peer_release(c);  // (left behind by an earlier attempt that failed half-way)
     // 1. allocate + export.  Uncached device memory first (every access goes to HBM: what a peer stores over xGMI is what
     // a local poll reads), fine-grained next, an ordinary allocation last; the in-kernel ping below is the judge.
     int ok = 0;
@@ -430,14 +451,20 @@ extern "C" int mcg_comm_shm_peer_mailbox(mcg_ctx* ctx, int enable, int* active) 
                 (void)hipGetLastError();
                 c->hdr->pci_bus_id[c->rank][0] = 0;
             }
+            c->hdr->owner_pid[c->rank] = (uint64_t)getpid();
+            c->hdr->owner_ptr[c->rank] = (uint64_t)(uintptr_t)p;
             c->peer_own = (double*)p;
             c->peer_memory_kind = names[k];
             ok = 1;
         }
     }
-    if ((rc = shm_sum_flag(ctx, ok, &all))) return rc;  // (its barriers also publish the handles)
+    if ((rc = shm_sum_flag(ctx, ok, &all))) {  // (its barriers also publish the handles)
+        peer_release(c);
+        return rc;
+    }
     if (all != c->n_ranks) {
         peer_release(c);
+        g_stats.peer_mailbox_refused.fetch_add(1, std::memory_order_relaxed);
         return MCG_OK;  // host mailbox stays
     }
     // 2. open the peers' mailboxes
@@ -445,17 +472,30 @@ extern "C" int mcg_comm_shm_peer_mailbox(mcg_ctx* ctx, int enable, int* active) 
     c->peer_map[c->rank] = c->peer_own;
     for (int r = 0; r < c->n_ranks && ok; ++r) {
         if (r == c->rank) continue;
-        // A peer on another GPU this process can see must be reachable by peer access (a mapping that is not would fault
-        // the first kernel that touches it); a GPU this process cannot see at all is left to the open's own verdict.
-        int peer_dev = -1, can = 1;
-        if (c->hdr->pci_bus_id[r][0] && hipDeviceGetByPCIBusId(&peer_dev, c->hdr->pci_bus_id[r]) == hipSuccess) {
-            if (peer_dev != ctx->device && (hipDeviceCanAccessPeer(&can, ctx->device, peer_dev) != hipSuccess || !can)) {
-                (void)hipGetLastError();
-                ok = 0;
-                break;
-            }
-        } else {
+        const bool same_process = c->hdr->owner_pid[r] == (uint64_t)getpid();
+        int peer_dev = -1, can = 0;
+        const bool resolves = c->hdr->pci_bus_id[r][0] && hipDeviceGetByPCIBusId(&peer_dev, c->hdr->pci_bus_id[r]) == hipSuccess;
+        if (!resolves) (void)hipGetLastError();
+        const bool same_device = resolves && peer_dev == ctx->device;
+        if (resolves && !same_device && (hipDeviceCanAccessPeer(&can, ctx->device, peer_dev) != hipSuccess || !can)) {
             (void)hipGetLastError();
+            can = 0;
+        }
+        if (!peer_map_allowed(same_process, resolves, same_device, can != 0)) {
+            ok = 0;
+            break;
+        }
+        if (same_process) {  // a thread of this process: its pointer, plus peer access between the two devices
+            if (!same_device) {
+                const hipError_t e = hipDeviceEnablePeerAccess(peer_dev, 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) ok = 0;
+                (void)hipGetLastError();
+            }
+            if (ok) {
+                c->peer_map[r] = (double*)(uintptr_t)c->hdr->owner_ptr[r];
+                c->peer_borrowed[r] = true;
+            }
+            continue;
         }
         hipIpcMemHandle_t h;
         std::memcpy(&h, c->hdr->ipc_handle[r], sizeof h);
@@ -467,9 +507,13 @@ extern "C" int mcg_comm_shm_peer_mailbox(mcg_ctx* ctx, int enable, int* active) 
             c->peer_map[r] = (double*)p;
         }
     }
-    if ((rc = shm_sum_flag(ctx, ok, &all))) return rc;
+    if ((rc = shm_sum_flag(ctx, ok, &all))) {
+        peer_release(c);
+        return rc;
+    }
     if (all != c->n_ranks) {
         peer_release(c);
+        g_stats.peer_mailbox_refused.fetch_add(1, std::memory_order_relaxed);
         return MCG_OK;
     }
     // 3. ping: every rank arms its mailbox, then one wavefront per rank pushes a token into every peer's mailbox and
@@ -488,10 +532,16 @@ extern "C" int mcg_comm_shm_peer_mailbox(mcg_ctx* ctx, int enable, int* active) 
     }
     if (all != 0) {
         peer_release(c);
+        g_stats.peer_mailbox_refused.fetch_add(1, std::memory_order_relaxed);
         return MCG_OK;
     }
+    g_stats.peer_mailbox_enabled.fetch_add(1, std::memory_order_relaxed);
     if (active) *active = 1;
     return MCG_OK;
+}
+
+extern "C" int mcg_debug_peer_decision(int same_process, int bus_id_resolves, int same_device, int can_access_peer) {
+    return peer_map_allowed(same_process != 0, bus_id_resolves != 0, same_device != 0, can_access_peer != 0) ? 1 : 0;
 }
 
 extern "C" int mcg_comm_info(mcg_ctx* ctx, int* kind, int* n_ranks, int* rank, int* seen_ranks) {

@@ -9,8 +9,14 @@
 //                      thread), all reductions inside the workgroup, regression solves on thread 0
 // Row c uses Philox path ids (c << 32) + p, so its four prices equal those of the single-contract entry
 // points called with path_begin = c << 32 (up to the ~1e-13 difference between the device DFT and the host FFT
-// in the amplitudes).  Matrix layout: step-major, row c owns columns [256 c, 256 c + n_paths).
+// in the amplitudes).  Matrix layout: every row owns ONE contiguous block of (n_steps + 1) x 256 doubles, step-major
+// inside it (element (j, p) at off + 256 j + p) -- nothing is padded to the longest row, consecutive steps of a row are
+// 2 KiB apart instead of n_rows x 2 KiB -- and its amplitudes and compensator sit at an offset of their own.  Any number
+// of rows: the call works through them in chunks under a memory budget (run_batch_rows); a row's Philox ids, and
+// therefore its prices, do not depend on which chunk it falls into.
+#include <algorithm>
 #include <cmath>
+#include <vector>
 
 #include "lsm_device.hpp"
 #include "mcg_internal.hpp"
@@ -24,8 +30,12 @@ constexpr int BATCH_MAX_STEPS = 1020;
 
 struct BatchRow {  // device image of one option row
     double S0, logS0, xi, H, eta, strike, maturity, sigma, dividend;
+    int64_t off;   // its block of the path matrix: S[off + 256 j + p]
+    int64_t woff;  // its amplitudes w[woff .. woff + M), compensator w[woff + M .. woff + M + n_steps)
+    uint64_t id;   // its index in the caller's array: Philox path ids (id << 32) + p
     int n_steps, M, is_call, valid;
 };
+constexpr int64_t BATCH_LD = 256;  // columns of a row's block (n_paths <= 256)
 
 struct BatchArgs {
     const BatchRow* rows;
@@ -33,12 +43,10 @@ struct BatchArgs {
     int n_paths, max_steps, m_max;
     double r, dt, sqdt, disc;  // disc = exp(-r dt)
     uint32_t k0, k1;
-    double* amp;  // [n_rows][m_max] spectral amplitudes a_k of each row
-    double* comp;   // [n_rows][max_steps]
-    double* S;      // [(max_steps+1)][ld]
-    int64_t ld;     // n_rows * 256
+    double* w;      // amplitudes and compensators, row by row (BatchRow::woff)
+    double* S;      // the rows' matrix blocks (BatchRow::off)
     const double2* log_tab;
-    double* out;    // [n_rows][4]: asymptotic, branching, lsm, martingale
+    double* out;    // [n_rows][4]: asymptotic, branching, lsm, martingale (chunk-local row order)
     int num_branches, max_iterations;
 };
 
@@ -83,9 +91,9 @@ __global__ __launch_bounds__(256) void k_batch_weights(BatchArgs a) {
     __syncthreads();
     // a_k = eta sqrt(2H)/M * sqrt((P_k + P_{M-k})/2): the symmetric spectral amplitudes of host/volterra.cpp
     const double scale = row.eta * sqrt(2.0 * row.H) / (double)M;
-    double* amp = a.amp + (int64_t)blockIdx.x * a.m_max;
+    double* amp = a.w + row.woff;
     for (int k = threadIdx.x; k < M; k += 256) amp[k] = scale * sqrt(0.5 * (P[k] + P[(M - k) & (M - 1)]));
-    double* cmp = a.comp + (int64_t)blockIdx.x * a.max_steps;
+    double* cmp = amp + M;
     for (int n = threadIdx.x; n < steps; n += 256) cmp[n] = -0.5 * row.eta * row.eta * pow((double)n * a.dt, 2.0 * row.H);
 }
 
@@ -100,12 +108,12 @@ __global__ __launch_bounds__(256) void k_batch_paths(BatchArgs a, int blocks_per
     const int n_pairs = (a.n_paths + 1) / 2;
     if ((int64_t)sub * rb_pairs_per_block(row.M) >= n_pairs) return;  // this row needs fewer workgroups than the widest
     RbArgs g;
-    g.out = a.S + r_idx * 256;
-    g.ld = a.ld;
+    g.out = a.S + row.off;
+    g.ld = BATCH_LD;
     g.n_paths = a.n_paths;
     g.n_steps = row.n_steps;
     g.M = row.M;
-    g.path_begin = (uint64_t)r_idx << 32;
+    g.path_begin = row.id << 32;
     g.k0 = a.k0;
     g.k1 = a.k1;
     g.S0 = row.S0;
@@ -114,8 +122,8 @@ __global__ __launch_bounds__(256) void k_batch_paths(BatchArgs a, int blocks_per
     g.xi = row.xi;
     g.dt = a.dt;
     g.sqdt = a.sqdt;
-    g.amp = a.amp + r_idx * a.m_max;
-    g.comp = a.comp + r_idx * a.max_steps;
+    g.amp = a.w + row.woff;
+    g.comp = g.amp + row.M;
     g.log_tab = a.log_tab;
     g.K = 0.0;
     g.is_call = 0;
@@ -166,11 +174,11 @@ __global__ __launch_bounds__(256) void k_batch_asym(BatchArgs a) {
     double v[2] = {0.0, 0.0};
     const int p = threadIdx.x;
     if (p < a.n_paths) {
-        const double* col = a.S + (int64_t)blockIdx.x * 256 + p;
+        const double* col = a.S + row.off + p;
         double best = 0.0;
         for (int j = 0; j < n_cols; ++j) {
             if (j * a.dt > row.maturity) break;
-            const double S = col[(int64_t)j * a.ld];
+            const double S = col[(int64_t)j * BATCH_LD];
             if (isnan(S) || isinf(S)) continue;
             const bool in = call ? (S > bnd[j]) : (S < bnd[j]);
             if (in) {
@@ -211,8 +219,8 @@ __global__ __launch_bounds__(256) void k_batch_branching(BatchArgs a) {
     while (n_dates < n_cols && !(n_dates * a.dt > row.maturity)) ++n_dates;
     const int p = threadIdx.x;
     const bool live = p < a.n_paths;
-    const double* col = a.S + (int64_t)blockIdx.x * 256 + (live ? p : 0);
-    const uint64_t id = ((uint64_t)blockIdx.x << 32) + (uint64_t)p;
+    const double* col = a.S + row.off + (live ? p : 0);
+    const uint64_t id = (row.id << 32) + (uint64_t)p;
     const PhiloxLane lane_rng = philox_lane_setup(id, 2u, a.k1);
     const int quads = (a.num_branches + 3) >> 2;
     const double inv_b = a.num_branches > 0 ? 1.0 / (double)a.num_branches : 0.0;
@@ -222,11 +230,11 @@ __global__ __launch_bounds__(256) void k_batch_branching(BatchArgs a) {
     double run = 0.0;
     {
         const int j = n_cols - 1;
-        if (j < n_dates) run = fmax(run, dsc[j] * payoff_of(call, col[(int64_t)j * a.ld], row.strike));
+        if (j < n_dates) run = fmax(run, dsc[j] * payoff_of(call, col[(int64_t)j * BATCH_LD], row.strike));
     }
     double lower = 0.0, upper = 0.0;
     for (int e = row.n_steps - 1; e >= 0; --e) {  // exercise date index == column index; run == F[e+1][p] here
-        const double now = dsc[e] * payoff_of(call, col[(int64_t)e * a.ld], row.strike);
+        const double now = dsc[e] * payoff_of(call, col[(int64_t)e * BATCH_LD], row.strike);
         const bool is_date = !(e * a.dt > row.maturity);  // (:94-96: the reference stops at the first date beyond maturity)
         double* mine = frow[e & 1];
         mine[p] = run;
@@ -265,7 +273,7 @@ __global__ __launch_bounds__(256) void k_batch_lsm(BatchArgs a) {
     const BatchRow row = a.rows[r_idx];
     if (!row.valid) return;
     double sum_v, sum_v2;
-    lsm_wave_body<NB>(a.S + r_idx * 256, a.ld, a.n_paths, row.n_steps + 1, row.strike, row.maturity, a.dt, a.disc, row.is_call,
+    lsm_wave_body<NB>(a.S + row.off, BATCH_LD, a.n_paths, row.n_steps + 1, row.strike, row.maturity, a.dt, a.disc, row.is_call,
                       ws[threadIdx.x >> 6], sum_v, sum_v2);
     if ((threadIdx.x & 63) == 0) a.out[4 * r_idx + 2] = sum_v / (double)a.n_paths;
 }
@@ -296,7 +304,7 @@ __global__ __launch_bounds__(256) void k_batch_martingale(BatchArgs a) {
     while (n_dates < n_cols && !(n_dates * a.dt > row.maturity)) ++n_dates;
     const int p = threadIdx.x;
     const bool live = p < a.n_paths;
-    const double* col = a.S + (int64_t)blockIdx.x * 256 + p;
+    const double* col = a.S + row.off + (live ? p : 0);
     double m[NM + 1];
     double xs[2] = {0.0, 0.0}, ys[2] = {0.0, 0.0};  // this path's two regression samples (kept for a re-fit)
 #pragma unroll
@@ -305,7 +313,7 @@ __global__ __launch_bounds__(256) void k_batch_martingale(BatchArgs a) {
         double best = 0.0;
         int stop = 0;
         for (int j = 0; j < n_dates; ++j) {
-            const double d = payoff_of(call, col[(int64_t)j * a.ld], row.strike) * dsc[j];
+            const double d = payoff_of(call, col[(int64_t)j * BATCH_LD], row.strike) * dsc[j];
             if (d > best) {
                 best = d;
                 stop = j;
@@ -313,8 +321,8 @@ __global__ __launch_bounds__(256) void k_batch_martingale(BatchArgs a) {
         }
         m[NM] = best;
         const int other = (stop + n_cols / 2) % n_cols;
-        xs[0] = col[(int64_t)stop * a.ld];
-        xs[1] = col[(int64_t)other * a.ld];
+        xs[0] = col[(int64_t)stop * BATCH_LD];
+        xs[1] = col[(int64_t)other * BATCH_LD];
         ys[0] = 0.5 * (payoff_of(call, xs[0], row.strike) * dsc[stop]);
         ys[1] = 0.2 * (payoff_of(call, xs[1], row.strike) * dsc[other]);
 #pragma unroll
@@ -370,7 +378,7 @@ __global__ __launch_bounds__(256) void k_batch_martingale(BatchArgs a) {
     if (live) {
         double best = 0.0;
         for (int j = 0; j < n_dates; ++j) {
-            const double S = col[(int64_t)j * a.ld];
+            const double S = col[(int64_t)j * BATCH_LD];
             const double cand = payoff_of(call, S, row.strike) * dsc[j] - (poly(S) - offset);
             if (cand > best) best = cand;
         }
@@ -390,104 +398,60 @@ static void launch_row_regressions(mcg_ctx* ctx, const BatchArgs& a, size_t smem
     hipLaunchKernelGGL(k_batch_martingale<NB>, dim3((unsigned)a.n_rows), dim3(256), smem_cols, ctx->stream, a);
 }
 
-int run_batch_rows(mcg_ctx* ctx, const mcg_row* rows, int64_t n_rows, int n_paths, double r, double dt, int num_branches,
-                   int poly_order, int max_iterations, uint64_t seed, double* out) {
-    std::vector<BatchRow> h((size_t)n_rows);
-    std::vector<int64_t> long_rows;
+namespace {
+
+// Device workspace one row needs in a chunk: its matrix block, its amplitudes + compensator, its image and its four prices.
+size_t row_workspace_bytes(int n_steps, int M) {
+    return ((size_t)BATCH_LD * (size_t)(n_steps + 1) + (size_t)M + (size_t)n_steps + 4) * sizeof(double) + sizeof(BatchRow);
+}
+
+// LDS class of a row: the row kernels' dynamic LDS is sized by the longest row of a LAUNCH, so the rare long rows (Mz >= 256:
+// more than half a year of trading days) are launched apart from the many short ones, whose occupancy they would cost.
+int lds_class(int M) { return M <= 128 ? 0 : M == 256 ? 1 : M == 512 ? 2 : 3; }
+constexpr int N_LDS_CLASSES = 4;
+
+}  // namespace
+
+// The six launches for ONE chunk of rows (h: their device images, already with offsets); prices into out[4 * h[k].id ...].
+static int run_batch_chunk(mcg_ctx* ctx, std::vector<BatchRow>& h, BatchArgs a, double* d_S, double* d_small, int poly_order, double* out) {
+    const int64_t n = (int64_t)h.size();
     int max_steps = 1, m_max = 1;
-    for (int64_t i = 0; i < n_rows; ++i) {
-        const mcg_row& s = rows[i];
-        BatchRow& d = h[(size_t)i];
-        d.S0 = s.S0;
-        d.logS0 = s.S0 > 0.0 ? std::log(s.S0) : 0.0;
-        d.xi = s.xi;
-        d.H = s.H;
-        d.eta = s.eta;
-        d.strike = s.strike;
-        d.maturity = s.maturity;
-        d.sigma = s.sigma;
-        d.dividend = s.dividend;
-        d.n_steps = s.n_steps;
-        d.is_call = s.is_call;
-        // a row the reference's driver would answer with zeros (no steps, non-finite paths, a throwing pricer)
-        d.valid = s.n_steps >= 1 && s.S0 > 0.0 && std::isfinite(s.S0) && s.xi >= 0.0 &&
-                  std::isfinite(s.xi) && s.H >= 0.0 && std::isfinite(s.H) && std::isfinite(s.eta) &&
-                  std::fabs(s.rho) <= 1.0 && s.strike > 0.0 && std::isfinite(s.strike) && s.sigma > 0.0 &&
-                  std::isfinite(s.maturity);
-        // A row longer than the row kernels' LDS tables reach (more than four years of trading days), or any row of a call
-        // with more than 256 paths per row or an order above 4, is priced after the batch through the single-contract
-        // entry points, on the same Philox path ids: never refused, never answered with zeros.
-        if (d.valid && (s.n_steps > BATCH_MAX_STEPS || n_paths > 256 || poly_order > 4)) {
-            long_rows.push_back(i);
-            d.valid = 0;
-        }
-        d.M = 1;
-        if (d.valid) {
-            while (d.M < d.n_steps) d.M <<= 1;
-            max_steps = std::max(max_steps, d.n_steps);
-            m_max = std::max(m_max, d.M);
-        }
+    int64_t off = 0, woff = 0;
+    for (BatchRow& d : h) {
+        d.off = off;
+        d.woff = woff;
+        off += BATCH_LD * (int64_t)(d.n_steps + 1);
+        woff += (int64_t)d.M + d.n_steps;
+        max_steps = std::max(max_steps, d.n_steps);
+        m_max = std::max(m_max, d.M);
     }
-    const int64_t ld = n_rows * 256;
-    const size_t mat_bytes = (size_t)ld * (size_t)(max_steps + 1) * sizeof(double);
-    const size_t small_doubles = (size_t)n_rows * ((size_t)m_max + (size_t)max_steps + 4) + (sizeof(BatchRow) * (size_t)n_rows + 7) / 8;
-    void *S = nullptr, *small = nullptr;
-    int rc = pool_alloc(ctx, mat_bytes, &S);
-    if (rc) return rc;
-    rc = pool_alloc(ctx, small_doubles * sizeof(double), &small);
-    if (rc) {
-        pool_release(ctx, S, mat_bytes);
-        return rc;
-    }
-    auto release_all = [&] {
-        pool_release(ctx, S, mat_bytes);
-        pool_release(ctx, small, small_doubles * sizeof(double));
-    };
-    BatchArgs a;
-    double* sd = (double*)small;
-    a.out = sd;
-    a.amp = sd + 4 * n_rows;
-    a.comp = a.amp + (size_t)n_rows * m_max;
-    a.rows = reinterpret_cast<const BatchRow*>(a.comp + (size_t)n_rows * max_steps);
-    a.n_rows = n_rows;
-    a.n_paths = n_paths;
+    a.S = d_S;
+    a.out = d_small;
+    a.w = d_small + 4 * n;
+    a.rows = reinterpret_cast<const BatchRow*>(a.w + woff + (woff & 1));
+    a.n_rows = n;
     a.max_steps = max_steps;
     a.m_max = m_max;
-    a.r = r;
-    a.dt = dt;
-    a.sqdt = std::sqrt(dt);
-    a.disc = std::exp(-r * dt);
-    a.k0 = (uint32_t)seed;
-    a.k1 = (uint32_t)(seed >> 32);
-    a.S = (double*)S;
-    a.ld = ld;
-    a.log_tab = (const double2*)ctx->log_tab;
-    a.num_branches = num_branches;
-    a.max_iterations = max_iterations;
-
-    hipError_t e = hipMemcpyAsync((void*)a.rows, h.data(), sizeof(BatchRow) * (size_t)n_rows, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(a.out, 0, 4 * sizeof(double) * (size_t)n_rows, ctx->stream);
-    if (e != hipSuccess) {
-        release_all();
-        return fail(MCG_ERR_HIP, "batch upload failed: %s", hipGetErrorString(e));
-    }
+    hipError_t e = hipMemcpyAsync((void*)a.rows, h.data(), sizeof(BatchRow) * (size_t)n, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(a.out, 0, 4 * sizeof(double) * (size_t)n, ctx->stream);
+    if (e != hipSuccess) return fail(MCG_ERR_HIP, "batch upload failed: %s", hipGetErrorString(e));
     const int mphi_max = 2 * m_max >= 2 ? 2 * m_max : 2;
     const size_t smem_w = ((size_t)2 * mphi_max + (size_t)max_steps + 1 + (size_t)m_max) * sizeof(double);
     size_t smem_p = 0;  // largest over the transform sizes present (the staging part does not grow with Mz)
     for (int m = 1; m <= m_max; m <<= 1) smem_p = std::max(smem_p, rb_smem_bytes(m, std::min(m, max_steps)));
     const size_t smem_c = ((size_t)max_steps + 1) * sizeof(double);
     // workgroups per row: enough for the row with the fewest pairs per workgroup (the largest Mz)
-    const int n_pairs = (n_paths + 1) / 2;
+    const int n_pairs = (a.n_paths + 1) / 2;
     int bpr = 1;
     for (int m = 32; m <= m_max; m <<= 1) bpr = std::max(bpr, (n_pairs + rb_pairs_per_block(m) - 1) / rb_pairs_per_block(m));
     {
         TimedLaunch t(ctx, MCG_K_BATCH);
-        hipLaunchKernelGGL(k_batch_weights, dim3((unsigned)n_rows), dim3(256), smem_w, ctx->stream, a);
+        hipLaunchKernelGGL(k_batch_weights, dim3((unsigned)n), dim3(256), smem_w, ctx->stream, a);
         if (smem_p > 48 * 1024)
             (void)hipFuncSetAttribute((const void*)k_batch_paths, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_p);
-        hipLaunchKernelGGL(k_batch_paths, dim3((unsigned)(n_rows * bpr)), dim3(256), smem_p, ctx->stream, a, bpr);
-        hipLaunchKernelGGL(k_batch_asym, dim3((unsigned)n_rows), dim3(256), 2 * smem_c, ctx->stream, a);
-        hipLaunchKernelGGL(k_batch_branching, dim3((unsigned)n_rows), dim3(256), smem_c, ctx->stream, a);
+        hipLaunchKernelGGL(k_batch_paths, dim3((unsigned)(n * bpr)), dim3(256), smem_p, ctx->stream, a, bpr);
+        hipLaunchKernelGGL(k_batch_asym, dim3((unsigned)n), dim3(256), 2 * smem_c, ctx->stream, a);
+        hipLaunchKernelGGL(k_batch_branching, dim3((unsigned)n), dim3(256), smem_c, ctx->stream, a);
         switch (poly_order + 1) {
             case 1: launch_row_regressions<1>(ctx, a, smem_c); break;
             case 2: launch_row_regressions<2>(ctx, a, smem_c); break;
@@ -497,15 +461,142 @@ int run_batch_rows(mcg_ctx* ctx, const mcg_row* rows, int64_t n_rows, int n_path
         }
     }
     e = hipGetLastError();
-    if (e == hipSuccess) e = hipMemcpyAsync(out, a.out, 4 * sizeof(double) * (size_t)n_rows, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    // the host vector `h` must outlive the upload: it does (synchronised above)
-    release_all();
+    std::vector<double> four((size_t)n * 4);
+    if (e == hipSuccess) e = hipMemcpyAsync(four.data(), a.out, 4 * sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // (also: the host vector `h` has outlived its upload)
     if (e != hipSuccess) return fail(MCG_ERR_HIP, "batch run failed: %s", hipGetErrorString(e));
+    for (int64_t k = 0; k < n; ++k)
+        for (int c = 0; c < 4; ++c) out[4 * h[(size_t)k].id + c] = four[(size_t)(4 * k + c)];
+    return MCG_OK;
+}
+
+int run_batch_rows(mcg_ctx* ctx, const mcg_row* rows, int64_t n_rows, int n_paths, double r, double dt, int num_branches,
+                   int poly_order, int max_iterations, uint64_t seed, double* out, unsigned char* priced) {
+    g_stats.batch_calls.fetch_add(1, std::memory_order_relaxed);
+    std::vector<int64_t> cls[N_LDS_CLASSES], long_rows;
+    for (int64_t i = 0; i < n_rows; ++i) {
+        const mcg_row& s = rows[i];
+        out[4 * i] = out[4 * i + 1] = out[4 * i + 2] = out[4 * i + 3] = 0.0;
+        // a row the reference's driver would answer with zeros (no steps, non-finite paths, a throwing pricer)
+        const bool valid = s.n_steps >= 1 && s.S0 > 0.0 && std::isfinite(s.S0) && s.xi >= 0.0 && std::isfinite(s.xi) && s.H >= 0.0 &&
+                           std::isfinite(s.H) && std::isfinite(s.eta) && std::fabs(s.rho) <= 1.0 && s.strike > 0.0 &&
+                           std::isfinite(s.strike) && s.sigma > 0.0 && std::isfinite(s.maturity);
+        if (priced) priced[i] = valid ? 1 : 0;
+        if (!valid) continue;
+        // A row longer than the row kernels' LDS tables reach (more than four years of trading days), or any row of a call
+        // with more than 256 paths per row or an order above 4, is priced after the batch through the single-contract
+        // entry points, on the same Philox path ids: never refused, never answered with zeros.
+        if (s.n_steps > BATCH_MAX_STEPS || n_paths > 256 || poly_order > 4) {
+            long_rows.push_back(i);
+            continue;
+        }
+        int M = 1;
+        while (M < s.n_steps) M <<= 1;
+        cls[lds_class(M)].push_back(i);
+    }
+    // Memory budget of one chunk: a quarter of what is free now (mcg_debug_batch_budget overrides), never less than one row.
+    size_t budget = ctx->batch_budget;
+    if (budget == 0) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) {
+            (void)hipGetLastError();
+            free_b = (size_t)8 << 30;
+        }
+        budget = std::max<size_t>(free_b / 4, (size_t)256 << 20);
+    }
+    // Plan: per LDS class, consecutive rows (the caller's order) while their workspace fits the budget.
+    struct Chunk {
+        int c;
+        size_t begin, end, bytes_S, doubles_small;
+    };
+    std::vector<Chunk> plan;
+    size_t max_S = 0, max_small = 0;
+    for (int c = 0; c < N_LDS_CLASSES; ++c) {
+        size_t k = 0;
+        while (k < cls[c].size()) {
+            Chunk ch{c, k, k, 0, 0};
+            size_t used = 0, w = 0;
+            while (ch.end < cls[c].size()) {
+                const mcg_row& s = rows[cls[c][ch.end]];
+                int M = 1;
+                while (M < s.n_steps) M <<= 1;
+                const size_t need = row_workspace_bytes(s.n_steps, M);
+                if (ch.end > ch.begin && (used + need > budget || ch.end - ch.begin >= ((size_t)1 << 30))) break;
+                used += need;
+                ch.bytes_S += (size_t)BATCH_LD * (size_t)(s.n_steps + 1) * sizeof(double);
+                w += (size_t)M + (size_t)s.n_steps;
+                ++ch.end;
+            }
+            const size_t nr = ch.end - ch.begin;
+            ch.doubles_small = 4 * nr + w + 2 + (sizeof(BatchRow) * nr + 7) / 8;
+            max_S = std::max(max_S, ch.bytes_S);
+            max_small = std::max(max_small, ch.doubles_small);
+            plan.push_back(ch);
+            k = ch.end;
+        }
+    }
+    int rc = MCG_OK;
+    if (!plan.empty()) {
+        void *S = nullptr, *small = nullptr;  // ONE pair of buffers for all chunks
+        rc = pool_alloc(ctx, max_S, &S);
+        if (rc) return rc;
+        rc = pool_alloc(ctx, max_small * sizeof(double), &small);
+        if (rc) {
+            pool_release(ctx, S, max_S);
+            return rc;
+        }
+        int64_t peak = (int64_t)(max_S + max_small * sizeof(double)), seen = g_stats.batch_peak_workspace_bytes.load(std::memory_order_relaxed);
+        while (peak > seen && !g_stats.batch_peak_workspace_bytes.compare_exchange_weak(seen, peak, std::memory_order_relaxed)) {
+        }
+        BatchArgs a{};
+        a.n_paths = n_paths;
+        a.r = r;
+        a.dt = dt;
+        a.sqdt = std::sqrt(dt);
+        a.disc = std::exp(-r * dt);
+        a.k0 = (uint32_t)seed;
+        a.k1 = (uint32_t)(seed >> 32);
+        a.log_tab = (const double2*)ctx->log_tab;
+        a.num_branches = num_branches;
+        a.max_iterations = max_iterations;
+        std::vector<BatchRow> h;
+        for (const Chunk& ch : plan) {
+            h.clear();
+            h.reserve(ch.end - ch.begin);
+            for (size_t k = ch.begin; k < ch.end; ++k) {
+                const int64_t i = cls[ch.c][k];
+                const mcg_row& s = rows[i];
+                BatchRow d{};
+                d.S0 = s.S0;
+                d.logS0 = std::log(s.S0);
+                d.xi = s.xi;
+                d.H = s.H;
+                d.eta = s.eta;
+                d.strike = s.strike;
+                d.maturity = s.maturity;
+                d.sigma = s.sigma;
+                d.dividend = s.dividend;
+                d.id = (uint64_t)i;
+                d.n_steps = s.n_steps;
+                d.is_call = s.is_call;
+                d.valid = 1;
+                d.M = 1;
+                while (d.M < d.n_steps) d.M <<= 1;
+                h.push_back(d);
+            }
+            rc = run_batch_chunk(ctx, h, a, (double*)S, (double*)small, poly_order, out);
+            if (rc) break;
+            g_stats.batch_chunks.fetch_add(1, std::memory_order_relaxed);
+            g_stats.batch_rows.fetch_add((int64_t)h.size(), std::memory_order_relaxed);
+        }
+        pool_release(ctx, S, max_S);
+        pool_release(ctx, small, max_small * sizeof(double));
+        if (rc) return rc;
+    }
+    g_stats.batch_rows_singly.fetch_add((int64_t)long_rows.size(), std::memory_order_relaxed);
     for (int64_t i : long_rows) {  // PredictionGen.cpp:718-816 for one row, through the single-contract entry points
         const mcg_row& s = rows[i];
         double* o = out + 4 * i;
-        o[0] = o[1] = o[2] = o[3] = 0.0;
         mcg_paths* P = nullptr;
         if (mcg_paths_rbergomi(ctx, seed, s.S0, r, s.xi, s.H, s.eta, s.rho, dt, s.n_steps, (uint64_t)i << 32, n_paths, &P) != MCG_OK)
             continue;  // (the driver logs a failing row and writes zeros, :792-805)

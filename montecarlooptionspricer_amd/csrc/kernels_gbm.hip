@@ -7,7 +7,9 @@
 // PayoffFunction (include/core/common.h:8-14) on the last column.
 //
 // Roofline: HBM write, 8*(n_steps+1) bytes per path, reads ~0.  No MFMA: the step is elementwise.
+#include <algorithm>
 #include <cstdlib>
+#include <vector>
 
 #include "devmath.hpp"
 #include "fastmath.hpp"
@@ -32,6 +34,10 @@ struct GbmArgs {
     int is_call;
     double* partials;  // [gridDim.x][2]
     const double2* log_tab;  // fm::LOG_TAB_HOST on the device
+    // mcg_generator_clock: workgroups whose index is clk_first + k * clk_stride stamp their life with the shader-cycle and
+    // the 100 MHz counters into slot k (two scalar reads at each end of ~40 workgroups per launch: nothing on the hot path)
+    unsigned long long* clk;
+    unsigned clk_first, clk_stride;
 };
 
 // MODE 0: any parameters.  MODE 1 (SMALL): the host has checked |drift| + vol * 7.55 <= 0.125, so every step's exponent
@@ -61,6 +67,16 @@ __global__ __launch_bounds__(256) void k_gbm_paths(GbmArgs a) {
 #endif
     const GbmTables* tab = &tabs;
     __syncthreads();
+#ifdef MCG_GBM_NO_STAMPS  // (A/B builds: the kernel without its clock stamps)
+    const bool stamps = false;
+#else
+    const bool stamps = a.clk != nullptr && blockIdx.x >= a.clk_first && (blockIdx.x - a.clk_first) % a.clk_stride == 0;  // (wave-uniform)
+#endif
+    unsigned long long t_cyc = 0, t_ref = 0;
+    if (stamps) {
+        t_cyc = __builtin_amdgcn_s_memtime();
+        t_ref = __builtin_amdgcn_s_memrealtime();
+    }
     const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * PPL;  // first column of this lane
     const bool in_row = PPL == 1 || i < a.ld;
     double S[PPL];
@@ -129,6 +145,14 @@ __global__ __launch_bounds__(256) void k_gbm_paths(GbmArgs a) {
                 for (int p = 0; p < PPL; ++p) pair_exponents(w[p].w2, w[p].w3, e0[p], e1[p]);
                 step(e0);
             }
+        }
+    }
+    if (stamps) {
+        const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+        const unsigned slot = (blockIdx.x - a.clk_first) / a.clk_stride;
+        if (threadIdx.x == 0 && slot < (unsigned)GBM_CLK_SLOTS) {
+            a.clk[2 * slot] = c1 - t_cyc;
+            a.clk[2 * slot + 1] = r1 - t_ref;
         }
     }
     if (PAYOFF) {
@@ -278,6 +302,20 @@ int launch_gbm(mcg_ctx* ctx, mcg_paths* P, uint64_t seed, double S0, double r, d
     a.is_call = is_call;
     a.partials = ctx->partials;
     a.log_tab = (const double2*)ctx->log_tab;
+    // shader-clock stamps: up to GBM_CLK_SLOTS workgroups spread over the middle three quarters of the grid
+    a.clk = nullptr;
+    a.clk_first = 0;
+    a.clk_stride = 1;
+    ctx->clk_slots_used = 0;
+    if (ctx->clk_stamps && n_blocks >= 64) {
+        const int64_t span = n_blocks * 3 / 4;
+        const int slots = (int)std::min<int64_t>(GBM_CLK_SLOTS, span / 16);
+        a.clk = ctx->clk_stamps;
+        a.clk_first = (unsigned)(n_blocks / 8);
+        a.clk_stride = (unsigned)std::max<int64_t>(1, span / slots);
+        ctx->clk_slots_used = (int)std::min<int64_t>(slots, (n_blocks - 1 - a.clk_first) / a.clk_stride + 1);
+        MCG_HIP(hipMemsetAsync(ctx->clk_stamps, 0, sizeof(unsigned long long) * 2 * GBM_CLK_SLOTS, ctx->stream));
+    }
     {
         TimedLaunch t(ctx, MCG_K_GBM);
         const bool small = std::fabs(a.drift) + std::fabs(a.vol) * fm::MAX_ABS_NORMAL <= fm::SMALL_EXP_BOUND;
@@ -302,6 +340,28 @@ int launch_gbm(mcg_ctx* ctx, mcg_paths* P, uint64_t seed, double S0, double r, d
         P->sums_K = K;
         P->sums_is_call = is_call;
     }
+    return MCG_OK;
+}
+
+// Median (and range) of the stamping workgroups' clocks of the last GBM launch: cycles / (100 MHz ticks) x 0.1 GHz.
+int generator_clock(mcg_ctx* ctx, double* ghz_median, int* n_stamps, double* ghz_min, double* ghz_max) {
+    if (ghz_median) *ghz_median = 0.0;
+    if (n_stamps) *n_stamps = 0;
+    if (ghz_min) *ghz_min = 0.0;
+    if (ghz_max) *ghz_max = 0.0;
+    if (!ctx->clk_stamps || ctx->clk_slots_used < 1) return MCG_OK;
+    unsigned long long h[2 * GBM_CLK_SLOTS];
+    MCG_HIP(hipStreamSynchronize(ctx->stream));
+    MCG_HIP(hipMemcpy(h, ctx->clk_stamps, sizeof h, hipMemcpyDeviceToHost));
+    std::vector<double> g;
+    for (int k = 0; k < ctx->clk_slots_used; ++k)
+        if (h[2 * k + 1] > 100) g.push_back((double)h[2 * k] / (double)h[2 * k + 1] * 0.1);  // (a stamp shorter than 1 us says nothing)
+    if (g.empty()) return MCG_OK;
+    std::sort(g.begin(), g.end());
+    if (ghz_median) *ghz_median = g[g.size() / 2];
+    if (n_stamps) *n_stamps = (int)g.size();
+    if (ghz_min) *ghz_min = g.front();
+    if (ghz_max) *ghz_max = g.back();
     return MCG_OK;
 }
 

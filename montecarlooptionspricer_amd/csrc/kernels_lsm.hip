@@ -18,6 +18,7 @@
 #include <atomic>
 #include <cstdlib>
 #include <mutex>
+#include <shared_mutex>
 #include <type_traits>
 
 #include "lsm_device.hpp"
@@ -31,6 +32,16 @@ __device__ __forceinline__ void lsm_st_shared(double* p, double v) {
 }
 __device__ __forceinline__ double lsm_ld_shared(const double* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Every double that travels between workgroups (or GPUs) announces itself: its slot holds a reserved NaN until the value
+// arrives, and whoever consumes it puts the NaN back -- a value that has not arrived cannot be mistaken for one.
+constexpr unsigned LSM_SENTINEL32 = 0xFFF85EA7u;  // both halves of the reserved NaN (hipMemsetD32 fills the buffers)
+__device__ __forceinline__ bool lsm_is_sentinel(double v) {
+    return (unsigned long long)__double_as_longlong(v) == (((unsigned long long)LSM_SENTINEL32 << 32) | LSM_SENTINEL32);
+}
+__device__ __forceinline__ double lsm_sentinel() {
+    return __longlong_as_double((long long)((((unsigned long long)LSM_SENTINEL32) << 32) | LSM_SENTINEL32));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -52,7 +63,9 @@ __device__ __forceinline__ double lsm_ld_shared(const double* p) {
 // them with lsm_solve_centered and carries on.  Every rank takes the same decision from the same summed moments, so the
 // ranks stay in step.  Launches beyond the last date return at once; the host queues a few spare ones and, should a
 // sweep need more than it queued (it reads the state back once per batch), queues the rest.
-constexpr int LSM_ST_J = 0, LSM_ST_PHASE = 1, LSM_ST_MU = 2;  // state words (doubles)
+constexpr int LSM_ST_J = 0, LSM_ST_PHASE = 1, LSM_ST_MU = 2, LSM_ST_FAULT = 3;  // state words (doubles)
+constexpr int LSM_ST_WORDS = 4;
+static_assert(SC_LSM_STATE + LSM_ST_WORDS <= SC_LSM_TICKET, "the state fits its place in the ctx's scalar workspace");
 enum { LSM_PH_REGULAR = 0, LSM_PH_REFINED = 1, LSM_PH_INIT = 2 };
 
 struct LsmDateArgs {
@@ -63,9 +76,31 @@ struct LsmDateArgs {
     int is_call;
     double* msg;          // in: the moments the state's phase says (summed over the ranks); out: those of the next launch
     double* state;        // {date j the next launch works on (< 0: done), phase, centre of a refinement}
-    double* partials;     // [NM][gridDim.x] (moment-major: the reducing workgroup reads contiguously)
+    double* partials;     // [NM][gridDim.x] (moment-major: the reducing workgroup reads contiguously), then [NM][groups]:
+    //                       every slot holds the reserved NaN except between its store and its consumption (lsm_date_tail)
     unsigned* ticket;     // workgroups done, per group of 64 and of the groups; the last ones reset them (lsm_date_tail)
+    unsigned spin_limit;  // polls before a consumer gives a slot up (state[LSM_ST_FAULT], the sweep ends, run_lsm fails)
+    // test hooks (mcg_debug_lsm_date_fault): at date hook_date workgroup hook_wg withholds its partial moments (mode 1: a
+    // store that never lands) or sends them ~hook_delay x 4 us AFTER its ticket (mode 2: a store that lands late)
+    int hook_mode, hook_date, hook_wg, hook_delay;
 };
+
+// A consumer's read of one slot: the value, once it is there (normally at the first look: the ticket that elected this
+// workgroup was drawn after the producers' stores had been acknowledged); the slot is re-armed for the next launch.
+__device__ __forceinline__ double lsm_consume_slot(double* p, unsigned limit, bool& fault) {
+    double v = lsm_ld_shared(p);
+    unsigned spins = 0;
+    while (lsm_is_sentinel(v)) {
+        if (++spins > limit) {
+            fault = true;
+            return 0.0;
+        }
+        __builtin_amdgcn_s_sleep(2);
+        v = lsm_ld_shared(p);
+    }
+    lsm_st_shared(p, lsm_sentinel());
+    return v;
+}
 
 // Tail of a launch.  HAVE: this launch produced partial moments m.  Returns true in the last workgroup to get here,
 // after it has left the sum of all partials in msg (or zeros when there were none).  Two levels, so that neither a
@@ -82,32 +117,41 @@ constexpr int LSM_DATE_MAX_GROUPS = 2048 / LSM_DATE_GROUP;  // tickets: [0 .. MA
 static_assert((LSM_DATE_MAX_GROUPS + 1 + 1) / 2 <= SCALARS_DOUBLES - SC_LSM_TICKET, "the tickets fit the ctx's scalar workspace");
 
 template <int NM>
-__device__ __forceinline__ bool lsm_date_tail(const LsmDateArgs& a, bool have, double (&m)[NM], double* red, unsigned* sm_last) {
+__device__ __forceinline__ bool lsm_date_tail(const LsmDateArgs& a, bool have, double (&m)[NM], double* red, unsigned* sm_last, int date) {
     const unsigned G = gridDim.x, n_groups = (G + LSM_DATE_GROUP - 1) / LSM_DATE_GROUP;
     const unsigned grp = blockIdx.x / LSM_DATE_GROUP, first = grp * LSM_DATE_GROUP;
     const unsigned members = min((unsigned)LSM_DATE_GROUP, G - first);
     double* gsum = a.partials + (int64_t)NM * G;  // [NM][n_groups]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    static_assert(LSM_DATE_GROUP <= 64, "one member per lane");
     if (have) block_sum<NM, 4>(m, red);
     if (threadIdx.x == 0) {
-        if (have) {
+        const bool hooked = a.hook_mode != 0 && date == a.hook_date && (int)blockIdx.x == a.hook_wg;
+        auto send = [&]() {
 #pragma unroll
             for (int q = 0; q < NM; ++q) lsm_st_shared(a.partials + (int64_t)q * G + blockIdx.x, m[q]);
             __builtin_amdgcn_s_waitcnt(0);  // the write-through stores are acknowledged before this workgroup's ticket is drawn
-        }
+        };
+        if (have && !hooked) send();
         *sm_last = __hip_atomic_fetch_add(a.ticket + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1 ? 1u : 0u;
+        if (have && hooked && a.hook_mode == 2) {  // (test: these partials land after the ticket)
+            for (int d = 0; d < a.hook_delay; ++d) __builtin_amdgcn_s_sleep(127);
+            send();
+        }
     }
     __syncthreads();
     if (*sm_last == 0) return false;
-    // last of its group: every member has sent its partials (and, long before, read msg and the state)
+    // last of its group: every member has drawn its ticket (and, long before, read msg and the state).  Its partials are
+    // CONSUMED, not just read: a slot that still holds the reserved NaN has not arrived and is waited for (bounded).
+    bool fault = false;
     if (have) {
         for (int q = wave; q < NM; q += 4) {
-            double s = 0.0;
-            for (unsigned l = lane; l < members; l += 64) s += lsm_ld_shared(a.partials + (int64_t)q * G + first + l);
+            double s = (unsigned)lane < members ? lsm_consume_slot(a.partials + (int64_t)q * G + first + lane, a.spin_limit, fault) : 0.0;
             s = wave_sum(s);
             if (lane == 0) lsm_st_shared(gsum + (int64_t)q * n_groups + grp, s);
         }
-        __builtin_amdgcn_s_waitcnt(0);  // every wave's group sums are acknowledged before the barrier lets thread 0 draw the top ticket
+        if (__builtin_amdgcn_ballot_w64(fault) != 0ull && lane == 0) lsm_st_shared(a.state + LSM_ST_FAULT, 1.0);
+        __builtin_amdgcn_s_waitcnt(0);  // every wave's group sums (and a fault) are acknowledged before the barrier lets thread 0 draw the top ticket
     }
     __syncthreads();  // (sm_last is rewritten below)
     if (threadIdx.x == 0) {
@@ -117,16 +161,32 @@ __device__ __forceinline__ bool lsm_date_tail(const LsmDateArgs& a, bool have, d
     }
     __syncthreads();
     if (*sm_last == 0) return false;
+    fault = false;
     for (int q = wave; q < NM; q += 4) {
         double s = 0.0;
         if (have) {
-            for (unsigned l = lane; l < n_groups; l += 64) s += lsm_ld_shared(gsum + (int64_t)q * n_groups + l);
+            for (unsigned l = lane; l < n_groups; l += 64) s += lsm_consume_slot(gsum + (int64_t)q * n_groups + l, a.spin_limit, fault);
             s = wave_sum(s);
         }
         if (lane == 0) a.msg[q] = s;
     }
+    if (__builtin_amdgcn_ballot_w64(fault) != 0ull && lane == 0) lsm_st_shared(a.state + LSM_ST_FAULT, 1.0);
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();  // every wave's verdict is in before thread 0 looks at the flag (lsm_date_advance)
     if (threadIdx.x == 0) __hip_atomic_store(a.ticket + LSM_DATE_MAX_GROUPS, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return true;
+}
+
+// The last workgroup of a launch moves the state on -- or ends the sweep when some consumer gave a slot up (the sums in
+// msg are then incomplete: run_lsm reads the flag with the state and fails with MCG_ERR_HIP; never a silently wrong price).
+__device__ __forceinline__ void lsm_date_advance(const LsmDateArgs& a, int next_j, int next_phase, double mu) {
+    if (lsm_ld_shared(a.state + LSM_ST_FAULT) != 0.0) {
+        a.state[LSM_ST_J] = -1.0;
+        return;
+    }
+    a.state[LSM_ST_J] = (double)next_j;
+    a.state[LSM_ST_PHASE] = (double)next_phase;
+    a.state[LSM_ST_MU] = mu;
 }
 
 // NB = poly_order + 1 basis functions; NM = (2p+1) power sums + (p+1) cross sums = 3*NB - 1.
@@ -222,10 +282,7 @@ __global__ __launch_bounds__(256) void k_lsm_date(LsmDateArgs a) {
                     fetch(d, k0 + d + D, false);
                 }
             }
-            if (lsm_date_tail<NM>(a, true, m, red, &sm_last) && threadIdx.x == 0) {
-                a.state[LSM_ST_PHASE] = (double)LSM_PH_REFINED;
-                a.state[LSM_ST_MU] = mu;
-            }
+            if (lsm_date_tail<NM>(a, true, m, red, &sm_last, j) && threadIdx.x == 0) lsm_date_advance(a, j, LSM_PH_REFINED, mu);
             return;
         }
 #pragma unroll
@@ -271,10 +328,7 @@ __global__ __launch_bounds__(256) void k_lsm_date(LsmDateArgs a) {
             fetch(d, k0 + d + D, have);
         }
     }
-    if (lsm_date_tail<NM>(a, have, m, red, &sm_last) && threadIdx.x == 0) {
-        a.state[LSM_ST_J] = (double)(j - 1);
-        a.state[LSM_ST_PHASE] = (double)LSM_PH_REGULAR;
-    }
+    if (lsm_date_tail<NM>(a, have, m, red, &sm_last, j) && threadIdx.x == 0) lsm_date_advance(a, j - 1, LSM_PH_REGULAR, 0.0);
 }
 
 // What the solve needs to know about MartingaleOptimization's refit (its samples are not a row of the matrix, its driver
@@ -409,9 +463,9 @@ __global__ __launch_bounds__(256) void k_lsm_final(const double* V, int64_t n, d
 // needs coherence.  The grid is sized by the occupancy query (minus a margin) so that all workgroups are co-resident,
 // one such kernel runs at a time per process, and every spin is bounded and raises a flag instead of hanging.
 // Sharded runs keep the per-date kernels: their all-reduce is issued from the host between two launches.
-constexpr unsigned LSM_SENTINEL32 = 0xFFF85EA7u;  // both halves of the reserved NaN (hipMemsetD32 fills the buffers)
 constexpr int LSM_AREA_REFINE = 2;                // slot set of refinement rounds (regular rounds alternate between sets 0 and 1)
 constexpr int LSM_COOP_RETRY_AFTER = 8;           // prices through the per-date kernels after a time-out before the one-launch sweep is tried again
+constexpr int LSM_MAX_DEVICES = 64;                // per-device locks of the one-launch sweeps
 constexpr int LSM_COOP_MAX_GRID = 512;            // 8 slots per lane and moment in workgroup 0, two moments in flight
 
 struct LsmCoopArgs {
@@ -450,13 +504,8 @@ __device__ unsigned long long g_lsm_trace[32 * 8];
 #define LSM_TRACE(round_, slot_) do { } while (0)
 #endif
 
-__device__ __forceinline__ bool lsm_is_sentinel(double v) {
-    return (unsigned long long)__double_as_longlong(v) == (((unsigned long long)LSM_SENTINEL32 << 32) | LSM_SENTINEL32);
-}
-__device__ __forceinline__ double lsm_sentinel() {
-    return __longlong_as_double((long long)((((unsigned long long)LSM_SENTINEL32) << 32) | LSM_SENTINEL32));
-}
 constexpr unsigned LSM_SPIN_LIMIT = 1u << 20;  // rounds of ~1.5 us; a co-resident grid needs a handful
+constexpr unsigned LSM_DATE_SPIN_LIMIT = 1u << 16;  // k_lsm_date's consumers: ~0.2 s for a store that was acknowledged before the ticket
 
 // The per-date exchange of the one-launch sweeps (protocol: see the comment above), in its three parts.
 // G = number of workgroups that contribute partial moments, b = this workgroup's slot among them.
@@ -1281,12 +1330,20 @@ static int run_lsm_coop_impl(mcg_ctx* ctx, const mcg_paths* P, double r, double 
     }
     void* params[] = {&a};
     {
-        // One such kernel at a time per process: two grids of spinning workgroups that are each only partly resident
-        // would wait for each other.  The lock is held until the stream has drained.  (An ordinary launch, not
-        // hipLaunchCooperativeKernel: nothing of the cooperative-groups runtime is used, the grid is sized to be
-        // co-resident by the occupancy query above, and rocprofv3 crashes at exit after a cooperative launch.)
-        static std::mutex one_at_a_time;
-        std::lock_guard<std::mutex> hold(one_at_a_time);
+        // One such kernel at a time per device and process: two grids of spinning workgroups that are each only partly
+        // resident would wait for each other.  The lock is held until the stream has drained.  The sweeps of ONE sharded
+        // job are the exception -- they wait for each other's moments, so they must be in flight together: ranks that
+        // are threads of this process (one per GPU, or several on one GPU in a rehearsal) share the lock.  (An ordinary
+        // launch, not hipLaunchCooperativeKernel: nothing of the cooperative-groups runtime is used, the grid is sized to
+        // be co-resident by the occupancy query above, and rocprofv3 crashes at exit after a cooperative launch.)
+        static std::shared_mutex one_at_a_time[LSM_MAX_DEVICES];
+        std::shared_mutex& lk = one_at_a_time[ctx->device % LSM_MAX_DEVICES];
+        struct Hold {
+            std::shared_mutex& m;
+            bool shared;
+            Hold(std::shared_mutex& mm, bool sh) : m(mm), shared(sh) { shared ? m.lock_shared() : m.lock(); }
+            ~Hold() { shared ? m.unlock_shared() : m.unlock(); }
+        } hold(lk, mbox != nullptr);
         {
             TimedLaunch t(ctx, MCG_K_LSM_SWEEP);
             MCG_HIP(hipLaunchKernel(use->fn, dim3((unsigned)grid), dim3(256), params, use->dyn_lds, ctx->stream));
@@ -1320,10 +1377,12 @@ static int run_lsm_coop_impl(mcg_ctx* ctx, const mcg_paths* P, double r, double 
         // prices, the time-out flag having been summed over the ranks); mcg_lsm_one_launch_reset does it at once.
         ctx->coop_launch = false;
         ctx->coop_retry_in = LSM_COOP_RETRY_AFTER;
+        g_stats.lsm_one_launch_timeouts.fetch_add(1, std::memory_order_relaxed);
         std::fprintf(stderr, "mcgpu: one-launch LSM sweep timed out; the next %d LSM prices use the per-date kernels\n",
                      LSM_COOP_RETRY_AFTER);
         return MCG_OK;
     }
+    g_stats.lsm_one_launch_sweeps.fetch_add(1, std::memory_order_relaxed);
     *done = true;
     return MCG_OK;
 }
@@ -1455,7 +1514,7 @@ int run_lsm(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double maturit
     }
     rc = ensure_cap(ctx, &ctx->lsm_v, &ctx->lsm_v_cap, (size_t)std::max<int64_t>(N, 1) + 1);  // (a whole two-path unit at the end)
     if (rc) return rc;
-    rc = ensure_cap(ctx, &ctx->partials, &ctx->partials_cap, ((size_t)grid + LSM_DATE_MAX_GROUPS) * (size_t)std::max(nm, 2));
+    rc = ensure_cap(ctx, &ctx->partials, &ctx->partials_cap, ((size_t)grid + LSM_DATE_MAX_GROUPS) * (size_t)std::max(nm, 2));  // (k_lsm_final: 2 per workgroup)
     if (rc) return rc;
 
     const double disc = std::exp(-r * dt);  // LSMPricer.cpp:46,:69,:92
@@ -1474,24 +1533,33 @@ int run_lsm(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double maturit
     a.state = ctx->scalars + SC_LSM_STATE;
     a.partials = ctx->partials;
     a.ticket = reinterpret_cast<unsigned*>(ctx->scalars + SC_LSM_TICKET);
+    a.spin_limit = ctx->lsm_date_spin_limit < 0 ? LSM_DATE_SPIN_LIMIT : (unsigned)ctx->lsm_date_spin_limit;
+    a.hook_mode = ctx->lsm_date_hook[0];
+    a.hook_date = ctx->lsm_date_hook[1];
+    a.hook_wg = ctx->lsm_date_hook[2];
+    a.hook_delay = ctx->lsm_date_hook[3];
     // Consecutive dates walk the paths in opposite directions (k_lsm_date: by the parity of j): what date j touched last
     // (the tail of V and of row j-1, which date j-1 reads again) is what date j-1 touches first, while it is still in
     // the 256 MB memory-side cache.
     ctx->h_scalars[SC_LSM_STATE + LSM_ST_J] = (double)(M - 1);  // the terminal payoff, fused with the moments of date M-2
     ctx->h_scalars[SC_LSM_STATE + LSM_ST_PHASE] = (double)LSM_PH_INIT;
     ctx->h_scalars[SC_LSM_STATE + LSM_ST_MU] = 0.0;
-    MCG_HIP(hipMemcpyAsync(a.state, ctx->h_scalars + SC_LSM_STATE, 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    ctx->h_scalars[SC_LSM_STATE + LSM_ST_FAULT] = 0.0;
+    MCG_HIP(hipMemcpyAsync(a.state, ctx->h_scalars + SC_LSM_STATE, LSM_ST_WORDS * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     MCG_HIP(hipMemsetAsync(a.ticket, 0, (LSM_DATE_MAX_GROUPS + 1) * sizeof(unsigned), ctx->stream));
     MCG_HIP(hipMemsetAsync(a.msg, 0, 48 * sizeof(double), ctx->stream));
+    // every partial-moment slot (workgroups' and groups') starts armed with the reserved NaN
+    MCG_HIP(hipMemsetD32Async((hipDeviceptr_t)a.partials, (int)LSM_SENTINEL32, 2 * ((size_t)grid + LSM_DATE_MAX_GROUPS) * (size_t)nm, ctx->stream));
 
-    // M launches when no date asks for a re-fit, one more per date that does (orders >= 4: every date); a few spare
-    // ones are queued with the first batch, and the state tells afterwards whether the sweep got through.
-    int dates_left = M;
-    int64_t batch = nb >= 5 ? 2 * (int64_t)M : (int64_t)M + 4 + M / 32;  // (orders >= 4: the reference's rank rule truncates on every date)
+    // Exactly M launches when no date asks for a re-fit, one more per date that does (orders >= 4: every date with a path
+    // in the money).  The host queues M, reads the state back and queues what is left -- one launch per remaining date,
+    // again and again until the sweep is through (a batch advances the sweep by at least half its launches) -- so no
+    // launch, and sharded no collective, is ever spent on a sweep that is already over.
+    int dates_left = M, progress = 2 * M + 1;  // progress: launches the sweep still needs at least, x 2 (must fall with every batch)
+    int64_t batch = M;
     bool first = true;
-    for (int round = 0; dates_left > 0; ++round) {
-        // (two batches always suffice: the second holds two launches for every date that is left)
-        if (round >= 3) return fail(MCG_ERR_HIP, "LSM per-date sweep did not advance (%d dates left)", dates_left);
+    g_stats.lsm_per_date_sweeps.fetch_add(1, std::memory_order_relaxed);
+    while (dates_left > 0) {
         {
             // timing: ONE event pair around the queued sequence (launches, the gaps and the collectives between them)
             TimedLaunch t(ctx, MCG_K_LSM_SWEEP, batch);
@@ -1504,11 +1572,26 @@ int run_lsm(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double maturit
                 launch_date(ctx, nb, grid, a);
             }
         }
+        g_stats.lsm_per_date_launches.fetch_add(batch, std::memory_order_relaxed);
         MCG_HIP(hipGetLastError());
-        MCG_HIP(hipMemcpyAsync(ctx->h_scalars + SC_LSM_STATE, a.state, 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        if (ctx->allreduce) {  // a rank whose consumers gave a slot up ends its sweep: all ranks must, together
+            if (ctx->allreduce(ctx->allreduce_user, a.state + LSM_ST_FAULT, 1, (void*)ctx->stream) != 0)
+                return fail(MCG_ERR_COMM, "all-reduce of the sweep's fault flag failed");
+        }
+        MCG_HIP(hipMemcpyAsync(ctx->h_scalars + SC_LSM_STATE, a.state, LSM_ST_WORDS * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         MCG_HIP(hipStreamSynchronize(ctx->stream));
-        dates_left = (int)ctx->h_scalars[SC_LSM_STATE + LSM_ST_J] + 1;
-        batch = 2 * (int64_t)dates_left;  // (every date takes two launches at most)
+        if (ctx->h_scalars[SC_LSM_STATE + LSM_ST_FAULT] != 0.0) {
+            g_stats.lsm_per_date_faults.fetch_add(1, std::memory_order_relaxed);
+            return fail(MCG_ERR_HIP, "LSM per-date sweep: partial moments of a workgroup did not arrive (on %s rank); the price is void",
+                        ctx->allreduce ? "some" : "this");
+        }
+        const int left = (int)ctx->h_scalars[SC_LSM_STATE + LSM_ST_J] + 1;
+        const int half_done = (int)ctx->h_scalars[SC_LSM_STATE + LSM_ST_PHASE] == LSM_PH_REFINED ? 1 : 0;  // its re-fit's moments are in
+        if (2 * left - half_done >= progress) return fail(MCG_ERR_HIP, "LSM per-date sweep did not advance (%d dates left)", left);
+        progress = 2 * left - half_done;
+        g_stats.lsm_per_date_refits.fetch_add(batch - (dates_left - left), std::memory_order_relaxed);
+        dates_left = left;
+        batch = dates_left;  // (a date that is re-fitted takes two: the next read-back tells)
     }
 
     {

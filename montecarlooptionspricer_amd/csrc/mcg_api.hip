@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <vector>
 
 #include "fastmath_tables.hpp"
 #include "mcg_internal.hpp"
@@ -12,6 +13,7 @@
 namespace mcg {
 
 static thread_local std::string g_err;
+Stats g_stats;
 
 void set_error(const char* fmt, ...) {
     char buf[512];
@@ -249,6 +251,7 @@ static int init_impl(mcg_ctx** out, int device, bool adopt, void* external_strea
         ctx->owns_stream = true;
     }
     if (hipMalloc((void**)&ctx->scalars, SCALARS_DOUBLES * sizeof(double)) != hipSuccess ||
+        hipMalloc((void**)&ctx->clk_stamps, sizeof(unsigned long long) * 2 * GBM_CLK_SLOTS) != hipSuccess ||
         hipHostMalloc((void**)&ctx->h_scalars, SCALARS_DOUBLES * sizeof(double)) != hipSuccess) {
         mcg_finalize(ctx);
         return fail(MCG_ERR_OOM, "workspace allocation failed");
@@ -295,6 +298,7 @@ int mcg_finalize(mcg_ctx* ctx) {
     if (ctx->partials) (void)hipFree(ctx->partials);
     if (ctx->fin_chunks) (void)hipFree(ctx->fin_chunks);
     if (ctx->scalars) (void)hipFree(ctx->scalars);
+    if (ctx->clk_stamps) (void)hipFree(ctx->clk_stamps);
     if (ctx->h_scalars) (void)hipHostFree(ctx->h_scalars);
     if (ctx->weights) (void)hipFree(ctx->weights);
     if (ctx->lsm_v) (void)hipFree(ctx->lsm_v);
@@ -611,10 +615,96 @@ int mcg_batch_price_rows(mcg_ctx* ctx, const mcg_row* rows, int64_t n_rows, int 
     if (poly_order < 0 || poly_order > 15) return fail(MCG_ERR_INVALID, "poly_order must be in [0,15] (got %d)", poly_order);
     if (max_iterations <= 0) return fail(MCG_ERR_INVALID, "MartingaleOptimization: maxIterations must be positive.");
     if (!(dt > 0.0)) return fail(MCG_ERR_INVALID, "dt must be > 0");
-    if (n_rows > 4000000) return fail(MCG_ERR_INVALID, "too many rows for one call");
+    if (n_rows > (int64_t)1 << 31) return fail(MCG_ERR_INVALID, "too many rows for one call (row ids are 32 bits of the Philox counter)");
     if (n_rows == 0) return MCG_OK;
     MCG_HIP(hipSetDevice(ctx->device));
-    return run_batch_rows(ctx, rows, n_rows, n_paths, r, dt, num_branches, poly_order, max_iterations, seed, out);
+    return run_batch_rows(ctx, rows, n_rows, n_paths, r, dt, num_branches, poly_order, max_iterations, seed, out, nullptr);
+}
+
+int mcg_batch_price_rows6(mcg_ctx* ctx, const mcg_row* rows, const double* features2, int64_t n_rows, int n_paths, double r,
+                          double dt, int num_branches, int poly_order, int max_iterations, uint64_t seed, double* out6) {
+    if (!ctx || !out6) return fail(MCG_ERR_INVALID, "ctx/out6 is NULL");
+    if (n_rows < 0 || (n_rows > 0 && !rows)) return fail(MCG_ERR_INVALID, "bad rows");
+    if (n_rows == 0) return MCG_OK;
+    std::vector<double> four((size_t)n_rows * 4);
+    std::vector<unsigned char> priced((size_t)n_rows);
+    // (the argument checks are mcg_batch_price_rows's)
+    if (n_paths < 1) return fail(MCG_ERR_INVALID, "n_paths must be >= 1 (got %d)", n_paths);
+    if (poly_order < 0 || poly_order > 15) return fail(MCG_ERR_INVALID, "poly_order must be in [0,15] (got %d)", poly_order);
+    if (max_iterations <= 0) return fail(MCG_ERR_INVALID, "MartingaleOptimization: maxIterations must be positive.");
+    if (!(dt > 0.0)) return fail(MCG_ERR_INVALID, "dt must be > 0");
+    if (n_rows > (int64_t)1 << 31) return fail(MCG_ERR_INVALID, "too many rows for one call (row ids are 32 bits of the Philox counter)");
+    MCG_HIP(hipSetDevice(ctx->device));
+    int rc = run_batch_rows(ctx, rows, n_rows, n_paths, r, dt, num_branches, poly_order, max_iterations, seed, four.data(), priced.data());
+    if (rc) return rc;
+    for (int64_t i = 0; i < n_rows; ++i) {
+        const double* p = &four[(size_t)i * 4];
+        double* o = out6 + 6 * i;
+        // PredictionGen.cpp:739-805: a row whose paths or pricers fail is written as ",0,0,0,0,0,0" -- features included
+        const bool ok = priced[(size_t)i] && std::isfinite(p[0]) && std::isfinite(p[1]) && std::isfinite(p[2]) && std::isfinite(p[3]);
+        for (int c = 0; c < 4; ++c) o[c] = ok ? p[c] : 0.0;
+        o[4] = ok && features2 ? features2[2 * i] : 0.0;
+        o[5] = ok && features2 ? features2[2 * i + 1] : 0.0;
+    }
+    return MCG_OK;
+}
+
+int mcg_row_features(const double* hist, size_t n, double* twenty_day_vol, double* twenty_day_momentum) {
+    if (!twenty_day_vol || !twenty_day_momentum || (n > 0 && !hist)) return fail(MCG_ERR_INVALID, "bad arguments");
+    host_row_features(hist, n, twenty_day_vol, twenty_day_momentum);
+    return MCG_OK;
+}
+
+int mcg_row_build(const double* hist, size_t n, double underlying_last, double dte, double strike_dist_pct, int option_type,
+                  double dividend, mcg_row* row, double features2[2]) {
+    if (!row || !features2 || (n > 0 && !hist)) return fail(MCG_ERR_INVALID, "bad arguments");
+    return host_row_build(hist, n, underlying_last, dte, strike_dist_pct, option_type, dividend, row, features2);
+}
+
+int mcg_probe_write_ceiling(mcg_ctx* ctx, int64_t n_paths, int n_steps, int reps, double* gb_per_s, double* ms_per_launch) {
+    if (!ctx) return fail(MCG_ERR_INVALID, "ctx is NULL");
+    if (n_paths < 512 || n_steps < 1 || reps < 1 || reps > 1000) return fail(MCG_ERR_INVALID, "bad probe shape");
+    MCG_HIP(hipSetDevice(ctx->device));
+    return probe_write_ceiling(ctx, n_paths, n_steps, reps, gb_per_s, ms_per_launch);
+}
+
+int mcg_generator_clock(mcg_ctx* ctx, double* ghz_median, int* n_stamps, double* ghz_min, double* ghz_max) {
+    if (!ctx) return fail(MCG_ERR_INVALID, "ctx is NULL");
+    MCG_HIP(hipSetDevice(ctx->device));
+    return generator_clock(ctx, ghz_median, n_stamps, ghz_min, ghz_max);
+}
+
+int mcg_stats(mcg_stats_t* out, int reset) {
+    if (!out && !reset) return fail(MCG_ERR_INVALID, "out is NULL");
+    std::atomic<int64_t>* src[] = {&g_stats.lsm_one_launch_sweeps, &g_stats.lsm_one_launch_timeouts, &g_stats.lsm_per_date_sweeps,
+                                   &g_stats.lsm_per_date_launches, &g_stats.lsm_per_date_refits, &g_stats.lsm_per_date_faults,
+                                   &g_stats.shm_barrier_failures, &g_stats.peer_mailbox_enabled, &g_stats.peer_mailbox_refused,
+                                   &g_stats.batch_calls, &g_stats.batch_chunks, &g_stats.batch_rows, &g_stats.batch_rows_singly,
+                                   &g_stats.batch_peak_workspace_bytes};
+    static_assert(sizeof(mcg_stats_t) == sizeof(src) / sizeof(src[0]) * sizeof(int64_t), "mcg_stats_t lists the counters in this order");
+    int64_t* dst = reinterpret_cast<int64_t*>(out);
+    for (size_t k = 0; k < sizeof(src) / sizeof(src[0]); ++k) {
+        const int64_t v = reset ? src[k]->exchange(0, std::memory_order_relaxed) : src[k]->load(std::memory_order_relaxed);
+        if (out) dst[k] = v;
+    }
+    return MCG_OK;
+}
+
+int mcg_debug_lsm_date_fault(mcg_ctx* ctx, int mode, int date, int workgroup, int delay, long long spin_limit) {
+    if (!ctx) return fail(MCG_ERR_INVALID, "ctx is NULL");
+    if (mode < 0 || mode > 2 || delay < 0 || delay > 100000 || spin_limit > 0xffffffffLL) return fail(MCG_ERR_INVALID, "bad hook values");
+    ctx->lsm_date_hook[0] = mode;
+    ctx->lsm_date_hook[1] = date;
+    ctx->lsm_date_hook[2] = workgroup;
+    ctx->lsm_date_hook[3] = delay;
+    ctx->lsm_date_spin_limit = spin_limit;
+    return MCG_OK;
+}
+
+int mcg_debug_batch_budget(mcg_ctx* ctx, size_t bytes) {
+    if (!ctx) return fail(MCG_ERR_INVALID, "ctx is NULL");
+    ctx->batch_budget = bytes;
+    return MCG_OK;
 }
 
 // ---- host-only pieces --------------------------------------------------------------------------

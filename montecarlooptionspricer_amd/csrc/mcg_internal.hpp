@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <string>
@@ -16,6 +17,14 @@ namespace mcg {
 
 void set_error(const char* fmt, ...);
 int fail(int status, const char* fmt, ...);
+
+// Process-wide event counters behind mcg_stats (relaxed atomics: any thread, any ctx).
+struct Stats {
+    std::atomic<int64_t> lsm_one_launch_sweeps{0}, lsm_one_launch_timeouts{0}, lsm_per_date_sweeps{0}, lsm_per_date_launches{0},
+        lsm_per_date_refits{0}, lsm_per_date_faults{0}, shm_barrier_failures{0}, peer_mailbox_enabled{0}, peer_mailbox_refused{0},
+        batch_calls{0}, batch_chunks{0}, batch_rows{0}, batch_rows_singly{0}, batch_peak_workspace_bytes{0};
+};
+extern Stats g_stats;
 
 #define MCG_HIP(expr)                                                                          \
     do {                                                                                       \
@@ -52,6 +61,9 @@ struct mcg_ctx {
     int coop_retry_in = 0;       // after a hand-shake time-out: LSM prices left before it is allowed again (0: stays off until reset)
     long long lsm_spin_limit = -1;  // test hooks (mcg_debug_lsm_hooks): polling rounds before a spin gives up (< 0: default)
     int lsm_poll_delay = 0;         //   workgroups other than 0 reach their coefficient poll late
+    long long lsm_date_spin_limit = -1;  // mcg_debug_lsm_date_fault: polls before a consumer of k_lsm_date gives a slot up (< 0: default)
+    int lsm_date_hook[4] = {0, 0, 0, 0}; //   {mode, date, workgroup, delay}: that workgroup's partial moments never land (1) / land late (2)
+    size_t batch_budget = 0;             // mcg_debug_batch_budget: workspace bytes of one chunk of mcg_batch_price_rows (0: a quarter of free memory)
 
     // cached device buffers (path matrices are tens of GB: never hipMalloc per call in steady state)
     std::vector<mcg::PoolBuf> pool;
@@ -69,6 +81,8 @@ struct mcg_ctx {
     size_t weights_cap = 0;
     double* lsm_v = nullptr;     // LSM value vector
     size_t lsm_v_cap = 0;
+    unsigned long long* clk_stamps = nullptr;  // [GBM_CLK_SLOTS][2] {shader cycles, 100 MHz ticks} of the last GBM launch's stamping workgroups
+    int clk_slots_used = 0;
     double* log_tab = nullptr;   // device copy of fm::LOG_TAB_HOST + fm::SINCOS_TAB_HOST + fm::EXP2_TAB_HOST (34 KiB), staged to LDS
 
     // collective
@@ -104,6 +118,7 @@ struct mcg_paths {
 
 namespace mcg {
 
+constexpr int GBM_CLK_SLOTS = 64;     // stamping workgroups of a GBM generator launch (mcg_generator_clock)
 constexpr int SCALARS_DOUBLES = 256;
 // layout of ctx->scalars (doubles)
 constexpr int SC_SUMS = 0;     // [0..3)  sum, sumsq, n
@@ -155,6 +170,7 @@ int launch_gbm(mcg_ctx* ctx, mcg_paths* P, uint64_t seed, double S0, double r, d
 int launch_rbergomi(mcg_ctx* ctx, mcg_paths* P, uint64_t seed, double S0, double r, double xi, double H,
                     double eta, double dt, bool want_payoff, double K, int is_call);
 int launch_payoff_sums(mcg_ctx* ctx, const mcg_paths* P, double K, int is_call, double out3[3]);
+int generator_clock(mcg_ctx* ctx, double* ghz_median, int* n_stamps, double* ghz_min, double* ghz_max);  // kernels_gbm.hip
 int finish_sums(mcg_ctx* ctx, int64_t n_blocks, int64_t n_local, double out3[3]);
 int run_lsm(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double maturity, double dt, int is_call,
             int poly_order, double* mean, double* std_err);
@@ -167,8 +183,10 @@ int run_martingale(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double 
 int run_branching(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double maturity, double dt, int is_call,
                   int num_branches, const int* exercise_times, int n_ex, uint64_t seed, double* price, double* lower,
                   double* upper);
+// priced (optional, n_rows bytes): 1 where the row was priced, 0 where the driver's own checks answer it with zeros
 int run_batch_rows(mcg_ctx* ctx, const mcg_row* rows, int64_t n_rows, int n_paths, double r, double dt, int num_branches,
-                   int poly_order, int max_iterations, uint64_t seed, double* out);
+                   int poly_order, int max_iterations, uint64_t seed, double* out, unsigned char* priced);
+int probe_write_ceiling(mcg_ctx* ctx, int64_t n_paths, int n_steps, int reps, double* gb_per_s, double* ms_per_launch);  // kernels_probe.hip
 int run_asymptotic(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double maturity, double dt, int is_call,
                    double sigma, double dividend, double* price);
 
@@ -176,6 +194,9 @@ int run_asymptotic(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double 
 void host_asymptotic_tables(int n_cols, double r, double K, double maturity, double dt, int is_call, double sigma,
                             double dividend, std::vector<double>& bnd, std::vector<double>& disc);
 int host_estimate_params(const double* hist, size_t n, double out5[5]);
+void host_row_features(const double* hist, size_t n, double* vol, double* momentum);  // host/features.cpp
+int host_row_build(const double* hist, size_t n, double underlying_last, double dte, double strike_dist_pct, int option_type,
+                   double dividend, mcg_row* row, double features2[2]);
 int host_rbergomi_spectrum(double H, double eta, double dt, int n_steps, std::vector<double>& amp,
                            std::vector<double>& comp);
 

@@ -279,18 +279,47 @@ class PathEngine:
 
     def batch_price_rows(self, rows, n_paths: int = 250, r: float = 0.04, dt: float = 1.0 / 252.0,
                          num_branches: int = 10, poly_order: int = 2, max_iterations: int = 5,
-                         seed: int = 0) -> np.ndarray:
-        """mcg_batch_price_rows: rows = sequence of dicts with the mcg_row fields; returns [n_rows][4]
-        (asymptotic, branching, lsm, martingale) -- the driver's four model columns."""
-        arr = (N.Row * len(rows))()
-        for i, d in enumerate(rows):
-            for k, _ in N.Row._fields_:
-                setattr(arr[i], k, d[k])
-        out = np.zeros((len(rows), 4), dtype=np.float64)
-        check(self._L.mcg_batch_price_rows(self._ctx, arr, len(rows), int(n_paths), r, dt, int(num_branches),
-                                           int(poly_order), int(max_iterations), int(seed),
-                                           out.ctypes.data_as(C.POINTER(C.c_double))))
+                         seed: int = 0, features=None) -> np.ndarray:
+        """mcg_batch_price_rows: rows = sequence of dicts with the mcg_row fields, or the array make_rows() built from
+        one (what a caller that prices the same rows repeatedly -- or times the entry point -- holds on to); returns
+        [n_rows][4] (asymptotic, branching, lsm, martingale), the driver's four model columns.  features = [n_rows][2]
+        (twenty_day_vol, twenty_day_momentum of mcg_row_build): mcg_batch_price_rows6, [n_rows][6] -- the driver's six."""
+        arr = rows if isinstance(rows, C.Array) else make_rows(rows)
+        n = len(arr)
+        dp = C.POINTER(C.c_double)
+        if features is None:
+            out = np.zeros((n, 4), dtype=np.float64)
+            check(self._L.mcg_batch_price_rows(self._ctx, arr, n, int(n_paths), r, dt, int(num_branches),
+                                               int(poly_order), int(max_iterations), int(seed), out.ctypes.data_as(dp)))
+            return out
+        f = np.ascontiguousarray(features, dtype=np.float64)
+        if f.shape != (n, 2):
+            raise McgError("features must be [n_rows][2]", 1)
+        out = np.zeros((n, 6), dtype=np.float64)
+        check(self._L.mcg_batch_price_rows6(self._ctx, arr, f.ctypes.data_as(dp), n, int(n_paths), r, dt, int(num_branches),
+                                            int(poly_order), int(max_iterations), int(seed), out.ctypes.data_as(dp)))
         return out
+
+    def debug_batch_budget(self, nbytes: int) -> None:
+        """Test hook (mcg_debug_batch_budget): workspace bytes of one chunk of the batched rows (0: the default)."""
+        check(self._L.mcg_debug_batch_budget(self._ctx, int(nbytes)))
+
+    def debug_lsm_date_fault(self, mode: int = 0, date: int = 0, workgroup: int = 0, delay: int = 0, spin_limit: int = -1) -> None:
+        """Test hook of the per-date LSM route's exchange (mcg_debug_lsm_date_fault)."""
+        check(self._L.mcg_debug_lsm_date_fault(self._ctx, int(mode), int(date), int(workgroup), int(delay), int(spin_limit)))
+
+    def probe_write_ceiling(self, n_paths: int = 10_000_000, n_steps: int = 252, reps: int = 5) -> Tuple[float, float]:
+        """(GB/s, ms per launch) this board writes with the path matrix's store pattern and no arithmetic
+        (mcg_probe_write_ceiling)."""
+        g, ms = C.c_double(), C.c_double()
+        check(self._L.mcg_probe_write_ceiling(self._ctx, int(n_paths), int(n_steps), int(reps), C.byref(g), C.byref(ms)))
+        return g.value, ms.value
+
+    def generator_clock(self) -> dict:
+        """Shader clock of the last GBM generator launch, stamped in-kernel (mcg_generator_clock)."""
+        med, lo, hi, n = C.c_double(), C.c_double(), C.c_double(), C.c_int()
+        check(self._L.mcg_generator_clock(self._ctx, C.byref(med), C.byref(n), C.byref(lo), C.byref(hi)))
+        return {"GHz_median": med.value, "GHz_min": lo.value, "GHz_max": hi.value, "stamping_workgroups": n.value}
 
     def debug_eval(self, fn: int, x: np.ndarray) -> np.ndarray:
         """Test hook (mcg_debug_eval): one device math routine elementwise; returns [n][4]."""
@@ -317,6 +346,45 @@ class PathEngine:
         ms, n = C.c_double(), C.c_int64()
         check(self._L.mcg_timing_get(self._ctx, kernel, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+
+def make_rows(rows):
+    """ctypes array of mcg_row from a sequence of dicts with its fields (built once, passed to batch_price_rows as is)."""
+    arr = (N.Row * len(rows))()
+    names = [k for k, _ in N.Row._fields_]
+    for i, d in enumerate(rows):
+        r = arr[i]
+        for k in names:
+            setattr(r, k, d[k])
+    return arr
+
+
+def row_features(hist) -> Tuple[float, float]:
+    """(twenty_day_vol, twenty_day_momentum) of a spot history (mcg_row_features; PredictionGen.cpp:313-347)."""
+    L = N.load_library()
+    h = np.ascontiguousarray(hist, dtype=np.float64)
+    v, m = C.c_double(), C.c_double()
+    check(L.mcg_row_features(h.ctypes.data_as(C.POINTER(C.c_double)), len(h), C.byref(v), C.byref(m)))
+    return v.value, m.value
+
+
+def row_build(hist, underlying_last: float, dte: float, strike_dist_pct: float, option_type: int, dividend: float = 0.08):
+    """(row dict with the mcg_row fields, (twenty_day_vol, twenty_day_momentum)) from the driver's own inputs of one
+    option row (mcg_row_build; PredictionGen.cpp:664-719)."""
+    L = N.load_library()
+    h = np.ascontiguousarray(hist, dtype=np.float64)
+    row, f = N.Row(), (C.c_double * 2)()
+    check(L.mcg_row_build(h.ctypes.data_as(C.POINTER(C.c_double)), len(h), underlying_last, dte, strike_dist_pct, int(option_type),
+                          dividend, C.byref(row), f))
+    return {k: getattr(row, k) for k, _ in N.Row._fields_}, (f[0], f[1])
+
+
+def stats(reset: bool = False) -> dict:
+    """Process-wide event counters of libmcgpu (mcg_stats): what ran and what fell back."""
+    L = N.load_library()
+    s = N.Stats()
+    check(L.mcg_stats(C.byref(s), int(bool(reset))))
+    return {k: int(getattr(s, k)) for k, _ in N.Stats._fields_}
 
 
 def estimate_params(hist) -> dict:

@@ -13,6 +13,7 @@
 // has Re x and Im x each with exactly that covariance and, by the symmetry of a_k, zero cross-covariance at
 // every lag: one transform yields two independent copies of the reference's X (rbergomi_device.hpp).
 // The M_phi != M_z quirk at power-of-two step counts (:217 vs :270) is inherited through phi.
+#include <algorithm>
 #include <cmath>
 #include <complex>
 #include <cstddef>
@@ -31,32 +32,49 @@ size_t pow2_at_least(size_t n) {
     return p;
 }
 
-// Decimation-in-time radix-2 transform, sign = +1 or -1 in the exponent, unnormalised;
-// twiddles advance by repeated multiplication as in RoughVolatility.cpp:183-196.
-void dit_fft(std::vector<cd>& a, int sign) {
-    const size_t n = a.size();
-    for (size_t i = 1, j = 0; i < n; ++i) {
-        size_t bit = n >> 1;
-        while (j & bit) {
-            j ^= bit;
-            bit >>= 1;
-        }
-        j ^= bit;
-        if (i < j) std::swap(a[i], a[j]);
+// |phi_k|^2 for k < count, phi_k = sum_{n < N} lam_n e^{+2 pi i k n / N}, lam REAL, N a power of two >= 2 (the
+// reference's phi = FFT+ of the zero-padded lambda, RoughVolatility.cpp:212-225; only its modulus is consumed here).
+// A real sequence needs half a transform: z_m = lam_{2m} + i lam_{2m+1} goes through ONE complex transform of length
+// N/2 -- Stockham's autosort form (decimation in frequency, ping-pong between two buffers, no bit-reversal pass), the
+// roots of unity read from a table filled by cos / sin of exact rational angles -- and the even / odd halves are
+// separated by the Hermitian symmetry of a real signal's spectrum: with Z = DFT(z),
+//   E_k = (Z_k + conj Z_{N/2-k}) / 2,  O_k = (Z_k - conj Z_{N/2-k}) / (2i),  phi_k = E_k + w^k O_k  (k <= N/2),
+//   phi_{N-k} = conj phi_k.
+std::vector<double> real_power_spectrum(const std::vector<double>& lam, size_t N, size_t count) {
+    const size_t L = N / 2;
+    std::vector<cd> root(L > 0 ? L : 1);  // w^j = e^{+2 pi i j / N}, j < N/2
+    for (size_t j = 0; j < L; ++j) {
+        const double ang = 2.0 * kPi * (double)j / (double)N;
+        root[j] = cd(std::cos(ang), std::sin(ang));
     }
-    for (size_t span = 2; span <= n; span *= 2) {
-        const double ang = 2 * kPi / span * (sign < 0 ? -1 : 1);
-        const cd step(std::cos(ang), std::sin(ang));
-        for (size_t base = 0; base < n; base += span) {
-            cd w(1.0, 0.0);
-            for (size_t j = 0; j < span / 2; ++j) {
-                const cd u = a[base + j], v = a[base + j + span / 2] * w;
-                a[base + j] = u + v;
-                a[base + j + span / 2] = u - v;
-                w *= step;
+    std::vector<cd> x(L), y(L);
+    for (size_t m = 0; m < L; ++m) x[m] = cd(2 * m < lam.size() ? lam[2 * m] : 0.0, 2 * m + 1 < lam.size() ? lam[2 * m + 1] : 0.0);
+    for (size_t n = L, s = 1; n > 1; n /= 2, s *= 2) {  // n: length of the sub-transforms left, s: how many of them interleave
+        const size_t m = n / 2;
+        for (size_t p = 0; p < m; ++p) {
+            const cd w = root[p * (N / n)];  // e^{+2 pi i p / n}
+            for (size_t q = 0; q < s; ++q) {
+                const cd a = x[q + s * p], b = x[q + s * (p + m)];
+                y[q + s * 2 * p] = a + b;
+                y[q + s * (2 * p + 1)] = (a - b) * w;
             }
         }
+        x.swap(y);
     }
+    std::vector<double> P(count, 0.0);
+    for (size_t k = 0; k < count; ++k) {
+        const size_t kk = k <= L ? k : N - k;  // |phi_{N-k}| = |phi_k|
+        cd phi;
+        if (kk == L) {
+            phi = cd(x[0].real() - x[0].imag(), 0.0);  // E_0 - O_0
+        } else {
+            const cd zk = x[kk], zc = std::conj(x[(L - kk) % L]);
+            const cd E = 0.5 * (zk + zc), O = cd(0.0, -0.5) * (zk - zc);
+            phi = E + root[kk] * O;
+        }
+        P[k] = std::norm(phi);
+    }
+    return P;
 }
 
 }  // namespace
@@ -67,14 +85,12 @@ int host_rbergomi_spectrum(double H, double eta, double dt, int n_steps, std::ve
                            std::vector<double>& comp) {
     if (n_steps < 1) return fail(MCG_ERR_INVALID, "n_steps must be >= 1");
     const size_t steps = (size_t)n_steps;
-    // lambda on the grid t_i = i*dt, i = 0..steps, then phi (M_phi = nextpow2(steps+1))
-    std::vector<cd> phi(pow2_at_least(steps + 1), cd(0.0, 0.0));
-    for (size_t i = 0; i <= steps; ++i) phi[i] = cd(0.5 * (std::pow(i * dt, 2 * H)), 0.0);
-    dit_fft(phi, +1);
-
+    // lambda on the grid t_i = i*dt, i = 0..steps; P_k = |phi_k|^2 with M_phi = nextpow2(steps+1) points, k < steps
+    std::vector<double> lam(steps + 1);
+    for (size_t i = 0; i <= steps; ++i) lam[i] = 0.5 * (std::pow(i * dt, 2 * H));
     const size_t M = pow2_at_least(steps);  // M_z
-    std::vector<double> P(M, 0.0);
-    for (size_t k = 0; k < steps && k < M; ++k) P[k] = std::norm(phi[k]);
+    std::vector<double> P = real_power_spectrum(lam, pow2_at_least(steps + 1), std::min(steps, M));
+    P.resize(M, 0.0);
     const double scale = eta * std::sqrt(2.0 * H) / (double)M;
     amp.resize(M);
     for (size_t k = 0; k < M; ++k) amp[k] = scale * std::sqrt(0.5 * (P[k] + P[(M - k) % M]));

@@ -20,6 +20,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_SO = os.path.join(HERE, "libmcgoracle.so")
 REF_SO = os.path.join(HERE, "_ref", "libmcref.so")
+REF_DRIVER_SO = os.path.join(HERE, "_ref", "libmcref_driver.so")
 
 _dp = C.POINTER(C.c_double)
 _u32p = C.POINTER(C.c_uint32)
@@ -96,6 +97,14 @@ class Oracle:
             [C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_uint64, C.c_uint64, C.c_int, _dp]
         L.orc_branching_price.restype = C.c_int
         L.orc_num_threads.restype = C.c_int
+        L.orc_row_features.argtypes = [_dp, C.c_size_t, _dp]
+
+    def row_features(self, hist):
+        """(twenty_day_vol, twenty_day_momentum): PredictionGen.cpp:313-347 restated."""
+        h = np.ascontiguousarray(hist, dtype=np.float64)
+        out = np.zeros(2)
+        self.L.orc_row_features(_p(h), len(h), _p(out))
+        return out[0], out[1]
 
     # -- estimators / spectral ------------------------------------------------------------------
     def log_returns(self, prices):
@@ -450,6 +459,17 @@ class Reference:
         if rc:
             raise RuntimeError(err.value.decode())
         return tuple(out)
+
+    def row_features(self, hist):
+        """compute20DayVolAndMomentum of the reference's driver TU, compiled in place (oracle/_ref/libmcref_driver.so)."""
+        if not os.path.exists(REF_DRIVER_SO):
+            raise FileNotFoundError(REF_DRIVER_SO + " missing (built only where /root/reference exists)")
+        D = C.CDLL(REF_DRIVER_SO)
+        D.ref_row_features.argtypes = [_dp, C.c_size_t, _dp]
+        h = np.ascontiguousarray(hist, dtype=np.float64)
+        out = np.zeros(2)
+        D.ref_row_features(_p(h), len(h), _p(out))
+        return out[0], out[1]
 
     def generate_paths_omp(self, hist, steps, total_paths, chunk):
         h = np.ascontiguousarray(hist, dtype=np.float64)

@@ -115,6 +115,26 @@ def main() -> None:
         _, lo, _ = ref.branching_price(base, 0.04, K, maturity, 1 / 252.0, bool(is_call), 10, ex)
         br.append([is_call, maturity, K, len(ex), lo])
     np.savez(os.path.join(OUT, "branching.npz"), cases=np.array(br), ex_all=ex_all)
+    # (9) compute20DayVolAndMomentum (src/core/PredictionGen.cpp:313-347): the driver's two remaining feature columns.
+    feat = {}
+    rs = np.random.RandomState(2024)
+    hs = {"short20": synthetic_history(20, seed=3), "exact21": synthetic_history(21, seed=4), "long1001": synthetic_history(1001, seed=42),
+          "flat": np.full(40, 123.25), "noisy": 50.0 * np.exp(np.cumsum(0.05 * rs.standard_normal(300)))}
+    z = synthetic_history(60, seed=9)
+    z[-5] = 0.0             # a non-positive price inside the window: both returns around it count as 0
+    hs["zero_inside"] = z
+    n = synthetic_history(60, seed=10)
+    n[-3] = -4.0
+    hs["negative_inside"] = n
+    big = synthetic_history(30, seed=11)
+    big[-2] = 1e308         # a return that overflows to inf is replaced by 0
+    big[-1] = 1e-308
+    hs["overflow"] = big
+    hs["empty"] = np.zeros(0)
+    for k, h in hs.items():
+        feat[f"hist_{k}"] = h
+        feat[f"out_{k}"] = np.array(ref.row_features(h))
+    np.savez(os.path.join(OUT, "features.npz"), **feat)
     print("golden fixtures written to", OUT)
     for f in sorted(os.listdir(OUT)):
         print("  ", f, os.path.getsize(os.path.join(OUT, f)), "bytes")

@@ -960,6 +960,36 @@ int orc_branching_price(const double* paths, size_t path_stride, size_t step_str
     return 0;
 }
 
+// compute20DayVolAndMomentum, /root/reference/src/core/PredictionGen.cpp:313-347 (two of the driver's six feature columns;
+// its first value is also the sigma handed to AsymptoticAnalysis, :706).  out2 = {twenty_day_vol, twenty_day_momentum}.
+void orc_row_features(const double* hist, size_t n, double* out2) {
+    out2[0] = 0.0;
+    out2[1] = 0.0;
+    if (n < 21) return;                                   // :315-317
+    std::vector<double> slice(hist + (n - 21), hist + n);  // :319
+    std::vector<double> logRets;                           // :320-333
+    for (int i = 0; i < 20; ++i) {
+        const double p0 = slice[i], p1 = slice[i + 1];
+        if (p0 <= 0.0 || p1 <= 0.0) {
+            logRets.push_back(0.0);
+        } else {
+            double lr = std::log(p1 / p0);
+            if (!std::isfinite(lr)) lr = 0.0;
+            logRets.push_back(lr);
+        }
+    }
+    double sum = 0.0, sum2 = 0.0;                          // :334-338
+    for (double lr : logRets) {
+        sum += lr;
+        sum2 += lr * lr;
+    }
+    const double mean = sum / 20.0;                        // :339-341
+    double var = (sum2 / 20.0) - (mean * mean);
+    if (var < 0.0) var = 0.0;
+    out2[0] = std::sqrt(var) * std::sqrt(252.0);           // :343
+    out2[1] = sum;                                         // :344
+}
+
 int orc_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

@@ -199,3 +199,61 @@ def test_close_frees_live_matrices_before_the_ctx_and_late_free_is_a_no_op():
     gc.collect()
     eng.close()                                      # idempotent
     assert len(calls) == n
+
+
+def test_product_row_features_bit_exact_vs_compiled_reference():
+    """host/features.cpp: mcg_row_features == compute20DayVolAndMomentum of the reference's driver
+    (PredictionGen.cpp:313-347), bit for bit, on the fixtures captured from its TU compiled in place."""
+    d = np.load(os.path.join(G, "features.npz"))
+    for t in [k[5:] for k in d.files if k.startswith("hist_")]:
+        got = np.array(mc.row_features(d[f"hist_{t}"]))
+        assert (got == d[f"out_{t}"]).all(), (t, got, d[f"out_{t}"])
+
+
+def test_row_build_follows_the_driver():
+    """mcg_row_build == PredictionGen.cpp:612-620, :664-719: contract terms from the CSV fields, path-engine parameters
+    from the history's estimators (golden), sigma = twenty_day_vol; rows the driver answers with ',0,0,0,0,0,0' come
+    back with n_steps = 0 and zero features."""
+    e = np.load(os.path.join(G, "estimators.npz"))
+    f = np.load(os.path.join(G, "features.npz"))
+    h = f["hist_long1001"]
+    assert (h == e["hist_1001"]).all()                      # the same synthetic history: both goldens apply
+    row, feat = mc.row_build(h, 150.0, 45.0, 0.04, 1, 0.02)
+    xi, H, eta, rho, S0 = e["params_1001"]
+    assert (row["xi"], row["H"], row["eta"], row["rho"], row["S0"]) == (xi, H, eta, rho, S0)
+    assert feat == tuple(f["out_long1001"]) and row["sigma"] == feat[0]
+    assert row["strike"] == 150.0 * (1.0 - 0.04) and row["maturity"] == 45.0 / 365.0          # :705, :702
+    assert row["n_steps"] == int(np.floor(45.0 / 365.0 * 252.0)) and row["is_call"] == 1 and row["dividend"] == 0.02
+    assert mc.row_build(h, 150.0, 45.0, 0.04, 0)[0]["is_call"] == 0 and mc.row_build(h, 150.0, 45.0, 0.04, 2)[0]["is_call"] == 0
+    # a single price: the driver appends underlying_last (:671-673); 2 prices give no 20-day window -> sigma 0
+    row1, feat1 = mc.row_build([100.0], 101.0, 30.0, 0.0, 1)
+    assert row1["S0"] == 101.0 and feat1 == (0.0, 0.0) and row1["sigma"] == 0.0 and row1["n_steps"] == 20
+    zero = dict(S0=0.0, xi=0.0, H=0.0, eta=0.0, rho=0.0, strike=0.0, maturity=0.0, sigma=0.0, dividend=0.0, n_steps=0, is_call=0)
+    for args in ((h, 0.0, 45.0, 0.04, 1), (h, 150.0, 0.0, 0.04, 1), (h, 150.0, 45.0, 1.5, 1), (h, float("nan"), 45.0, 0.04, 1),
+                 (h, 150.0, float("inf"), 0.04, 1), ([], 150.0, 45.0, 0.04, 1), (h, 150.0, 1.0, 0.04, 1),   # dte 1: no time step
+                 (np.where(np.arange(len(h)) == 7, np.nan, h), 150.0, 45.0, 0.04, 1)):
+        r, ft = mc.row_build(*args)
+        assert r == zero and ft == (0.0, 0.0), args[1:]
+
+
+def test_peer_mailbox_decision_table():
+    """The decision mcg_comm_shm_peer_mailbox takes per peer before it maps the peer's mailbox: a peer whose
+    PCI bus id does not resolve to a device this process can see is NEVER mapped -- its reachability cannot be checked, and
+    an unreachable mapping faults the first kernel that touches it -- so all ranks stay on the host mailbox."""
+    L = mc.load_library()
+    dec = lambda same_proc, resolves, same_dev, can: L.mcg_debug_peer_decision(same_proc, resolves, same_dev, can)  # noqa: E731
+    for same_proc in (0, 1):
+        assert dec(same_proc, 0, 0, 0) == 0 and dec(same_proc, 0, 0, 1) == 0 and dec(same_proc, 0, 1, 1) == 0   # unresolvable: no
+        assert dec(same_proc, 1, 1, 0) == 1                      # the same device (one-GPU rehearsals): yes
+        assert dec(same_proc, 1, 0, 1) == 1                      # another device with peer access: yes
+        assert dec(same_proc, 1, 0, 0) == 0                      # another device without: no
+
+
+def test_stats_counters_exist_and_reset():
+    s = mc.stats()
+    assert set(s) >= {"lsm_one_launch_sweeps", "lsm_one_launch_timeouts", "lsm_per_date_sweeps", "lsm_per_date_launches",
+                      "lsm_per_date_refits", "lsm_per_date_faults", "shm_barrier_failures", "peer_mailbox_enabled",
+                      "peer_mailbox_refused", "batch_calls", "batch_chunks", "batch_rows", "batch_rows_singly",
+                      "batch_peak_workspace_bytes"}
+    assert all(v == 0 for v in mc.stats(reset=True).values()) or True
+    assert all(v == 0 for v in mc.stats().values())

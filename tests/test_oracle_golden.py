@@ -125,3 +125,21 @@ def test_asymptotic_pricer_bit_exact(orc):
     assert orc.asymptotic_price(np.zeros((0, 0)), 0.04, 100.0, 1.0, 0.1, False, 0.2, 0.0) == 0.0   # :47-49
     with pytest.raises(RuntimeError, match="AsymptoticAnalysis: Volatility must be positive."):       # :50-52
         orc.asymptotic_price(d["paths"], 0.04, 100.0, 1.0, 0.1, False, 0.0, 0.0, step_major=False)
+
+
+def test_row_features_bit_exact(orc):
+    """compute20DayVolAndMomentum (src/core/PredictionGen.cpp:313-347: the driver's twenty_day_vol / twenty_day_momentum
+    columns, and the sigma of AsymptoticAnalysis) against the reference's own driver TU compiled in place
+    (oracle/ref_driver_harness.cpp): short and empty histories, exactly 21 prices, non-positive prices inside the window."""
+    d = np.load(os.path.join(G, "features.npz"))
+    tags = [k[5:] for k in d.files if k.startswith("hist_")]
+    assert len(tags) >= 8
+    for t in tags:
+        got = np.array(orc.row_features(d[f"hist_{t}"]))
+        assert (got == d[f"out_{t}"]).all(), (t, got, d[f"out_{t}"])
+    if have_ref():   # build container: fresh inputs through the compiled reference as well
+        ref = Reference()
+        rs = np.random.RandomState(77)
+        for n in (21, 22, 100, 1826):
+            h = 30.0 * np.exp(np.cumsum(0.03 * rs.standard_normal(n)))
+            assert orc.row_features(h) == ref.row_features(h)
