@@ -246,7 +246,7 @@ def extra_configs(eng, N) -> list:
     return out
 
 
-def widening_configs(eng, N) -> list:
+def widening_configs(eng, N, mc) -> list:
     """SURVEY 8(f) rows in this round's terms: the three other pricers of the reference's driver on the C3 matrix
     (GBM, 1M paths x 50 dates, device-resident) and the batched driver rows (20 000 option rows x 250 rBergomi paths, four
     prices each), once each after one untimed pass: device ms of the pricer's kernels (HIP events), the bytes its
@@ -291,33 +291,43 @@ def widening_configs(eng, N) -> list:
                          rho=-0.3, strike=S0 * float(rs.uniform(0.9, 1.1)), maturity=st / 252.0, sigma=float(rs.uniform(0.1, 0.6)),
                          dividend=0.08, n_steps=st, is_call=int(rs.randint(0, 2))))
     eng.batch_price_rows(rows[:64])
+    arr = mc.make_rows(rows)   # the C array of mcg_row, built ONCE: what is timed below is the entry point, not its marshalling
+    eng.batch_price_rows(arr, seed=1)
     eng.timing_reset()
     t0 = time.perf_counter()
     for _ in range(reps):
-        pr = eng.batch_price_rows(rows, seed=1)
+        pr = eng.batch_price_rows(arr, seed=1)
     wall = (time.perf_counter() - t0) / reps * 1e3
     ms, cnt = eng.timing_get(N.K_BATCH)
     cols = sum(r["n_steps"] + 1 for r in rows)
     # paths written once and read by each of the four pricers; branching additionally writes and re-reads F
     moved = 8.0 * 250 * cols * (1 + 4 + 2)
     out.append({"config": "mcg_batch_price_rows: 20 000 driver rows x 250 rBergomi paths (5-126 steps), four prices per row",
-                "rows": len(rows), "ms_per_call": wall, "rows_per_s": len(rows) / wall * 1e3, "kernel_ms_per_call": ms / max(cnt, 1),
-                "launches_per_call": 6, "bytes_moved_per_call": moved,
+                "rows": len(rows), "ms_per_call": wall, "rows_per_s": len(rows) / wall * 1e3, "kernel_ms_per_call": ms / reps,
+                "rows_per_s_of_device_time": len(rows) / (ms / reps) * 1e3, "launches_per_call": 6 * cnt // reps, "chunks_per_call": cnt // reps,
+                "timed": "mcg_batch_price_rows on a prebuilt array of mcg_row (upload, kernels, download, scatter); device time = the chunks' kernel spans",
+                "bytes_moved_per_call": moved,
                 "bytes_moved": "row matrices written once, read by the four pricers, F of the branching rows written and read",
-                "hbm_frac": moved / (ms / max(cnt, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "hbm_frac": moved / (ms / reps * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "note": "latency- and issue-bound small-row work: the HBM fraction is reported, not the bound",
                 "mean_prices": [float(x) for x in pr.mean(axis=0)]})
     return out
 
 
-def install_collective(eng, mc, want: str, dist, torch, rank: int, world: int) -> str:
-    """Give `eng` the collective `want` ("shm", "ipc", "rccl", "torch") -- every rank ends up on the SAME one: a set-up
-    that fails on any rank sends all of them one step down (ipc -> shm -> rccl -> torch).  Returns what is installed."""
-    def everyone(ok: bool) -> bool:
-        t = torch.tensor([1 if ok else 0], device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        return int(t.item()) == 1
+def everyone(ok: bool, dist, torch, dev) -> bool:
+    """True iff `ok` on EVERY rank.  Every rank enters it -- from its except branch too -- so it doubles as the point where
+    the ranks of a step that may fail locally meet again, whatever happened to them."""
+    t = torch.tensor([1 if ok else 0], device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return int(t.item()) == 1
 
+
+def install_collective(eng, mc, want: str, dist, torch, rank: int, world: int, dev="cuda") -> str:
+    """Give `eng` the collective `want` ("ipc", "shm", "rccl", "torch") -- every rank ends up on the SAME one: a set-up
+    that fails on any rank sends all of them one step down (ipc -> shm -> rccl -> torch).  Returns what is installed.
+    No rank can be left alone in a collective: whatever a rank does before a broadcast cannot fail (the segment's name is
+    a string; the RCCL id is created inside a try and an empty one is broadcast on failure, PathEngine.init_rccl), and
+    every local step that can fail is followed by everyone()."""
     got = want
     if want in ("shm", "ipc"):
         box = [f"/mcg_bench_{os.getpid()}_{time.time_ns()}" if rank == 0 else None]
@@ -328,11 +338,20 @@ def install_collective(eng, mc, want: str, dist, torch, rank: int, world: int) -
         except mc.McgError as e:
             print(f"bench: shared-memory communicator unavailable ({e}); using RCCL", file=sys.stderr)
             ok = False
-        if not everyone(ok):
+        if not everyone(ok, dist, torch, dev):
             eng.set_allreduce(None)
             got = f"rccl ({want} init failed" + ("" if not ok else " on a peer") + ")"
-        elif want == "ipc" and not eng.shm_peer_mailbox(True):   # (collective over the segment: the ranks agree inside)
-            got = "shm (peer-memory mailbox unavailable: export, open or in-kernel ping failed on some rank)"
+        elif want == "ipc":
+            try:     # (collective over the segment: the ranks agree inside; an error poisons the segment for all of them)
+                peer = eng.shm_peer_mailbox(True)
+            except mc.McgError as e:
+                print(f"bench: peer-memory mailbox failed ({e})", file=sys.stderr)
+                peer, ok = False, False
+            if not everyone(ok, dist, torch, dev):
+                eng.set_allreduce(None)
+                got = "rccl (ipc set-up failed" + ("" if not ok else " on a peer") + ")"
+            elif not peer:
+                got = "shm (peer-memory mailbox unavailable: export, open or in-kernel ping failed on some rank)"
     if got.startswith("rccl"):
         def bcast(uid):
             box = [uid]
@@ -344,7 +363,7 @@ def install_collective(eng, mc, want: str, dist, torch, rank: int, world: int) -
         except mc.McgError as e:           # communicator set-up failed on this node: use torch's, and say so
             print(f"bench: built-in RCCL communicator unavailable ({e}); using torch.distributed", file=sys.stderr)
             ok = False
-        if not everyone(ok):               # all ranks take the same route
+        if not everyone(ok, dist, torch, dev):               # all ranks take the same route
             got = "torch (built-in RCCL init failed" + ("" if not ok else " on a peer") + ")"
             eng.use_torch_distributed()
     elif got == "torch":
@@ -357,57 +376,93 @@ def c5_sharded_rows(args, mc, N, dist, torch, device, stream, rank, world) -> li
     LSM order 2, 252 steps, --c5-paths (8M) paths per GPU of ONE Philox stream, timed through each collective of
     --c5-collectives in turn on a fresh context.  One untimed pass, then 3 timed between barriers; per row: the slowest
     and the fastest rank's ms per pass, the collective that ran, what its communicator has seen (mcg_comm_info), the
-    launches of the LSM sweep per pass (1 = the one-launch sweep exchanged inside the kernel) and the global price."""
+    launches of the LSM sweep per pass (1 = the one-launch sweep exchanged inside the kernel) and the global price.
+    A row is a sequence of local phases; after each the ranks meet in everyone(): a rank that raised is there too, so the
+    row is recorded as failed on ALL ranks at once instead of some of them waiting in the next collective."""
     from montecarlooptionspricer_amd.sharding import shard_range
     rows, reps, steps = [], 3, 252
     total = args.c5_paths * world
     begin, count = shard_range(total, rank, world, align=2)
+    dev = torch.device("cuda", device)
     for want in [c for c in args.c5_collectives.split(",") if c]:
-        e5 = mc.PathEngine(device, stream=stream)
-        try:
-            got = "none (every rank prices its own shard alone: a local price, the baseline the routes below add their exchange to)" \
-                if want == "none" else install_collective(e5, mc, want, dist, torch, rank, world)
-            info = e5.comm_info()
+        e5, err, row = None, None, None
 
-            def one_pass():
-                P = e5.rbergomi(SEED, RB["S0"], RB["r"], RB["xi"], RB["H"], RB["eta"], RB["rho"], DT, steps, count, path_begin=begin)
-                r = e5.price_lsm(P, RB["r"], 100.0, steps * DT, DT, False, 2)
-                P.free()
-                return r
+        def phase(fn):
+            """Run a local step; every rank then learns whether it worked everywhere."""
+            nonlocal err
+            ok = True
+            if err is None:
+                try:
+                    fn()
+                except Exception as ex:   # noqa: BLE001
+                    err, ok = f"{type(ex).__name__}: {ex}", False
+            else:
+                ok = False
+            return everyone(ok, dist, torch, dev)
 
+        st = {}
+
+        def setup():
+            nonlocal e5
+            e5 = mc.PathEngine(device, stream=stream)
+
+        def one_pass():
+            P = e5.rbergomi(SEED, RB["S0"], RB["r"], RB["xi"], RB["H"], RB["eta"], RB["rho"], DT, steps, count, path_begin=begin)
+            r = e5.price_lsm(P, RB["r"], 100.0, steps * DT, DT, False, 2)
+            P.free()
+            return r
+
+        def warm():
             one_pass()
             e5.synchronize()
             torch.cuda.synchronize()
-            dist.barrier()
+
+        def timed():
             e5.timing_enable(True)
             e5.timing_reset()
             t0 = time.perf_counter()
             for _ in range(reps):
-                price, se = one_pass()
+                st["price"], st["se"] = one_pass()
             e5.synchronize()
             torch.cuda.synchronize()
-            mine = (time.perf_counter() - t0) / reps * 1e3
-            dist.barrier()
-            t = torch.tensor([mine, -mine], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            ms_max, ms_min = float(t[0].item()), -float(t[1].item())
-            gen_ms, _ = e5.timing_get(N.K_RBERGOMI)
-            sw_ms, sw_n = e5.timing_get(N.K_LSM_SWEEP)
-            seen = torch.tensor([info["seen_ranks"]], device="cuda")
-            dist.all_reduce(seen, op=dist.ReduceOp.MIN)
-            rows.append({
-                "config": f"C5: rBergomi American put LSM order 2, {args.c5_paths} paths x {steps} steps per GPU, {world} rank(s) "
-                          f"= {total} paths of one Philox stream",
-                "collective_requested": want, "collective": got, "comm": dict(info, seen_ranks_min_over_ranks=int(seen.item())),
-                "paths_per_gpu": args.c5_paths, "global_paths": total,
-                "ms_per_pass_slowest_rank": ms_max, "ms_per_pass_fastest_rank": ms_min,
-                "Mpaths_per_s": total / ms_max / 1e3, "price": price, "std_err": se,
-                "rank0_generator_ms_per_pass": gen_ms / reps, "rank0_lsm_sweep_ms_per_pass": sw_ms / reps,
-                "rank0_lsm_sweep_launches_per_pass": sw_n // reps, "lsm_one_launch": e5.lsm_one_launch_enabled() and sw_n // reps <= 2})
-        except Exception as ex:   # a row that fails is reported, the others still run
-            rows.append({"config": "C5", "collective_requested": want, "error": str(ex)})
+            st["mine"] = (time.perf_counter() - t0) / reps * 1e3
+
+        try:
+            good = phase(setup)
+            if good:
+                # (install_collective agrees among the ranks inside; an exception there is the same on every rank)
+                st["got"] = "none (every rank prices its own shard alone: a local price, the baseline the routes below add their exchange to)" \
+                    if want == "none" else install_collective(e5, mc, want, dist, torch, rank, world, dev)
+                st["info"] = e5.comm_info()
+            good = good and phase(warm) and phase(timed)
+            if good:
+                t = torch.tensor([st["mine"], -st["mine"]], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                ms_max, ms_min = float(t[0].item()), -float(t[1].item())
+                gen_ms, _ = e5.timing_get(N.K_RBERGOMI)
+                sw_ms, sw_n = e5.timing_get(N.K_LSM_SWEEP)
+                seen = torch.tensor([st["info"]["seen_ranks"]], device=dev)
+                dist.all_reduce(seen, op=dist.ReduceOp.MIN)
+                row = {
+                    "config": f"C5: rBergomi American put LSM order 2, {args.c5_paths} paths x {steps} steps per GPU, {world} rank(s) "
+                              f"= {total} paths of one Philox stream",
+                    "collective_requested": want, "collective": st["got"],
+                    "comm": dict(st["info"], seen_ranks_min_over_ranks=int(seen.item())),
+                    "paths_per_gpu": args.c5_paths, "global_paths": total,
+                    "ms_per_pass_slowest_rank": ms_max, "ms_per_pass_fastest_rank": ms_min,
+                    "Mpaths_per_s": total / ms_max / 1e3, "price": st["price"], "std_err": st["se"],
+                    "rank0_generator_ms_per_pass": gen_ms / reps, "rank0_lsm_sweep_ms_per_pass": sw_ms / reps,
+                    "rank0_lsm_sweep_launches_per_pass": sw_n // reps,
+                    "lsm_one_launch": e5.lsm_one_launch_enabled() and sw_n // reps <= 2, "rank0_stats": mc.stats()}
+            else:
+                row = {"config": "C5", "collective_requested": want,
+                       "error": err or "a peer rank failed in this row (its own stderr says why); all ranks abandoned it together"}
+        except Exception as ex:   # (outside the phases: the collectives of this function itself)
+            row = {"config": "C5", "collective_requested": want, "error": f"{type(ex).__name__}: {ex}"}
         finally:
-            e5.close()
+            if e5 is not None:
+                e5.close()
+        rows.append(row)
     return rows
 
 
@@ -456,8 +511,8 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the C3/C4/C5-shard timings after the headline loop")
     ap.add_argument("--collective", default=os.environ.get("MCG_COLLECTIVE", "auto"), choices=["auto", "shm", "ipc", "rccl", "torch"],
-                    help="auto: shm (node-local shared memory; the LSM sweeps exchange inside the kernel) for c5, rccl for c2; "
-                         "ipc: shm with the in-kernel mailbox in peer-mapped device memory")
+                    help="auto: ipc for c5 (the LSM sweeps exchange inside the kernel through a mailbox in peer-mapped device memory; "
+                         "falls back to shm = the same mailbox in host memory, then rccl, then torch), rccl for c2")
     ap.add_argument("--c5-paths", type=int, default=8_000_000, help="paths per GPU of the C5 rows under extra.configs at N > 1")
     ap.add_argument("--c5-collectives", default="none,shm,ipc,rccl",
                     help="collectives the C5 rows at N > 1 are timed through (none: every rank prices its own shard alone -- the "
@@ -525,8 +580,8 @@ def main() -> None:
     collective = "none"
     if dist is not None:
         collective = args.collective
-        if collective == "auto":
-            collective = "shm" if args.config == "c5" else "rccl"
+        if collective == "auto":   # c5: the in-kernel mailbox in peer memory (xGMI on a node) first; it falls back by itself
+            collective = "ipc" if args.config == "c5" else "rccl"
         collective = install_collective(eng, mc, collective, dist, torch, rank, world)
 
     if args.config == "c2":
@@ -608,6 +663,18 @@ def main() -> None:
     k_ms, k_n = eng.timing_get(k_main)
     sweep_ms, sweep_n = eng.timing_get(N.K_LSM_SWEEP)
     solve_ms, solve_n = eng.timing_get(N.K_LSM_SOLVE)
+    # What lets a reader tell a slow board from a regression (boards of one pool differ by ~10 % on this power-limited
+    # kernel): the shader clock the timed launches ran at, stamped inside the last one by ~60 workgroups, and -- right after
+    # the timed region, device still at load -- what THIS board writes with the matrix's store pattern and no arithmetic.
+    clock, ceiling = None, None
+    if rank == 0:
+        try:
+            eng.timing_enable(False)
+            if args.config == "c2":
+                clock = eng.generator_clock()
+            ceiling = eng.probe_write_ceiling(count, n_steps, reps=5)
+        except Exception as e:   # noqa: BLE001 -- measurement aids only
+            print(f"bench: board probe failed ({e})", file=sys.stderr)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -654,7 +721,15 @@ def main() -> None:
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": kernel_name,
                          "kernel_avg_ms": k_avg_ms, "launches": int(k_n),
-                         "algorithmic_bytes_per_launch": alg_bytes},
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "board_write_ceiling_GBs": ceiling[0] if ceiling else None,
+                         "board_write_ceiling_ms_per_launch": ceiling[1] if ceiling else None,
+                         "frac_of_board_ceiling": achieved / ceiling[0] if ceiling else None,
+                         "board_write_ceiling_source": "mcg_probe_write_ceiling: 5 launches, right after the timed region, of a kernel that "
+                                                       "stores the same matrix with the generator's store pattern and no arithmetic",
+                         "shader_clock_GHz": clock,
+                         "shader_clock_source": "s_memtime / s_memrealtime stamps of ~60 workgroups of the last timed k_gbm_paths launch "
+                                                "(mcg_generator_clock)" if clock else None},
             "parity": parity,
         }
         if args.config == "c5":
@@ -697,7 +772,7 @@ def main() -> None:
         if world == 1 and dist is None and args.config == "c2" and not args.no_extra:
             try:
                 out["parity"]["rough_regime_vs_reference_sample"] = rough_regime_parity(eng)
-                out["extra"] = {"configs": extra_configs(eng, N) + widening_configs(eng, N)}
+                out["extra"] = {"configs": extra_configs(eng, N) + widening_configs(eng, N, mc)}
                 out["extra"]["c2_cold_first_launch_ms"] = cold_ms
             except Exception as e:
                 out["extra"] = {"configs": [], "error": str(e)}

@@ -267,12 +267,9 @@ static void launch_gbm_mode(mcg_ctx* ctx, const GbmArgs& a, int mode, unsigned n
     else hipLaunchKernelGGL((k_gbm_paths<PAYOFF, 0, PPL>), grid, block, 0, ctx->stream, a);
 }
 
-// paths per lane: 2 once every CU has several workgroups of 512 paths to work on (MCG_GBM_PPL overrides, for timing studies)
+// paths per lane: 2 once every CU has several workgroups of 512 paths to work on
 static int gbm_paths_per_lane(const mcg_ctx* ctx, int64_t n_paths) {
-    static const int forced = [] {
-        const char* e = std::getenv("MCG_GBM_PPL");
-        return e ? std::atoi(e) : 0;
-    }();
+    static const int forced = study_switch("MCG_GBM_PPL", 0);
     if (forced == 1 || forced == 2) return forced;
     return n_paths >= (int64_t)ctx->n_cus * 512 * 8 ? 2 : 1;
 }

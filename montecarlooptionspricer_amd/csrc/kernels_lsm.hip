@@ -1243,7 +1243,7 @@ static int run_lsm_coop_impl(mcg_ctx* ctx, const mcg_paths* P, double r, double 
     // workgroup 0 short: take the fewest paths per thread that need at most two workgroups per CU, else the most.
     const CoopVariant* use = nullptr;
     int grid = 0, workers = 0;
-    static const int min_ppt = std::getenv("MCG_LSM_COOP_MIN_PPT") ? std::atoi(std::getenv("MCG_LSM_COOP_MIN_PPT")) : 0;  // experiments
+    static const int min_ppt = study_switch("MCG_LSM_COOP_MIN_PPT", 0);
     static std::atomic<int> occ_cache[10][LSM_N_VARIANTS];  // workgroups per CU of each variant (0 = not asked yet); same on every device
     static std::atomic<int> regs_cache[10][LSM_N_VARIANTS]; // its VGPR count (hipFuncGetAttributes)
     for (int k = 0; eligible && k < LSM_N_VARIANTS; ++k) {
@@ -1445,10 +1445,7 @@ static int date_kernel_occupancy(int nb) {
     }
     // three per CU even where four fit (orders <= 3): 768 workgroups stream as fast as 1024 and leave fewer partials and
     // tickets to the tail (C5 shard, span per pass: 10.86 ms at four, 10.69 at three and at two)
-    int want = 3;
-    if (const char* e = std::getenv("MCG_LSM_DATE_WGS_PER_CU")) {  // timing studies: another number
-        if (std::atoi(e) >= 1) want = std::atoi(e);
-    }
+    const int want = std::max(1, study_switch("MCG_LSM_DATE_WGS_PER_CU", 3));
     occ = std::min(occ, want);
     cache[nb].store(occ, std::memory_order_relaxed);
     return occ;

@@ -207,14 +207,10 @@ static void launch_fft(mcg_ctx* ctx, const RbArgs& a, dim3 g, dim3 b, size_t sme
 }
 #undef MCG_RB_LAUNCH
 
-// workgroups per CU of the persistent FFT kernels (MCG_RB_GRID_PER_CU overrides, for timing studies)
+// workgroups per CU of the persistent FFT kernels
 static int rb_grid_per_cu() {
-    static const int v = [] {
-        const char* e = std::getenv("MCG_RB_GRID_PER_CU");
-        const int n = e ? std::atoi(e) : 0;
-        return n > 0 ? n : RB_WAVES;
-    }();
-    return v;
+    static const int v = study_switch("MCG_RB_GRID_PER_CU", 0);
+    return v > 0 ? v : RB_WAVES;
 }
 
 template <bool PAYOFF>

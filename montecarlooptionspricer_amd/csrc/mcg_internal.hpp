@@ -7,6 +7,7 @@
 #include <atomic>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <utility>
 #include <vector>
@@ -17,6 +18,17 @@ namespace mcg {
 
 void set_error(const char* fmt, ...);
 int fail(int status, const char* fmt, ...);
+
+// Timing-study switches (another grid size, another variant): read from the environment in A/B builds only
+// (tools/build_variant.sh ... -DMCG_STUDY_SWITCHES); the product library reads no such variable.
+inline int study_switch(const char* name, int fallback) {
+#ifdef MCG_STUDY_SWITCHES
+    if (const char* e = std::getenv(name)) return std::atoi(e);
+#else
+    (void)name;
+#endif
+    return fallback;
+}
 
 // Process-wide event counters behind mcg_stats (relaxed atomics: any thread, any ctx).
 struct Stats {

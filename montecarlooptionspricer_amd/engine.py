@@ -154,13 +154,20 @@ class PathEngine:
 
     def init_rccl(self, rank: int, world: int, broadcast_bytes: Callable[[Optional[bytes]], bytes]) -> None:
         """Built-in RCCL communicator.  broadcast_bytes(id_or_None) returns rank 0's 128-byte id on
-        every rank (e.g. via torch.distributed.broadcast_object_list)."""
-        uid = None
+        every rank (e.g. via torch.distributed.broadcast_object_list).  Rank 0 ALWAYS enters the broadcast: if it cannot
+        create the id it sends an empty one, and every rank raises -- no rank is left alone in a collective."""
+        uid, err = None, None
         if rank == 0:
             buf = C.create_string_buffer(128)
-            check(self._L.mcg_comm_unique_id(buf))
-            uid = buf.raw
+            if self._L.mcg_comm_unique_id(buf) != 0:
+                msg = self._L.mcg_last_error()
+                err = msg.decode() if msg else "mcg_comm_unique_id failed"
+                uid = b""
+            else:
+                uid = buf.raw
         uid = broadcast_bytes(uid)
+        if not uid:
+            raise McgError("rank 0 could not create the RCCL id" + (f": {err}" if err else ""), 7)
         check(self._L.mcg_comm_init_rank(self._ctx, uid, int(world), int(rank)))
 
     def init_shm(self, name: str, rank: int, world: int, peer_mailbox: bool = False) -> bool:

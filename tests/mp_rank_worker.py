@@ -123,6 +123,7 @@ def main() -> None:
         P.free()
         b, c = shard_range(JOBS["rb_paths"], rank, world, align=2)
     res["allreduce_calls"] = {"3": calls.count(3), "8": calls.count(8)}
+    res["stats"] = mc.stats()   # this process's event counters: time-outs, fall-backs, re-fits
     res["shard"] = [b, c]
     eng.close()
     with open(f"{out_path}.{rank}", "w") as f:

@@ -52,15 +52,15 @@ def test_c5_shard_full_size():
     a.close()
     assert eu2 == eu and ese2 == ese
     assert abs(am2 - am) <= 1e-9 * am and abs(ase2 - ase) <= 1e-9 * ase
-    # 3p+2 moments between two launches of the per-date kernel (one per date + the spare ones); payoff + final sums
-    assert calls.count(8) == per_date_launches(steps) - 1 and calls.count(3) == 2
+    # 3p+2 moments between two launches of the per-date kernel (exactly one launch per column: no spare launch, no spare
+    # collective), the sweep's fault flag once, payoff + final sums
+    assert calls.count(8) == per_date_launches(steps) - 1 and calls.count(3) == 2 and calls.count(1) == 1
 
 
-def per_date_launches(steps):
-    """k_lsm_date launches the host queues for a sweep of `steps` + 1 columns when no date asks for a re-fit: one per
-    column plus a few spare ones that return at once (kernels_lsm.hip: run_lsm)."""
-    m = steps + 1
-    return m + 4 + m // 32
+def per_date_launches(steps, refits=0):
+    """k_lsm_date launches of a sweep over `steps` + 1 columns: one per column, plus one per re-fitted date -- the host
+    queues exactly those (kernels_lsm.hip: run_lsm reads the device-side state back and queues what is left)."""
+    return steps + 1 + refits
 
 
 def _free_port():
@@ -134,14 +134,16 @@ def test_two_rank_processes_equal_single_rank(tmp_path, mode):
             assert abs(got[1] - want[1]) <= max(tol, 1e-9) * abs(want[1]), (r, got, want)
         if mode == "gloo":
             # one all-reduce BETWEEN two launches of the per-date kernel, nothing else per date
-            # (plus the three near-degenerate matrices: two dates each, one final sum each)
+            # (plus the three near-degenerate matrices: three columns each, the middle date re-fitted, one final sum each)
             assert res["allreduce_calls"] == {"3": 4 + len(DEGENERATE),
                                               "8": per_date_launches(JOBS["lsm_steps"]) + per_date_launches(JOBS["rb_steps"]) - 2
-                                                   + len(DEGENERATE) * (per_date_launches(2) - 1)}
+                                                   + len(DEGENERATE) * (per_date_launches(2, refits=1) - 1)}
+            assert res["stats"]["lsm_per_date_refits"] == len(DEGENERATE) and res["stats"]["lsm_per_date_faults"] == 0
             assert res["gbm_lsm_sweep_launches"] == per_date_launches(JOBS["lsm_steps"]) + 1   # + the final sums
             assert res["comm"]["kind"] == "callback"
         elif mode in ("shm", "shm4", "ipc", "ipc4"):
             assert res["one_launch_enabled"], "\n".join(logs)                       # no hand-shake ever timed out
+            assert res["stats"]["lsm_one_launch_timeouts"] == 0 and res["stats"]["shm_barrier_failures"] == 0, res["stats"]
             assert res["gbm_lsm_sweep_launches"] == 1 and res["rb_lsm_sweep_launches"] == 1
             assert res["comm"]["n_ranks"] == world and res["comm"]["seen_ranks"] == world and res["comm"]["rank"] == r
             if mode.startswith("ipc"):   # every rank exported, opened and pinged: the mailbox is in device memory

@@ -684,8 +684,9 @@ def test_allreduce_callback_plumbing():
     l2, lse2 = e.price_lsm(P, 0.04, 100.0, 1.0, 0.02, False, 2)
     assert abs(m2 - m1) <= 1e-13 * m1 and abs(se2 * math.sqrt(2.0) - se1) <= 1e-4 * se1
     assert abs(l2 - l1) <= 1e-12 * l1 and abs(lse2 * math.sqrt(2.0) - lse1) <= 1e-4 * lse1
-    # 3p+2 = 8 moments between two launches of the per-date kernel: 51 columns + 5 spare launches that return at once
-    assert calls.count(3) == 2 and calls.count(8) == 51 + 4 + 51 // 32 - 1
+    # 3p+2 = 8 moments between two launches of the per-date kernel -- 51 columns, 51 launches, none spare -- and the
+    # sweep's fault flag once
+    assert calls.count(3) == 2 and calls.count(8) == 50 and calls.count(1) == 1
     e.set_allreduce(None)
     m3, _ = e.price_european(P, 100.0, 0.04, 1.0, False)
     assert m3 == m1
