@@ -34,10 +34,12 @@ struct GbmArgs {
     int is_call;
     double* partials;  // [gridDim.x][2]
     const double2* log_tab;  // fm::LOG_TAB_HOST on the device
-    // mcg_generator_clock: workgroups whose index is clk_first + k * clk_stride stamp their life with the shader-cycle and
-    // the 100 MHz counters into slot k (two scalar reads at each end of ~40 workgroups per launch: nothing on the hot path)
+    // mcg_generator_clock: the workgroups whose index is clk_first modulo 2^clk_shift stamp their life with the shader-cycle
+    // and the 100 MHz counters into slot (index >> clk_shift) -- two scalar reads at each end of <= 64 workgroups per
+    // launch; the start stamps wait in LDS, not in registers (the kernel has no scalar register to spare: held in four
+    // of them for the kernel's life, the stamps pushed Horner constants out into spilled lanes)
     unsigned long long* clk;
-    unsigned clk_first, clk_stride;
+    unsigned clk_first, clk_shift;
 };
 
 // MODE 0: any parameters.  MODE 1 (SMALL): the host has checked |drift| + vol * 7.55 <= 0.125, so every step's exponent
@@ -70,12 +72,17 @@ __global__ __launch_bounds__(256) void k_gbm_paths(GbmArgs a) {
 #ifdef MCG_GBM_NO_STAMPS  // (A/B builds: the kernel without its clock stamps)
     const bool stamps = false;
 #else
-    const bool stamps = a.clk != nullptr && blockIdx.x >= a.clk_first && (blockIdx.x - a.clk_first) % a.clk_stride == 0;  // (wave-uniform)
+    const bool stamps = a.clk != nullptr && (blockIdx.x & ((1u << a.clk_shift) - 1u)) == a.clk_first;  // (wave-uniform)
 #endif
-    unsigned long long t_cyc = 0, t_ref = 0;
-    if (stamps) {
-        t_cyc = __builtin_amdgcn_s_memtime();
-        t_ref = __builtin_amdgcn_s_memrealtime();
+    // (everything the end of the kernel needs -- whether this workgroup stamps, where to, the start stamps -- waits in LDS)
+    __shared__ unsigned long long stamp0[3];
+    if (threadIdx.x == 0) {
+        stamp0[2] = 0;
+        if (stamps && (blockIdx.x >> a.clk_shift) < (unsigned)GBM_CLK_SLOTS) {
+            stamp0[2] = (unsigned long long)(a.clk + 2 * (blockIdx.x >> a.clk_shift));
+            stamp0[0] = __builtin_amdgcn_s_memtime();
+            stamp0[1] = __builtin_amdgcn_s_memrealtime();
+        }
     }
     const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * PPL;  // first column of this lane
     const bool in_row = PPL == 1 || i < a.ld;
@@ -147,13 +154,11 @@ __global__ __launch_bounds__(256) void k_gbm_paths(GbmArgs a) {
             }
         }
     }
-    if (stamps) {
+    if (threadIdx.x == 0 && stamp0[2] != 0) {
         const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
-        const unsigned slot = (blockIdx.x - a.clk_first) / a.clk_stride;
-        if (threadIdx.x == 0 && slot < (unsigned)GBM_CLK_SLOTS) {
-            a.clk[2 * slot] = c1 - t_cyc;
-            a.clk[2 * slot + 1] = r1 - t_ref;
-        }
+        unsigned long long* dst = (unsigned long long*)stamp0[2];
+        dst[0] = c1 - stamp0[0];
+        dst[1] = r1 - stamp0[1];
     }
     if (PAYOFF) {
         __shared__ double red[2 * 4];
@@ -299,18 +304,18 @@ int launch_gbm(mcg_ctx* ctx, mcg_paths* P, uint64_t seed, double S0, double r, d
     a.is_call = is_call;
     a.partials = ctx->partials;
     a.log_tab = (const double2*)ctx->log_tab;
-    // shader-clock stamps: up to GBM_CLK_SLOTS workgroups spread over the middle three quarters of the grid
+    // shader-clock stamps: one workgroup in every 2^shift, the smallest shift that needs at most GBM_CLK_SLOTS slots
     a.clk = nullptr;
     a.clk_first = 0;
-    a.clk_stride = 1;
+    a.clk_shift = 0;
     ctx->clk_slots_used = 0;
     if (ctx->clk_stamps && n_blocks >= 64) {
-        const int64_t span = n_blocks * 3 / 4;
-        const int slots = (int)std::min<int64_t>(GBM_CLK_SLOTS, span / 16);
+        unsigned shift = 2;
+        while (((n_blocks - 1) >> shift) >= GBM_CLK_SLOTS) ++shift;
         a.clk = ctx->clk_stamps;
-        a.clk_first = (unsigned)(n_blocks / 8);
-        a.clk_stride = (unsigned)std::max<int64_t>(1, span / slots);
-        ctx->clk_slots_used = (int)std::min<int64_t>(slots, (n_blocks - 1 - a.clk_first) / a.clk_stride + 1);
+        a.clk_shift = shift;
+        a.clk_first = (1u << shift) / 2;   // (the middle of each stretch; the last stretch may end before it)
+        ctx->clk_slots_used = (int)(((n_blocks - 1 - a.clk_first) >> shift) + 1);
         MCG_HIP(hipMemsetAsync(ctx->clk_stamps, 0, sizeof(unsigned long long) * 2 * GBM_CLK_SLOTS, ctx->stream));
     }
     {

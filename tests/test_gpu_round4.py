@@ -4,15 +4,12 @@ sharded job as eight threads of this process on GPU 0 (the pool's process guard 
 PROCESSES on one card are not possible there; eight rank threads are -- and one host thread per GPU is a deployment the
 reference's own OpenMP driver suggests)."""
 import math
-import threading
 
 import numpy as np
 import pytest
 
 import montecarlooptionspricer_amd as mc
 from montecarlooptionspricer_amd import _native as N
-from montecarlooptionspricer_amd.engine import _DevView
-from montecarlooptionspricer_amd.sharding import shard_range
 
 pytestmark = pytest.mark.gpu
 
@@ -210,13 +207,31 @@ def test_write_ceiling_probe_and_in_kernel_clock(eng):
     tiny.free()
 
 
+def test_bench_line_attributes_its_own_variance():
+    """bench.py's roofline object carries what separates a slow board from a regression: the board's own write ceiling,
+    measured in the same process right after the timed region, the fraction of it the generator reaches, and the shader
+    clock stamped inside the timed kernel."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-extra"],
+                       cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    j = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    r = j["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / 8000.0) < 1e-12
+    assert 3000.0 < r["board_write_ceiling_GBs"] < 8000.0
+    assert abs(r["frac_of_board_ceiling"] - r["achieved"] / r["board_write_ceiling_GBs"]) < 1e-12 and 0.5 < r["frac_of_board_ceiling"] < 1.05
+    c = r["shader_clock_GHz"]
+    assert c["stamping_workgroups"] >= 32 and 0.8 < c["GHz_min"] <= c["GHz_median"] <= c["GHz_max"] < 2.7
+
+
 # ------------------------------------------------------------------------------------------------
 # world size 8: eight rank threads of one process on GPU 0 (VERDICT r3, next #1)
 # ------------------------------------------------------------------------------------------------
-JOBS = dict(euro_paths=300_001, lsm_paths=200_001, lsm_steps=50, rb_paths=100_003, rb_steps=64)
-
-
-def _single_rank_reference():
+def _single_rank_reference(JOBS):
     e = mc.PathEngine(0)
     P = e.gbm(SEED, 100.0, 0.04, 0.2, DT, 252, JOBS["euro_paths"], payoff=(100.0, True))
     euro = e.price_european(P, 100.0, 0.04, 1.0, True)
@@ -233,98 +248,31 @@ def _single_rank_reference():
     return dict(euro=euro, gbm_lsm=lsm, rb_lsm=rb, rb_euro_put=rb_eu)
 
 
-def _run_rank_threads(world, mode, tag):
-    """Every rank a thread with a ctx of its own; returns the per-rank result dicts (or raises the first rank's error)."""
-    import torch
-    res, errs = [None] * world, []
-    bar = threading.Barrier(world)
-    acc = {}
-    lock = threading.Lock()
-
-    def allreduce_over_threads(rank):
-        def fn(ptr, count, _stream):
-            t = torch.as_tensor(_DevView(ptr, count), device="cuda:0")
-            h = t.cpu().numpy().copy()                   # (waits for the producing kernel: the ctx runs on torch's stream)
-            k = bar.wait()                                # phase 1: everybody is here (k: arrival index, unused)
-            with lock:
-                acc.setdefault("parts", {})[rank] = h
-            bar.wait()                                    # phase 2: all parts are in
-            tot = np.zeros(count)
-            for r in range(world):
-                tot += acc["parts"][r]                    # rank order: the same bits on every rank
-            bar.wait()                                    # phase 3: everybody has summed before anybody overwrites its part
-            t.copy_(torch.from_numpy(tot))
-            calls[rank].append(count)
-        return fn
-
-    calls = [[] for _ in range(world)]
-
-    def work(rank):
-        try:
-            if mode == "callback":
-                torch.cuda.set_device(0)
-                e = mc.PathEngine(0, stream=torch.cuda.current_stream().cuda_stream)
-                e.set_allreduce(allreduce_over_threads(rank))
-                peer = False
-            else:
-                e = mc.PathEngine(0)
-                peer = e.init_shm(f"/mcg_threads_{tag}", rank, world, peer_mailbox=(mode == "ipc"))
-            e.timing_enable(True)
-            out = {}
-            b, c = shard_range(JOBS["euro_paths"], rank, world)
-            P = e.gbm(SEED, 100.0, 0.04, 0.2, DT, 252, c, path_begin=b, payoff=(100.0, True))
-            out["euro"] = e.price_european(P, 100.0, 0.04, 1.0, True)
-            P.free()
-            b, c = shard_range(JOBS["lsm_paths"], rank, world)
-            P = e.gbm(SEED, 100.0, 0.04, 0.2, 0.02, JOBS["lsm_steps"], c, path_begin=b)
-            e.timing_reset()
-            out["gbm_lsm"] = e.price_lsm(P, 0.04, 100.0, 1.0, 0.02, False, 2)
-            out["gbm_lsm_sweep_launches"] = e.timing_get(N.K_LSM_SWEEP)[1]
-            P.free()
-            b, c = shard_range(JOBS["rb_paths"], rank, world, align=2)
-            out["shard"] = (b, c)
-            T = JOBS["rb_steps"] * DT
-            P = e.rbergomi(SEED, RB["S0"], RB["r"], RB["xi"], RB["H"], RB["eta"], RB["rho"], DT, JOBS["rb_steps"], c, path_begin=b)
-            e.timing_reset()
-            out["rb_lsm"] = e.price_lsm(P, RB["r"], 100.0, T, DT, False, 2)
-            out["rb_lsm_sweep_launches"] = e.timing_get(N.K_LSM_SWEEP)[1]
-            out["rb_euro_put"] = e.price_european(P, 100.0, RB["r"], T, False)
-            P.free()
-            out["one_launch_enabled"] = e.lsm_one_launch_enabled()
-            out["comm"] = e.comm_info()
-            out["peer_mailbox"] = bool(peer)
-            res[rank] = out
-            if mode != "callback":
-                e._L.mcg_synchronize(e._ctx)
-            bar.wait()                                    # nobody leaves (and frees its mailbox) while a peer may still push into it
-            e.close()
-        except BaseException as ex:   # noqa: BLE001
-            errs.append((rank, ex))
-            bar.abort()
-
-    th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
-    for t in th:
-        t.start()
-    for t in th:
-        t.join(300)
-    assert not any(t.is_alive() for t in th), "a rank thread hangs"
-    if errs:
-        raise errs[0][1]
-    return res, calls
-
-
 @pytest.mark.parametrize("mode", ["shm", "ipc", "callback"])
-def test_eight_rank_threads_equal_single_rank(mode):
+def test_eight_rank_threads_equal_single_rank(tmp_path, mode):
     """BASELINE.json configs[4]'s world size, on the one GPU there is: eight ranks of one sharded job as eight threads of
-    this process, each with its own ctx (and, shm / ipc, its own stream: the eight one-launch sweeps are resident on the
-    GPU together and exchange their per-date moments through an 8-row mailbox -- in the host segment, or in device memory
-    with every rank pushing into all eight copies).  Every rank must hold the single-rank price; shards are unequal and,
-    for rBergomi, even-aligned."""
+    ONE child process (tests/thread_ranks_worker.py; eight rank processes would exceed the pool's limit of six GPU
+    processes), each with its own ctx and -- shm / ipc -- its own stream and hardware queue: the eight one-launch sweeps
+    are resident on the GPU together and exchange their per-date moments through an 8-row mailbox, in the host segment
+    or in device memory with every rank pushing into all eight copies.  "callback": the per-date route with an all-reduce
+    over the eight threads.  Every rank must hold the single-rank price; shards are unequal and, for rBergomi,
+    even-aligned."""
+    import json
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    from thread_ranks_worker import JOBS
     world = 8
-    want = _single_rank_reference()
-    mc.stats(reset=True)
-    ranks, calls = _run_rank_threads(world, mode, f"{mode}8")
-    s = mc.stats()
+    want = _single_rank_reference(JOBS)
+    out_file = str(tmp_path / "ranks.json")
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="16", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(here, "thread_ranks_worker.py"), str(world), mode, out_file], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-4000:]
+    j = json.load(open(out_file))
+    ranks, calls, s = j["ranks"], j["calls"], j["stats"]
     for r, out in enumerate(ranks):
         for key, tol in (("euro", 1e-12), ("rb_euro_put", 1e-12), ("gbm_lsm", 1e-9), ("rb_lsm", 1e-9)):
             assert abs(out[key][0] - want[key][0]) <= tol * abs(want[key][0]), (mode, r, key, out[key], want[key])
@@ -334,9 +282,9 @@ def test_eight_rank_threads_equal_single_rank(mode):
             assert out["comm"]["kind"] == "callback"
             # exactly one all-reduce between two launches of the per-date kernel, one of the fault flag, one of the sums
             assert out["gbm_lsm_sweep_launches"] == JOBS["lsm_steps"] + 1 + 1
-            assert calls[r].count(8) == JOBS["lsm_steps"] + JOBS["rb_steps"] and calls[r].count(1) == 2 and calls[r].count(3) == 4
+            assert calls[r] == {"8": JOBS["lsm_steps"] + JOBS["rb_steps"], "1": 2, "3": 4}
         else:
-            assert out["one_launch_enabled"] and out["gbm_lsm_sweep_launches"] == 1 and out["rb_lsm_sweep_launches"] == 1
+            assert out["one_launch_enabled"] and out["gbm_lsm_sweep_launches"] == 1 and out["rb_lsm_sweep_launches"] == 1, p.stdout[-2000:]
             assert out["comm"]["n_ranks"] == world and out["comm"]["seen_ranks"] == world and out["comm"]["rank"] == r
             assert out["comm"]["kind"] == ("shm+peer-memory mailbox" if mode == "ipc" else "shm")
             assert out["peer_mailbox"] == (mode == "ipc")
