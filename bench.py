@@ -314,6 +314,31 @@ def widening_configs(eng, N, mc) -> list:
     return out
 
 
+class Gpu:
+    """What this script asks of torch.cuda (tests/bench_rehearsal.py has the CPU stand-in of --rehearsal)."""
+    name = "cuda"
+
+    @staticmethod
+    def set_device(d):
+        import torch
+        torch.cuda.set_device(d)
+
+    @staticmethod
+    def synchronize():
+        import torch
+        torch.cuda.synchronize()
+
+    @staticmethod
+    def current_stream_handle():
+        import torch
+        return torch.cuda.current_stream().cuda_stream
+
+    @staticmethod
+    def device_count():
+        import torch
+        return torch.cuda.device_count()
+
+
 def everyone(ok: bool, dist, torch, dev) -> bool:
     """True iff `ok` on EVERY rank.  Every rank enters it -- from its except branch too -- so it doubles as the point where
     the ranks of a step that may fail locally meet again, whatever happened to them."""
@@ -371,7 +396,7 @@ def install_collective(eng, mc, want: str, dist, torch, rank: int, world: int, d
     return got
 
 
-def c5_sharded_rows(args, mc, N, dist, torch, device, stream, rank, world) -> list:
+def c5_sharded_rows(args, mc, N, dist, torch, device, stream, rank, world, hw=Gpu, make_engine=None) -> list:
     """BASELINE.json configs[4] on this run's N ranks, after the headline loop: rBergomi (H = 0.1, eta = 1.9) American put,
     LSM order 2, 252 steps, --c5-paths (8M) paths per GPU of ONE Philox stream, timed through each collective of
     --c5-collectives in turn on a fresh context.  One untimed pass, then 3 timed between barriers; per row: the slowest
@@ -383,9 +408,11 @@ def c5_sharded_rows(args, mc, N, dist, torch, device, stream, rank, world) -> li
     rows, reps, steps = [], 3, 252
     total = args.c5_paths * world
     begin, count = shard_range(total, rank, world, align=2)
-    dev = torch.device("cuda", device)
+    dev = torch.device("cuda", device) if hw is Gpu else torch.device("cpu")
+    make_engine = make_engine or (lambda: mc.PathEngine(device, stream=stream))
     for want in [c for c in args.c5_collectives.split(",") if c]:
         e5, err, row = None, None, None
+        os.environ["MCG_REHEARSAL_ROW"] = want   # (read by the rehearsal's failure injection only)
 
         def phase(fn):
             """Run a local step; every rank then learns whether it worked everywhere."""
@@ -404,7 +431,7 @@ def c5_sharded_rows(args, mc, N, dist, torch, device, stream, rank, world) -> li
 
         def setup():
             nonlocal e5
-            e5 = mc.PathEngine(device, stream=stream)
+            e5 = make_engine()
 
         def one_pass():
             P = e5.rbergomi(SEED, RB["S0"], RB["r"], RB["xi"], RB["H"], RB["eta"], RB["rho"], DT, steps, count, path_begin=begin)
@@ -415,7 +442,7 @@ def c5_sharded_rows(args, mc, N, dist, torch, device, stream, rank, world) -> li
         def warm():
             one_pass()
             e5.synchronize()
-            torch.cuda.synchronize()
+            hw.synchronize()
 
         def timed():
             e5.timing_enable(True)
@@ -424,7 +451,7 @@ def c5_sharded_rows(args, mc, N, dist, torch, device, stream, rank, world) -> li
             for _ in range(reps):
                 st["price"], st["se"] = one_pass()
             e5.synchronize()
-            torch.cuda.synchronize()
+            hw.synchronize()
             st["mine"] = (time.perf_counter() - t0) / reps * 1e3
 
         try:
@@ -483,7 +510,7 @@ def c5_rows_in_child_job(args, dist, rank: int, world: int):
         if k.startswith("TORCHELASTIC_") or k in ("TORCH_NCCL_ASYNC_ERROR_HANDLING",):
             env.pop(k)
     cmd = [sys.executable, os.path.abspath(__file__), "--c5-child", "--gpus", str(world), "--backend", args.backend,
-           "--c5-paths", str(args.c5_paths), "--c5-collectives", args.c5_collectives]
+           "--c5-paths", str(args.c5_paths), "--c5-collectives", args.c5_collectives] + (["--rehearsal"] if args.rehearsal else [])
     rows = None
     try:
         p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
@@ -519,6 +546,9 @@ def main() -> None:
                          "time the exchange adds nothing to)")
     ap.add_argument("--backend", default=os.environ.get("MCG_DIST_BACKEND", "nccl"), choices=["nccl", "gloo"],
                     help="torch.distributed backend; gloo lets several ranks share one GPU (rehearsal only)")
+    ap.add_argument("--rehearsal", action="store_true",
+                    help="control-flow rehearsal of an N > 1 run on CPU ranks (gloo; tests/bench_rehearsal.py stands in for the GPU "
+                         "and the engine): every collective of this script runs, nothing is computed or timed, the line says so")
     ap.add_argument("--c5-child", action="store_true",
                     help="(internal) this process is one rank of the child job that times the C5 rows of an N > 1 run")
     args = ap.parse_args()
@@ -543,10 +573,19 @@ def main() -> None:
     from montecarlooptionspricer_amd import _native as N
     from montecarlooptionspricer_amd.sharding import shard_range
 
+    hw, make_engine = Gpu, None
+    if args.rehearsal:
+        if world < 2:
+            raise SystemExit("--rehearsal rehearses the N > 1 control flow: start it with several ranks")
+        from tests.bench_rehearsal import Cpu, RehearsalEngine
+        hw, args.backend = Cpu, "gloo"
+        make_engine = lambda: RehearsalEngine()   # noqa: E731
+    dev_name = hw.name
+
     dist = None
     force_dist = os.environ.get("MCG_FORCE_DIST") == "1"   # rehearse the collective path with one rank
-    device = local_rank % max(torch.cuda.device_count(), 1)
-    torch.cuda.set_device(device)
+    device = local_rank % max(hw.device_count(), 1)
+    hw.set_device(device)
     if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -561,8 +600,8 @@ def main() -> None:
     if args.c5_child:   # one rank of the child job: the C5 rows, nothing else; rank 0 prints them as one JSON list
         if os.environ.get("MCG_BENCH_C5_CHILD_FAIL") == "1":   # test hook: the child job dies; the parent's line must survive it
             os._exit(3)
-        stream = torch.cuda.current_stream().cuda_stream
-        rows = c5_sharded_rows(args, mc, N, dist, torch, device, stream, rank, world)
+        stream = hw.current_stream_handle()
+        rows = c5_sharded_rows(args, mc, N, dist, torch, device, stream, rank, world, hw, make_engine)
         if rank == 0:
             print(json.dumps(rows), file=json_out, flush=True)
         dist.barrier()
@@ -575,14 +614,14 @@ def main() -> None:
     total_paths = args.paths * world
     begin, count = shard_range(total_paths, rank, world, align=2 if args.config == "c5" else 1)
 
-    stream = torch.cuda.current_stream().cuda_stream if dist is not None else None
-    eng = mc.PathEngine(device, stream=stream)
+    stream = hw.current_stream_handle() if dist is not None else None
+    eng = make_engine() if make_engine else mc.PathEngine(device, stream=stream)
     collective = "none"
     if dist is not None:
         collective = args.collective
         if collective == "auto":   # c5: the in-kernel mailbox in peer memory (xGMI on a node) first; it falls back by itself
             collective = "ipc" if args.config == "c5" else "rccl"
-        collective = install_collective(eng, mc, collective, dist, torch, rank, world)
+        collective = install_collective(eng, mc, collective, dist, torch, rank, world, dev_name)
 
     if args.config == "c2":
         k_main = N.K_GBM
@@ -625,13 +664,13 @@ def main() -> None:
         queue has drained before the clock starts.  Same at every N; reported as config.untimed_ramp_launches (the same
         ramp also precedes the W warm-up steps)."""
         eng.synchronize()
-        torch.cuda.synchronize()
+        hw.synchronize()
         if ramp:
             run_ramp()
         if dist is not None:
             dist.barrier()
         eng.synchronize()
-        torch.cuda.synchronize()
+        hw.synchronize()
 
     # the very first launch of the measured kernel in this process, on a device that has been idle: reported, not timed
     eng.timing_enable(True)
@@ -657,9 +696,22 @@ def main() -> None:
     elapsed = time.perf_counter() - t0
     eng.timing_select(None)
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev_name)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    if args.rehearsal:   # nothing was computed or timed: say what ran, and stop
+        c5_rows = c5_rows_in_child_job(args, dist, rank, world) if not args.no_extra else None
+        if rank == 0:
+            print(json.dumps({"rehearsal": True, "metric": "Mpaths/sec at 252 steps", "value": None, "unit": "Mpaths/s", "n_gpus": world,
+                              "steps": args.steps, "warmup": args.warmup, "data": "none (control-flow rehearsal on CPU ranks: nothing computed, nothing timed)",
+                              "config": {"workload": "the N > 1 control flow of this script", "paths_per_gpu": args.paths, "global_paths": total_paths,
+                                         "collective": collective, "comm": eng.comm_info()},
+                              "ids_counted": price, "ids_summed": se,     # every rank's shard went through the collective once
+                              "extra": {"configs": c5_rows}}), file=json_out, flush=True)
+        eng.close()
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     k_ms, k_n = eng.timing_get(k_main)
     sweep_ms, sweep_n = eng.timing_get(N.K_LSM_SWEEP)
     solve_ms, solve_n = eng.timing_get(N.K_LSM_SOLVE)

@@ -11,7 +11,7 @@ import pytest
 
 from montecarlooptionspricer_amd import _native as N
 
-MAGIC = 0x4D434754
+MAGIC = 0x4D434755   # comm_shm.cpp: SHM_MAGIC (layout of round 4)
 SEG_BYTES = 16 << 20     # >= sizeof(ShmHeader) + the mailbox
 
 
@@ -122,3 +122,53 @@ def test_poison_releases_a_waiting_rank(L):
     assert not w.is_alive() and out["rc"] == 7
     L.mcg_debug_shm_detach(res[1][1])
     L.mcg_debug_shm_detach(res[0][1])
+
+
+@pytest.mark.parametrize("world", [8, 16])
+def test_eight_and_sixteen_ranks_join_and_stay_in_step(L, world):
+    """BASELINE.json configs[4]'s world size (and the segment's maximum): the ranks arrive in a scrambled order, rank 0 in
+    the middle; everybody joins the same fresh segment; 300 barriers keep them in step (no rank is ever seen a round
+    ahead of another between two barriers); a poison while fifteen of sixteen wait releases all of them at once."""
+    name = f"/mcg_pytest_w{world}_{os.getpid()}"
+    res, order = {}, [(5 * r + 3) % world for r in range(world)]
+    assert sorted(order) == list(range(world))
+    ts = []
+    for r in order:
+        t = threading.Thread(target=_attach, args=(L, name, world, r, 60.0, res, r))
+        t.start()
+        ts.append(t)
+        time.sleep(0.01)
+    for t in ts:
+        t.join(90)
+    assert all(res[r][0] == 0 for r in range(world)), res
+    rounds, at, errors = 300, [0] * world, []
+
+    def run(r):
+        for k in range(rounds):
+            at[r] = k
+            if L.mcg_debug_shm_barrier(res[r][1]) != 0:
+                errors.append((r, k, "barrier failed"))
+                return
+            lo, hi = min(at), max(at)          # everybody has reached round k; nobody can be beyond k + 1
+            if lo < k or hi > k + 1:
+                errors.append((r, k, lo, hi))
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(120)
+    assert not any(t.is_alive() for t in ts) and not errors, errors[:5]
+    out = {}
+    ws = [threading.Thread(target=lambda r=r: out.__setitem__(r, L.mcg_debug_shm_barrier(res[r][1]))) for r in range(1, world)]
+    for w in ws:
+        w.start()
+    time.sleep(0.3)
+    assert all(w.is_alive() for w in ws)                 # world - 1 ranks wait for the last one ...
+    assert L.mcg_debug_shm_poison(res[0][1]) == 0        # ... which fails locally instead
+    t0 = time.time()
+    for w in ws:
+        w.join(10)
+    assert time.time() - t0 < 5 and out == {r: 7 for r in range(1, world)}
+    for r in reversed(range(world)):
+        L.mcg_debug_shm_detach(res[r][1])
+    assert not os.path.exists("/dev/shm" + name)
