@@ -52,35 +52,76 @@ struct BranchArgs {
 
 // The dates are the OUTER loop: every thread carries the bounds of its BR_PPT paths in registers and all resident
 // threads work on one exercise date at about the same time, so the device's gathers of that moment fall into ONE row of
-// F (8 MB at a million paths: L2 / MALL) instead of being spread over the whole matrix (round 2: paths outermost, each
-// thread walking its own dates: 7.7 ms for the 5 10^8 gathers of a 1M x 50 matrix; 5.4 ms this way).  A launch covers
-// gridDim.x * 256 * BR_PPT paths starting at p0; larger shards take several launches.
+// F instead of being spread over the whole matrix (round 2: paths outermost, each thread walking its own dates: 7.7 ms
+// for the 5 10^8 gathers of a 1M x 50 matrix; 5.4 ms this way).  A launch covers gridDim.x * 256 * BR_PPT paths
+// starting at p0; larger shards take several launches.
+//
+// Round 4 -- the row in SLICES.  The counters (profiles/r04_branching_counters.json) put numbers on where a gather is
+// served: a row that fits an XCD's 4 MiB of L2 (250k paths: 2 MB) is gathered at 188 G/s with 94 % L2 hits; the 8 MB row
+// of a million paths at 92 G/s with 34 %, two thirds of the gathers going out to the fabric as one 64-byte request
+// each (61 G requests/s: the rate at which the memory side serves random sectors, whatever cache they hit); the 32 MB
+// row of 4M paths at 55 G/s with 4.5 %.  So the row is walked in slices of 2 MB: a thread draws the indices of all its
+// branches for the date ONCE, keeps them in registers (4 QUADS words per path) and then passes over the slices, gathering
+// in pass s only the indices that fall into slice s -- every lane of the device is in the same couple of slices at a
+// time, which the L2 of every XCD holds.  The loads stay unconditional (a lane whose index lies elsewhere reads the
+// slice's first element -- one line for all of them -- and adds zero), so all of a pass's loads are in flight together.
+// Rows beyond 16 MB take 8 slices of n/8 (more passes would cost more instructions than the misses they avoid).
 constexpr int BR_PPT = 4;
+constexpr int BR_SLICE_SHIFT = 18;  // 2^18 paths = 2 MB of a row of F
+constexpr int BR_MAX_SLICES = 8;
+constexpr int BR_DATE_MAX_SLICES = 4;  // per-date launches pay for rows of up to four slices (8 MB: a million paths), see run_branching
+constexpr int BR_WGS_PER_CU = 4;    // resident workgroups per CU the register budget is held to: a launch's grid is one resident wave
 
-__global__ __launch_bounds__(256) void k_branch_bounds(BranchArgs a, int64_t p0, double* partials) {
+struct BranchLane {  // one thread's BR_PPT paths
+    int64_t p[BR_PPT];
+    bool live[BR_PPT], have_lower[BR_PPT];
+    double lower[BR_PPT], upper[BR_PPT];
+    PhiloxLane rng[BR_PPT];  // block numbers are wave-uniform
+};
+
+__device__ __forceinline__ void branch_lane_setup(BranchLane& t, const BranchArgs& a, int64_t p0) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+#pragma unroll
+    for (int q = 0; q < BR_PPT; ++q) {
+        t.p[q] = p0 + (int64_t)blockIdx.x * 256 + threadIdx.x + q * stride;
+        t.live[q] = t.p[q] < a.n;
+        if (!t.live[q]) t.p[q] = a.n - 1;  // (reads stay in range; the result is dropped)
+        t.have_lower[q] = false;
+        t.lower[q] = t.upper[q] = 0.0;
+        t.rng[q] = philox_lane_setup(a.path_begin + (uint64_t)t.p[q], STREAM_BRANCH, a.k1);
+    }
+}
+
+__device__ __forceinline__ void branch_lane_finish(const BranchLane& t, double* red, double* partials) {
+    double v[2] = {0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < BR_PPT; ++q) {
+        if (t.live[q]) {
+            v[0] += t.lower[q];
+            v[1] += t.upper[q];
+        }
+    }
+    block_sum<2, 4>(v, red);
+    if (threadIdx.x == 0) {
+        partials[2 * (int64_t)blockIdx.x] = v[0];
+        partials[2 * (int64_t)blockIdx.x + 1] = v[1];
+    }
+}
+
+// QUADS = Philox blocks per path and date = ceil(num_branches / 4) <= 3 (the driver's 10 branches: 3); more branches than
+// twelve take k_branch_bounds_any, which gathers as it draws.
+template <int QUADS>
+__global__ __launch_bounds__(256, BR_WGS_PER_CU) void k_branch_bounds(BranchArgs a, int64_t p0, double* partials, int slice_shift, int n_slices) {
     __shared__ double red[2 * 4];
     const bool call = a.is_call != 0;
     const uint32_t n32 = (uint32_t)a.n;
-    const int quads = (a.num_branches + 3) >> 2;
     const double inv_b = a.num_branches > 0 ? 1.0 / (double)a.num_branches : 0.0;
-    const int64_t stride = (int64_t)gridDim.x * 256;
     if (a.n <= 0) {  // an empty shard still takes part in the collective that follows
         if (threadIdx.x == 0) partials[2 * (int64_t)blockIdx.x] = partials[2 * (int64_t)blockIdx.x + 1] = 0.0;
         return;
     }
-    int64_t p[BR_PPT];
-    bool live[BR_PPT], have_lower[BR_PPT];
-    double lower[BR_PPT], upper[BR_PPT];
-    PhiloxLane rng[BR_PPT];  // block numbers below are wave-uniform
-#pragma unroll
-    for (int q = 0; q < BR_PPT; ++q) {
-        p[q] = p0 + (int64_t)blockIdx.x * 256 + threadIdx.x + q * stride;
-        live[q] = p[q] < a.n;
-        if (!live[q]) p[q] = a.n - 1;  // (reads stay in range; the result is dropped)
-        have_lower[q] = false;
-        lower[q] = upper[q] = 0.0;
-        rng[q] = philox_lane_setup(a.path_begin + (uint64_t)p[q], STREAM_BRANCH, a.k1);
-    }
+    BranchLane t;
+    branch_lane_setup(t, a, p0);
     for (int e = 0; e < a.n_ex; ++e) {
         const int t_idx = a.ex[e];
         const double* rowS = a.S + (int64_t)t_idx * a.ld;
@@ -89,18 +130,166 @@ __global__ __launch_bounds__(256) void k_branch_bounds(BranchArgs a, int64_t p0,
         // `t > maturity` break, :97-99) leaves its `k` loop (:110) empty for t_idx = n_cols-1: continuation 0.
         const bool branch = t_idx < a.ex_last && t_idx + 1 < a.n_cols && a.num_branches > 0;
         const double* rowF = a.F + (int64_t)(branch ? t_idx + 1 : t_idx) * a.ld;
+        double now[BR_PPT];
 #pragma unroll
         for (int q = 0; q < BR_PPT; ++q) {
-            const double now = dsc * payoff_of(call, rowS[p[q]], a.K);
-            if (!have_lower[q] && now > 0.0) {  // :62-65, first positive discounted payoff
-                lower[q] = now;
-                have_lower[q] = true;
+            now[q] = dsc * payoff_of(call, rowS[t.p[q]], a.K);
+            if (!t.have_lower[q] && now[q] > 0.0) {  // :62-65, first positive discounted payoff
+                t.lower[q] = now[q];
+                t.have_lower[q] = true;
+            }
+        }
+        double sum[BR_PPT];
+#pragma unroll
+        for (int q = 0; q < BR_PPT; ++q) sum[q] = 0.0;
+        if (branch) {  // (wave-uniform)
+            uint32_t idx[BR_PPT][4 * QUADS];  // uniform on [0, n); a branch beyond num_branches gets an index in no slice
+#pragma unroll
+            for (int q = 0; q < BR_PPT; ++q) {
+#pragma unroll
+                for (int k = 0; k < QUADS; ++k) {
+                    const Philox4 w = philox4x32_10_lane(t.rng[q], (uint32_t)(e * QUADS + k), a.k0, a.k1);
+                    const uint32_t ws[4] = {w.w0, w.w1, w.w2, w.w3};
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) idx[q][4 * k + s] = 4 * k + s < a.num_branches ? __umulhi(ws[s], n32) : 0xFFFFFFFFu;
+                }
+            }
+            for (int sl = 0; sl < n_slices; ++sl) {
+                const uint32_t first = (uint32_t)sl << slice_shift;  // (< n: the slices cover [0, n))
+#pragma unroll
+                for (int q = 0; q < BR_PPT; ++q) {
+#pragma unroll
+                    for (int b = 0; b < 4 * QUADS; ++b) {
+                        const bool in = (idx[q][b] >> slice_shift) == (uint32_t)sl;
+                        const double v = rowF[in ? idx[q][b] : first];
+                        sum[q] += in ? v : 0.0;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < BR_PPT; ++q) {
+            double better = now[q];
+            const double cont = sum[q] * inv_b;
+            if (branch && cont > better) better = cont;
+            if (better > t.upper[q]) t.upper[q] = better;
+        }
+    }
+    branch_lane_finish(t, red, partials);
+}
+
+// ONE EXERCISE DATE per launch (rows of F beyond one slice): inside one launch of ~100 us the workgroups stay within a
+// slice or two of each other, which a whole sweep's worth of drift in k_branch_bounds does not -- its 1M-path row was still
+// gathered with 42 % L2 hits (profiles/r04_branching_counters.json).  The bounds of a path travel between the launches in
+// `state` = {lower, upper} per path (lower > 0 <=> the first positive payoff has been seen): 32 B per path and date.
+template <int QUADS>
+__global__ __launch_bounds__(256, BR_WGS_PER_CU) void k_branch_date(BranchArgs a, int64_t p0, int e, double2* state, int first_date,
+                                                                   int slice_shift, int n_slices) {
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    const bool call = a.is_call != 0;
+    const uint32_t n32 = (uint32_t)a.n;
+    const double inv_b = 1.0 / (double)a.num_branches;
+    const int t_idx = a.ex[e];
+    const double* rowS = a.S + (int64_t)t_idx * a.ld;
+    // :104-121.  No continuation at the list's last date nor at an index on the last column (k_branch_bounds): n_slices = 0
+    const bool branch = n_slices > 0;
+    const double* rowF = a.F + (int64_t)(branch ? t_idx + 1 : t_idx) * a.ld;
+    const double dsc = a.disc[t_idx];
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    int64_t p[BR_PPT];
+    bool live[BR_PPT];
+    double now[BR_PPT], sum[BR_PPT];
+    v2d st[BR_PPT];
+    uint32_t idx[BR_PPT][4 * QUADS];
+#pragma unroll
+    for (int q = 0; q < BR_PPT; ++q) {
+        p[q] = p0 + (int64_t)blockIdx.x * 256 + threadIdx.x + q * stride;
+        live[q] = p[q] < a.n;
+        if (!live[q]) p[q] = a.n - 1;
+        st[q] = first_date ? v2d{0.0, 0.0} : __builtin_nontemporal_load(reinterpret_cast<const v2d*>(state) + p[q]);
+        now[q] = dsc * payoff_of(call, __builtin_nontemporal_load(rowS + p[q]), a.K);
+        sum[q] = 0.0;
+        if (branch) {  // (wave-uniform)
+            const PhiloxLane rng = philox_lane_setup(a.path_begin + (uint64_t)p[q], STREAM_BRANCH, a.k1);
+#pragma unroll
+            for (int k = 0; k < QUADS; ++k) {
+                const Philox4 w = philox4x32_10_lane(rng, (uint32_t)(e * QUADS + k), a.k0, a.k1);
+                const uint32_t ws[4] = {w.w0, w.w1, w.w2, w.w3};
+#pragma unroll
+                for (int s = 0; s < 4; ++s) idx[q][4 * k + s] = 4 * k + s < a.num_branches ? __umulhi(ws[s], n32) : 0xFFFFFFFFu;
+            }
+        }
+    }
+    for (int sl = 0; sl < n_slices; ++sl) {
+        const uint32_t first = (uint32_t)sl << slice_shift;
+#pragma unroll
+        for (int q = 0; q < BR_PPT; ++q) {
+#pragma unroll
+            for (int b = 0; b < 4 * QUADS; ++b) {
+                const bool in = (idx[q][b] >> slice_shift) == (uint32_t)sl;
+                const double v = rowF[in ? idx[q][b] : first];
+                sum[q] += in ? v : 0.0;
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < BR_PPT; ++q) {
+        if (!(st[q].x > 0.0) && now[q] > 0.0) st[q].x = now[q];  // :62-65, first positive discounted payoff
+        double better = now[q];
+        const double cont = sum[q] * inv_b;
+        if (branch && cont > better) better = cont;
+        if (better > st[q].y) st[q].y = better;
+        if (live[q]) __builtin_nontemporal_store(st[q], reinterpret_cast<v2d*>(state) + p[q]);
+    }
+}
+
+// sum of {lower, upper} over the paths -> partials[grid][2]
+__global__ __launch_bounds__(256) void k_branch_finish(const double2* state, int64_t n, double* partials) {
+    __shared__ double red[2 * 4];
+    double v[2] = {0.0, 0.0};
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < n; p += (int64_t)gridDim.x * 256) {
+        const double2 st = state[p];
+        v[0] += st.x;
+        v[1] += st.y;
+    }
+    block_sum<2, 4>(v, red);
+    if (threadIdx.x == 0) {
+        partials[2 * (int64_t)blockIdx.x] = v[0];
+        partials[2 * (int64_t)blockIdx.x + 1] = v[1];
+    }
+}
+
+// any number of branches: the indices are used as they are drawn (no slices)
+__global__ __launch_bounds__(256) void k_branch_bounds_any(BranchArgs a, int64_t p0, double* partials) {
+    __shared__ double red[2 * 4];
+    const bool call = a.is_call != 0;
+    const uint32_t n32 = (uint32_t)a.n;
+    const int quads = (a.num_branches + 3) >> 2;
+    const double inv_b = a.num_branches > 0 ? 1.0 / (double)a.num_branches : 0.0;
+    if (a.n <= 0) {
+        if (threadIdx.x == 0) partials[2 * (int64_t)blockIdx.x] = partials[2 * (int64_t)blockIdx.x + 1] = 0.0;
+        return;
+    }
+    BranchLane t;
+    branch_lane_setup(t, a, p0);
+    for (int e = 0; e < a.n_ex; ++e) {
+        const int t_idx = a.ex[e];
+        const double* rowS = a.S + (int64_t)t_idx * a.ld;
+        const double dsc = a.disc[t_idx];
+        const bool branch = t_idx < a.ex_last && t_idx + 1 < a.n_cols && a.num_branches > 0;
+        const double* rowF = a.F + (int64_t)(branch ? t_idx + 1 : t_idx) * a.ld;
+#pragma unroll
+        for (int q = 0; q < BR_PPT; ++q) {
+            const double now = dsc * payoff_of(call, rowS[t.p[q]], a.K);
+            if (!t.have_lower[q] && now > 0.0) {
+                t.lower[q] = now;
+                t.have_lower[q] = true;
             }
             double better = now;
             if (branch) {
                 double sum = 0.0;
                 for (int k = 0; k < quads; ++k) {
-                    const Philox4 w = philox4x32_10_lane(rng[q], (uint32_t)(e * quads + k), a.k0, a.k1);
+                    const Philox4 w = philox4x32_10_lane(t.rng[q], (uint32_t)(e * quads + k), a.k0, a.k1);
                     const uint32_t ws[4] = {w.w0, w.w1, w.w2, w.w3};
 #pragma unroll
                     for (int s = 0; s < 4; ++s) {
@@ -110,22 +299,10 @@ __global__ __launch_bounds__(256) void k_branch_bounds(BranchArgs a, int64_t p0,
                 const double cont = sum * inv_b;
                 if (cont > better) better = cont;
             }
-            if (better > upper[q]) upper[q] = better;
+            if (better > t.upper[q]) t.upper[q] = better;
         }
     }
-    double v[2] = {0.0, 0.0};
-#pragma unroll
-    for (int q = 0; q < BR_PPT; ++q) {
-        if (live[q]) {
-            v[0] += lower[q];
-            v[1] += upper[q];
-        }
-    }
-    block_sum<2, 4>(v, red);
-    if (threadIdx.x == 0) {
-        partials[2 * (int64_t)blockIdx.x] = v[0];
-        partials[2 * (int64_t)blockIdx.x + 1] = v[1];
-    }
+    branch_lane_finish(t, red, partials);
 }
 
 int run_branching(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double maturity, double dt, int is_call,
@@ -153,9 +330,10 @@ int run_branching(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double m
     if (grid < 1) grid = 1;
     int rc = ensure_cap(ctx, &ctx->weights, &ctx->weights_cap, (size_t)n_cols + (ex.size() + 1) / 2 + 1);
     if (rc) return rc;
-    // k_branch_bounds: launches of at most 8 workgroups per CU, BR_PPT paths per thread
+    // k_branch_bounds: launches of one resident wave of workgroups (all of them walk the dates -- and the slices of a
+    // date's row -- together), BR_PPT paths per thread
     const int64_t per_wg = 256 * (int64_t)BR_PPT;
-    const int bgrid = (int)std::max<int64_t>(1, std::min<int64_t>((P->n_paths + per_wg - 1) / per_wg, (int64_t)ctx->n_cus * 8));
+    const int bgrid = (int)std::max<int64_t>(1, std::min<int64_t>((P->n_paths + per_wg - 1) / per_wg, (int64_t)ctx->n_cus * BR_WGS_PER_CU));
     const int64_t per_launch = (int64_t)bgrid * per_wg;
     const int64_t n_launches = std::max<int64_t>(1, (P->n_paths + per_launch - 1) / per_launch);
     rc = ensure_cap(ctx, &ctx->partials, &ctx->partials_cap, (size_t)2 * (size_t)std::max<int64_t>(grid, bgrid * n_launches));
@@ -193,13 +371,63 @@ int run_branching(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double m
     a.num_branches = num_branches;
     a.K = K;
     a.is_call = is_call;
-    for (int64_t l = 0; l < n_launches; ++l) {
-        TimedLaunch t(ctx, MCG_K_BRANCHING);
-        hipLaunchKernelGGL(k_branch_bounds, dim3(bgrid), dim3(256), 0, ctx->stream, a, l * per_launch, ctx->partials + 2 * l * bgrid);
+    // slices of the gathered row: 2 MB each, at most BR_MAX_SLICES (then of n / BR_MAX_SLICES, rounded up to a power of two)
+    int slice_shift = BR_SLICE_SHIFT;
+    while ((((P->n_paths > 0 ? P->n_paths : 1) - 1) >> slice_shift) + 1 > BR_MAX_SLICES) ++slice_shift;
+    const int n_slices = (int)((((P->n_paths > 0 ? P->n_paths : 1) - 1) >> slice_shift) + 1);
+    const int quads = (num_branches + 3) / 4;
+    int64_t n_partials = (int64_t)bgrid * n_launches;
+    void* state = nullptr;
+    size_t state_bytes = 0;
+    if (n_slices > 1 && n_slices <= BR_DATE_MAX_SLICES && quads >= 1 && quads <= 3 && !ex.empty()) {
+        // Rows of two to four slices: one launch per exercise date, bounds in `state`.  A/B on one board, 1M x 50: 5.55 ms
+        // (one launch, no slices) -> 5.25 (one launch, slices: 42 % L2 hits) -> 2.83 (per-date launches).  A pass costs
+        // ~40 cycles per wave-load however few lanes take part, so rows of many slices lose what the hits gain (4M x 50,
+        // 16 slices: 44.7 ms per date-launches against 29.6 in one launch with 8 slices and 35.3 without): those keep the
+        // one-launch kernel.
+        state_bytes = (size_t)P->n_paths * sizeof(double2);
+        rc = pool_alloc(ctx, state_bytes, &state);
+        if (rc) {
+            pool_release(ctx, Fbuf, P->bytes);
+            return rc;
+        }
+        {
+            TimedLaunch t(ctx, MCG_K_BRANCHING, (int64_t)ex.size() * n_launches + 1);
+            for (int e = 0; e < (int)ex.size(); ++e) {
+                const int t_idx = ex[(size_t)e];
+                const bool branch = t_idx < ex_last && t_idx + 1 < n_cols;
+                for (int64_t l = 0; l < n_launches; ++l) {
+                    const dim3 g(bgrid), b(256);
+                    const int ns = branch ? n_slices : 0;
+                    if (quads == 1) hipLaunchKernelGGL(k_branch_date<1>, g, b, 0, ctx->stream, a, l * per_launch, e, (double2*)state, e == 0, slice_shift, ns);
+                    else if (quads == 2) hipLaunchKernelGGL(k_branch_date<2>, g, b, 0, ctx->stream, a, l * per_launch, e, (double2*)state, e == 0, slice_shift, ns);
+                    else hipLaunchKernelGGL(k_branch_date<3>, g, b, 0, ctx->stream, a, l * per_launch, e, (double2*)state, e == 0, slice_shift, ns);
+                }
+            }
+            hipLaunchKernelGGL(k_branch_finish, dim3(grid), dim3(256), 0, ctx->stream, (const double2*)state, P->n_paths, ctx->partials);
+        }
+        n_partials = grid;
+    } else {
+        for (int64_t l = 0; l < n_launches; ++l) {
+            TimedLaunch t(ctx, MCG_K_BRANCHING);
+            double* part = ctx->partials + 2 * l * bgrid;
+            const dim3 g(bgrid), b(256);
+            if (quads <= 1) hipLaunchKernelGGL(k_branch_bounds<1>, g, b, 0, ctx->stream, a, l * per_launch, part, slice_shift, n_slices);
+            else if (quads == 2) hipLaunchKernelGGL(k_branch_bounds<2>, g, b, 0, ctx->stream, a, l * per_launch, part, slice_shift, n_slices);
+            else if (quads == 3) hipLaunchKernelGGL(k_branch_bounds<3>, g, b, 0, ctx->stream, a, l * per_launch, part, slice_shift, n_slices);
+            else hipLaunchKernelGGL(k_branch_bounds_any, g, b, 0, ctx->stream, a, l * per_launch, part);
+        }
+    }
+    if (hipGetLastError() != hipSuccess) {
+        (void)hipStreamSynchronize(ctx->stream);
+        pool_release(ctx, Fbuf, P->bytes);
+        if (state) pool_release(ctx, state, state_bytes);
+        return fail(MCG_ERR_HIP, "BranchingProcesses: kernel launch failed");
     }
     double s[3];
-    rc = finish_sums(ctx, (int64_t)bgrid * n_launches, P->n_paths, s);  // {sum lower, sum upper, N}
+    rc = finish_sums(ctx, n_partials, P->n_paths, s);  // {sum lower, sum upper, N}; synchronises the stream
     pool_release(ctx, Fbuf, P->bytes);
+    if (state) pool_release(ctx, state, state_bytes);
     if (rc) return rc;
     if (!(s[2] >= 1.0)) return fail(MCG_ERR_EMPTY_PATHS, "BranchingProcesses: Empty pricePaths.");
     const double lo = s[0] / s[2], up = s[1] / s[2];
