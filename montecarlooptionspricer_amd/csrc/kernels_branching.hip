@@ -56,7 +56,7 @@ struct BranchArgs {
 // for the 5 10^8 gathers of a 1M x 50 matrix; 5.4 ms this way).  A launch covers gridDim.x * 256 * BR_PPT paths
 // starting at p0; larger shards take several launches.
 //
-// Round 4 -- the row in SLICES.  The counters (profiles/r04_branching_counters.json) put numbers on where a gather is
+// Round 4 -- the row in SLICES.  The counters (profiles/r04_branching_counters_before.json) put numbers on where a gather is
 // served: a row that fits an XCD's 4 MiB of L2 (250k paths: 2 MB) is gathered at 188 G/s with 94 % L2 hits; the 8 MB row
 // of a million paths at 92 G/s with 34 %, two thirds of the gathers going out to the fabric as one 64-byte request
 // each (61 G requests/s: the rate at which the memory side serves random sectors, whatever cache they hit); the 32 MB
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256, BR_WGS_PER_CU) void k_branch_bounds(BranchArgs
 
 // ONE EXERCISE DATE per launch (rows of F beyond one slice): inside one launch of ~100 us the workgroups stay within a
 // slice or two of each other, which a whole sweep's worth of drift in k_branch_bounds does not -- its 1M-path row was still
-// gathered with 42 % L2 hits (profiles/r04_branching_counters.json).  The bounds of a path travel between the launches in
+// gathered with 42 % L2 hits (profiles/r04_branching_counters_before.json).  The bounds of a path travel between the launches in
 // `state` = {lower, upper} per path (lower > 0 <=> the first positive payoff has been seen): 32 B per path and date.
 template <int QUADS>
 __global__ __launch_bounds__(256, BR_WGS_PER_CU) void k_branch_date(BranchArgs a, int64_t p0, int e, double2* state, int first_date,

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/r04_branching_counters.json from the separate `rocprofv3 --pmc` passes of tools/bench_branching.py
+"""profiles/r04_branching_counters_before.json from the separate `rocprofv3 --pmc` passes of tools/bench_branching.py
 (tools/gpu_r4a.sh): per shape, the cache counters of k_branch_bounds per launch, the request traffic they imply and what
 that is of the guide's random-row rates (MI355X_MICROARCH.md, 'Indexed rows')."""
 import csv, glob, json, os, sys
@@ -48,5 +48,5 @@ for grid, cs in sorted(acc.items()):
             row["L1_to_L2_read_requests_per_gather"] = c["TCP_TCC_READ_REQ_sum"] / gathers
             row["L2_request_TBps_at_64B_per_request"] = c["TCP_TCC_READ_REQ_sum"] * 64 / (ms * 1e-3) / 1e12
     out["shapes"][f"{paths}x{dates}" if paths else str(grid)] = row
-json.dump(out, open("profiles/r04_branching_counters.json", "w"), indent=1)
+json.dump(out, open("profiles/r04_branching_counters_before.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
