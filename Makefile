@@ -54,5 +54,10 @@ build/dropin_driver: tests/cpp/dropin_driver.cpp $(LIB) $(HDRS)
 	g++ -O2 -std=c++17 -fopenmp -Iinclude tests/cpp/dropin_driver.cpp -o $@ \
 	    -L$(PKG)/lib -lmcgpu -Wl,-rpath,'$$ORIGIN/../$(PKG)/lib'
 
-cpp: build/dropin_driver
+build/batch_driver: tests/cpp/batch_driver.cpp $(LIB) $(HDRS)
+	@mkdir -p build
+	g++ -O2 -std=c++17 -fopenmp -Iinclude tests/cpp/batch_driver.cpp -o $@ \
+	    -L$(PKG)/lib -lmcgpu -Wl,-rpath,'$$ORIGIN/../$(PKG)/lib' -Wl,-rpath-link,/opt/rocm/lib
+
+cpp: build/dropin_driver build/batch_driver
 .PHONY: cpp

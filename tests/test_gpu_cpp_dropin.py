@@ -27,3 +27,19 @@ def test_cpp_dropin_driver_openmp():
         tok = l.split()
         by_steps.setdefault(tok[3], set()).add((tok[5], tok[7]))
     assert all(len(v) == 1 for v in by_steps.values()), by_steps
+
+
+def test_cpp_batched_driver_rows_six_columns():
+    """tests/cpp/batch_driver.cpp: the reference driver's row loop rewritten on mcg_row_build + mcg_batch_price_rows6
+    (INTEGRATION.md section 1), from C++ against include/mcgpu.h -- rows built under OpenMP, one call for all lines, the
+    driver's six columns per line, six zeros for the lines it skips."""
+    subprocess.run(["make", "cpp"], cwd=ROOT, check=True, stdout=subprocess.DEVNULL)
+    env = dict(os.environ, OMP_NUM_THREADS="6")
+    res = subprocess.run([os.path.join(ROOT, "build", "batch_driver"), "300"], capture_output=True, text=True, env=env, timeout=300)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
+    lines = res.stdout.strip().splitlines()
+    assert lines[-1].startswith("OK rows=300 priced=")
+    rows = [l.split() for l in lines if l.startswith("row ")]
+    assert len(rows) == 300 and all(len(t) == 8 for t in rows)
+    zero = [t for t in rows if all(float(x) == 0.0 for x in t[2:])]
+    assert 30 <= len(zero) <= 80                      # every 11th line (short history) and every 13th (no time step)
