@@ -383,10 +383,18 @@ def install_collective(eng, mc, want: str, dist, torch, rank: int, world: int, d
             dist.broadcast_object_list(box, src=0)
             return box[0]
         ok = True
-        try:
-            eng.init_rccl(rank, world, bcast)
-        except mc.McgError as e:           # communicator set-up failed on this node: use torch's, and say so
-            print(f"bench: built-in RCCL communicator unavailable ({e}); using torch.distributed", file=sys.stderr)
+        try:                               # can EVERY rank load librccl?  (agreed before anybody enters ncclCommInitRank, where a
+            eng.rccl_probe()               #  rank whose peer never arrives would wait)
+        except mc.McgError as e:
+            print(f"bench: librccl unavailable on rank {rank} ({e})", file=sys.stderr)
+            ok = False
+        if everyone(ok, dist, torch, dev):
+            try:
+                eng.init_rccl(rank, world, bcast)
+            except mc.McgError as e:       # communicator set-up failed on this node: use torch's, and say so
+                print(f"bench: built-in RCCL communicator unavailable ({e}); using torch.distributed", file=sys.stderr)
+                ok = False
+        else:
             ok = False
         if not everyone(ok, dist, torch, dev):               # all ranks take the same route
             got = "torch (built-in RCCL init failed" + ("" if not ok else " on a peer") + ")"

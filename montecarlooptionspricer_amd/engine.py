@@ -170,6 +170,13 @@ class PathEngine:
             raise McgError("rank 0 could not create the RCCL id" + (f": {err}" if err else ""), 7)
         check(self._L.mcg_comm_init_rank(self._ctx, uid, int(world), int(rank)))
 
+    def rccl_probe(self) -> None:
+        """Raises McgError unless librccl loads and hands out an id on THIS rank.  A launcher calls it on every rank and
+        lets the ranks agree BEFORE init_rccl: a rank that cannot load the library would otherwise leave its peers waiting
+        inside ncclCommInitRank."""
+        buf = C.create_string_buffer(128)
+        check(self._L.mcg_comm_unique_id(buf))
+
     def init_shm(self, name: str, rank: int, world: int, peer_mailbox: bool = False) -> bool:
         """Node-local shared-memory collective (mcg_comm_init_shm): `name` starts with '/', is the same on every rank
         and unique to the job.  Host all-reduce for the sums; the one-launch LSM sweeps exchange their per-date moments

@@ -11,6 +11,7 @@ every rank's shard went through that collective exactly once), and the line benc
 Failure injection (MCG_REHEARSAL_FAIL = comma-separated):
   shm_init:<rank>     that rank's init_shm raises            -> all ranks fall to rccl together
   rccl_id             rank 0 cannot create the RCCL id       -> all ranks raise together, fall to torch
+  rccl_probe:<rank>   that rank cannot load librccl          -> nobody enters ncclCommInitRank, all fall to torch
   pass:<rank>:<want>  that rank raises in the passes of the C5 row <want> -> the row fails on ALL ranks, the next row runs
 """
 import ctypes as C
@@ -81,6 +82,10 @@ class RehearsalEngine:
             return t.tolist()
         self._kind, self._sum = "callback", s
         self._world = dist.get_world_size()
+
+    def rccl_probe(self):
+        if _fail(f"rccl_probe:{self._rank}"):
+            raise mc.McgError("injected: cannot dlopen librccl on this rank", 7)
 
     def init_rccl(self, rank, world, broadcast_bytes):
         uid = None

@@ -63,6 +63,7 @@ def test_eight_ranks_run_the_drivers_command_end_to_end():
 
 @pytest.mark.parametrize("fail,expect", [
     ("rccl_id", "rank 0 cannot create the RCCL id: it still enters the broadcast, every rank raises, all fall to torch"),
+    ("rccl_probe:1", "one rank cannot load librccl: the ranks agree before anybody enters ncclCommInitRank, all fall to torch"),
     ("shm_init:5", "one rank cannot join the segment: all ranks leave it and take RCCL's route (here: torch) together"),
     ("pass:3:shm", "one rank fails inside the passes of the shm row: the row fails on ALL ranks at once, the next rows run"),
 ])
@@ -77,7 +78,7 @@ def test_injected_failures_keep_the_ranks_in_step(fail, expect):
     rows = out["extra"]["configs"]
     total = world * 100_001
     assert [r["collective_requested"] for r in rows] == ["shm", "rccl"]
-    if fail == "rccl_id":
+    if fail in ("rccl_id", "rccl_probe:1"):
         assert all("error" not in r for r in rows) and rows[1]["collective"].startswith("torch (built-in RCCL init failed")
         assert [rows[1]["price"], rows[1]["std_err"]] == _ids(total)
     elif fail == "shm_init:5":          # (world 4: rank 5 does not exist -> nothing fails; rank 2 below does)
