@@ -61,3 +61,15 @@ build/batch_driver: tests/cpp/batch_driver.cpp $(LIB) $(HDRS)
 
 cpp: build/dropin_driver build/batch_driver
 .PHONY: cpp
+
+# Static check of the device assembly for the gfx940+ hazards hipcc does not cover inside inline-asm statements
+# (tools/check_asm_hazards.py: VALU-written SGPRs read too soon by an asm statement; an asm store's data registers
+# overwritten too soon).  Run by tests/test_asm_hazards.py.
+ASM_SRCS := $(HIP_SRCS)
+ASM_OUT  := $(patsubst %,build/asm/%.s,$(notdir $(ASM_SRCS)))
+build/asm/%.hip.s: $(PKG)/csrc/%.hip $(HDRS)
+	@mkdir -p build/asm
+	$(HIPCC) $(HIPFLAGS) -S --cuda-device-only -o $@ $< 2>/dev/null
+asmcheck: $(ASM_OUT)
+	python3 tools/check_asm_hazards.py $(ASM_OUT)
+.PHONY: asmcheck

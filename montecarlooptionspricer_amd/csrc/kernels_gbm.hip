@@ -100,8 +100,15 @@ __global__ __launch_bounds__(256) void k_gbm_paths(GbmArgs a) {
             if constexpr (PPL == 1) {
                 asm volatile("global_store_dwordx2 %0, %1, %2 nt" : : "v"(lane_bytes), "v"(S[0]), "s"(r) : "memory");
             } else {
+                // The `s_nop 1` belongs to the store: on gfx940+ a store of more than 64 bits reads its data registers
+                // AFTER issue, and a VALU instruction that overwrites them within the next two wait states corrupts what is
+                // stored (ISA: required software-inserted wait states).  hipcc covers its own stores; an asm statement is
+                // opaque to it, and S[] is overwritten by the next step's FMA right behind this store.  Round 4: a build
+                // whose scheduling put that FMA first stored foreign low / high words in rows 0, 1 and 5 of the matrix
+                // (1.2e-10 and percent-size errors in a quarter of the lanes, tools/diag_stamps.py) while the chain in
+                // the registers stayed right; tools/check_asm_hazards.py finds the pattern in the assembly.
                 const v2d v = {S[0], S[PPL - 1]};
-                asm volatile("global_store_dwordx4 %0, %1, %2 nt" : : "v"(lane_bytes), "v"(v), "s"(r) : "memory");
+                asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" : : "v"(lane_bytes), "v"(v), "s"(r) : "memory");
             }
         };
         store_row(row);

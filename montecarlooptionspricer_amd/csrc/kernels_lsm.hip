@@ -737,10 +737,16 @@ __device__ __forceinline__ void lsm_accumulate(double (&m)[3 * NB - 1], const Ls
 }
 
 // per lane: mask bit set ? a : b
+// The mask comes straight from a v_cmp (ballot), i.e. from a VALU instruction that writes an SGPR pair; on gfx940+ a VALU
+// instruction must not read such a pair within 2 wait states, and hipcc does not guard the operands of an asm statement
+// (tools/check_asm_hazards.py).  tools/ubench_hazard.hip could not make this pattern fail on the hardware (2 10^8 selects
+// back to back: none wrong), but the ISA asks for the wait states, so the statement carries them: both halves in ONE
+// statement behind one `s_nop 1` (A/B on the C5 sweep: nothing measurable).
 __device__ __forceinline__ double lsm_select(unsigned long long mask, double a, double b) {
     int lo, hi;
-    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(lo) : "v"(__double2loint(b)), "v"(__double2loint(a)), "s"(mask));
-    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(hi) : "v"(__double2hiint(b)), "v"(__double2hiint(a)), "s"(mask));
+    asm("s_nop 1\n\tv_cndmask_b32_e64 %0, %2, %3, %6\n\tv_cndmask_b32_e64 %1, %4, %5, %6"
+        : "=&v"(lo), "=&v"(hi)
+        : "v"(__double2loint(b)), "v"(__double2loint(a)), "v"(__double2hiint(b)), "v"(__double2hiint(a)), "s"(mask));
     return __hiloint2double(hi, lo);
 }
 

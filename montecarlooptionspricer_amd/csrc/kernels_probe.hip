@@ -14,7 +14,7 @@ __global__ __launch_bounds__(256) void k_probe_write(double* out, int64_t ld, in
     const unsigned lane_bytes = threadIdx.x * 16u;
     v2d v = {seed + (double)blockIdx.x, seed + (double)threadIdx.x};
     for (int n = 0; n <= n_steps; ++n) {
-        asm volatile("global_store_dwordx4 %0, %1, %2 nt" : : "v"(lane_bytes), "v"(v), "s"(row) : "memory");
+        asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" : : "v"(lane_bytes), "v"(v), "s"(row) : "memory");  // (the generator's statement, its hazard cover included)
         row += ld;
     }
 }

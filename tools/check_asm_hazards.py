@@ -10,6 +10,14 @@ pointers (global_store ... s[base]) from SGPRs inside asm statements.  Seen in r
 generator spilled a Horner constant, the restore landed right before the asm FMA, the FMA read the register's PREVIOUS
 content and the paths came out 1e-10 off (tests/test_gpu_parity.py caught it at its 1e-11).
 
+A second hazard of the same family, and the one that actually bit (round 4, found by comparing the two builds' matrices
+element by element, tools/diag_stamps.py): on gfx940+ a VMEM STORE of more than 64 bits must be followed by 2 wait states
+before a VALU instruction overwrites the store's DATA registers -- the memory pipeline reads them after issue.  For its own
+stores hipcc inserts the wait states; `global_store_dwordx4` inside an asm statement is opaque to it.  In the failing
+build the generator's next instruction overwrote half of the data pair: rows 0, 1 and 5 of the matrix held values with a
+foreign low or high word in a quarter of the lanes (relative error 2^-33 = 1.2e-10, or percent) while the price chain in
+the registers stayed right.  The store's asm statement now carries its own `s_nop 1`.
+
 Usage: check_asm_hazards.py file.s [...]   -> lists every asm statement that reads an SGPR too soon after a VALU write;
 exit code 1 if any."""
 import re
@@ -50,6 +58,53 @@ def wait_states(line):
     return int(m.group(1)) + 1 if m else 1
 
 
+VREG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
+WIDE_STORE = re.compile(r"^\s*(?:global|flat|buffer|scratch)_store_dwordx[34]\b")
+
+
+def vregs(tok):
+    out = set()
+    for m in VREG.finditer(tok):
+        if m.group(1) is not None:
+            out.add(int(m.group(1)))
+        else:
+            out.update(range(int(m.group(2)), int(m.group(3)) + 1))
+    return out
+
+
+def check_wide_stores(path):
+    """asm-embedded stores of > 64 bits whose data VGPRs a VALU instruction writes within the next 2 wait states"""
+    bad = []
+    lines = open(path, errors="ignore").read().splitlines()
+    kernel, in_asm = "?", False
+    pending = []   # [data vgprs, wait states since the store, line, text]
+    for n, line in enumerate(lines, 1):
+        t = line.strip()
+        head = t.split(";")[0].strip()
+        if head.endswith(":") and head.startswith("_Z"):
+            kernel = head[:-1]
+        if "#ASMSTART" in t:
+            in_asm = True
+            continue
+        if "#ASMEND" in t:
+            in_asm = False
+            continue
+        if not is_insn(line):
+            continue
+        body = t.split(";")[0]
+        if body.startswith("v_") and not body.startswith(("v_cmp", "v_readlane", "v_readfirstlane")):
+            dst = vregs(body.split(None, 1)[1].split(",")[0]) if " " in body else set()
+            for data, age, ln, txt in pending:
+                if age < 2 and dst & data:
+                    bad.append((path, ln, kernel, txt, sorted(dst & data), age, n, body))
+        ws = wait_states(line)
+        pending = [(d, age + ws, ln, txt) for d, age, ln, txt in pending if age + ws < 2]
+        if in_asm and WIDE_STORE.match(body):
+            ops = body.split(None, 1)[1].split(",")
+            pending.append((vregs(ops[1]), 0, n, body))   # global_store vaddr, vdata, saddr
+    return bad
+
+
 def check(path):
     bad = []
     lines = open(path, errors="ignore").read().splitlines()
@@ -58,8 +113,9 @@ def check(path):
     in_asm = False
     for n, line in enumerate(lines, 1):
         t = line.strip()
-        if t.endswith(":") and t.startswith("_Z"):
-            kernel = t[:-1]
+        head = t.split(";")[0].strip()
+        if head.endswith(":") and head.startswith("_Z"):
+            kernel = head[:-1]
         if "#ASMSTART" in t:
             in_asm = True
             continue
@@ -88,10 +144,13 @@ def check(path):
 
 
 if __name__ == "__main__":
-    allbad = []
+    allbad, stores = [], []
     for f in sys.argv[1:]:
         allbad += check(f)
+        stores += check_wide_stores(f)
     for path, n, kernel, t, r, age, need in allbad:
         print(f"{path}:{n}: {kernel}: asm `{t}` reads s{r} {age} wait state(s) after a VALU write (needs {need})")
-    print(f"{len(allbad)} hazard(s) in {len(sys.argv) - 1} file(s)")
-    sys.exit(1 if allbad else 0)
+    for path, ln, kernel, txt, regs_, age, n, body in stores:
+        print(f"{path}:{ln}: {kernel}: asm `{txt}`: its data v{regs_} is overwritten {age} wait state(s) later by `{body}` (line {n}; needs 2)")
+    print(f"{len(allbad) + len(stores)} hazard(s) in {len(sys.argv) - 1} file(s)")
+    sys.exit(1 if allbad or stores else 0)
