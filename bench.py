@@ -420,7 +420,8 @@ def c5_sharded_rows(args, mc, N, dist, torch, device, stream, rank, world, hw=Gp
     make_engine = make_engine or (lambda: mc.PathEngine(device, stream=stream))
     for want in [c for c in args.c5_collectives.split(",") if c]:
         e5, err, row = None, None, None
-        os.environ["MCG_REHEARSAL_ROW"] = want   # (read by the rehearsal's failure injection only)
+        if args.rehearsal:
+            os.environ["MCG_REHEARSAL_ROW"] = want   # (read by the rehearsal's failure injection only)
 
         def phase(fn):
             """Run a local step; every rank then learns whether it worked everywhere."""
