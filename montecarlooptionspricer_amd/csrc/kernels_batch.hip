@@ -176,14 +176,23 @@ __global__ __launch_bounds__(256) void k_batch_asym(BatchArgs a) {
     if (p < a.n_paths) {
         const double* col = a.S + row.off + p;
         double best = 0.0;
-        for (int j = 0; j < n_cols; ++j) {
-            if (j * a.dt > row.maturity) break;
-            const double S = col[(int64_t)j * BATCH_LD];
-            if (isnan(S) || isinf(S)) continue;
-            const bool in = call ? (S > bnd[j]) : (S < bnd[j]);
-            if (in) {
-                const double d = dsc[j] * payoff_of(call, S, row.strike);
-                if (d > best) best = d;
+        int n_scan = 0;  // the reference scans until the first date beyond the maturity (:62-64)
+        while (n_scan < n_cols && !(n_scan * a.dt > row.maturity)) ++n_scan;
+        // a thread's scan is a chain of dependent-looking loads (one row of the block per date): four at a time are in flight
+        for (int j0 = 0; j0 < n_scan; j0 += 4) {
+            double S4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) S4[u] = col[(int64_t)min(j0 + u, n_scan - 1) * BATCH_LD];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + u;
+                const double S = S4[u];
+                if (j >= n_scan || isnan(S) || isinf(S)) continue;
+                const bool in = call ? (S > bnd[j]) : (S < bnd[j]);
+                if (in) {
+                    const double d = dsc[j] * payoff_of(call, S, row.strike);
+                    if (d > best) best = d;
+                }
             }
         }
         if (!isnan(best) && !isinf(best)) {
