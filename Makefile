@@ -59,7 +59,12 @@ build/batch_driver: tests/cpp/batch_driver.cpp $(LIB) $(HDRS)
 	g++ -O2 -std=c++17 -fopenmp -Iinclude tests/cpp/batch_driver.cpp -o $@ \
 	    -L$(PKG)/lib -lmcgpu -Wl,-rpath,'$$ORIGIN/../$(PKG)/lib' -Wl,-rpath-link,/opt/rocm/lib
 
-cpp: build/dropin_driver build/batch_driver
+build/thread_ranks_driver: tests/cpp/thread_ranks_driver.cpp $(LIB) $(HDRS)
+	@mkdir -p build
+	g++ -O2 -std=c++17 -fopenmp -Iinclude tests/cpp/thread_ranks_driver.cpp -o $@ \
+	    -L$(PKG)/lib -lmcgpu -Wl,-rpath,'$$ORIGIN/../$(PKG)/lib' -Wl,-rpath-link,/opt/rocm/lib
+
+cpp: build/dropin_driver build/batch_driver build/thread_ranks_driver
 .PHONY: cpp
 
 # Static check of the device assembly for the gfx940+ hazards hipcc does not cover inside inline-asm statements

@@ -43,3 +43,15 @@ def test_cpp_batched_driver_rows_six_columns():
     assert len(rows) == 300 and all(len(t) == 8 for t in rows)
     zero = [t for t in rows if all(float(x) == 0.0 for x in t[2:])]
     assert 30 <= len(zero) <= 80                      # every 11th line (short history) and every 13th (no time step)
+
+
+@pytest.mark.parametrize("mailbox", ["shm", "ipc"])
+def test_cpp_one_thread_per_rank_sharded_job(mailbox):
+    """tests/cpp/thread_ranks_driver.cpp: one process, one OpenMP thread per rank (the reference driver's shape on a
+    multi-GPU node), eight ranks on GPU 0, from C++ against include/mcgpu.h: every rank holds the single-context European,
+    GBM-LSM and rBergomi-LSM prices; every sweep one launch, no time-out, no barrier failure."""
+    subprocess.run(["make", "cpp"], cwd=ROOT, check=True, stdout=subprocess.DEVNULL)
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="16", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="8")
+    res = subprocess.run([os.path.join(ROOT, "build", "thread_ranks_driver"), "8", mailbox], capture_output=True, text=True, env=env, timeout=300)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
+    assert res.stdout.strip().splitlines()[-1] == "OK ranks=8 mailbox=" + ("peer memory" if mailbox == "ipc" else "host")
