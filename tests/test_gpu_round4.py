@@ -320,3 +320,22 @@ def test_branching_rows_beyond_one_slice_match_oracle(n_paths, steps, branches, 
         assert np.allclose(got, want, rtol=1e-12, atol=1e-14), (n_paths, is_call, got, want)
     P.free()
     e.close()
+
+
+def test_batch_rows6_arguments(eng):
+    rows = _rows(3, np.random.RandomState(2))
+    four = eng.batch_price_rows(rows, seed=5)
+    import ctypes as C
+    arr = mc.make_rows(rows)
+    out = np.full((3, 6), -1.0)
+    dp = C.POINTER(C.c_double)
+    # features2 = NULL: the four prices, zeros in the feature columns
+    assert eng._L.mcg_batch_price_rows6(eng._ctx, arr, None, 3, 250, 0.04, DT, 10, 2, 5, 5, out.ctypes.data_as(dp)) == 0
+    assert np.array_equal(out[:, :4], four) and (out[:, 4:] == 0.0).all()
+    assert eng._L.mcg_batch_price_rows6(eng._ctx, arr, None, 0, 250, 0.04, DT, 10, 2, 5, 5, out.ctypes.data_as(dp)) == 0   # no rows: nothing to do
+    for bad in ((eng._ctx, arr, None, 3, 0, 0.04, DT, 10, 2, 5, 5), (eng._ctx, arr, None, 3, 250, 0.04, DT, 10, 16, 5, 5),
+                (eng._ctx, arr, None, 3, 250, 0.04, DT, 10, 2, 0, 5), (eng._ctx, arr, None, 3, 250, 0.04, 0.0, 10, 2, 5, 5),
+                (eng._ctx, None, None, 3, 250, 0.04, DT, 10, 2, 5, 5), (None, arr, None, 3, 250, 0.04, DT, 10, 2, 5, 5)):
+        assert eng._L.mcg_batch_price_rows6(*bad, out.ctypes.data_as(dp)) == 1, bad
+    with pytest.raises(mc.McgError, match="features must be"):
+        eng.batch_price_rows(rows, features=np.zeros((2, 2)))
