@@ -1,7 +1,8 @@
 // Batched driver rows: the per-row work of the reference's production caller
 // (/root/reference/src/core/PredictionGen.cpp:700-791 -- 250 rBergomi paths, then AsymptoticAnalysis,
 // BranchingProcesses(10 branches, exercise dates 0..steps-1), LSM(polyOrder 2), MartingaleOptimization(2))
-// for MANY option rows in six launches instead of ~15 launches and ~8 host synchronisations per row:
+// for MANY option rows in six launches (per chunk of rows, run_batch_rows) instead of ~15 launches and ~8 host
+// synchronisations per row:
 //   k_batch_weights    one workgroup per row: lambda -> |phi_k|^2 -> spectral amplitudes a_k and compensator
 //                      (the host/volterra.cpp math, done with a direct DFT against an LDS table of roots of unity)
 //   k_batch_paths      a few workgroups per row: the FFT generator of rbergomi_device.hpp
