@@ -807,13 +807,15 @@ def main() -> None:
                 "shape": "one launch (V in registers; beyond 2.09M paths the matrix streams through an LDS-DMA ring)" if one_launch
                          else "per-date route: one kernel + one all-reduce of 8 moments per exercise date; sweep_ms is the span of the "
                               "queued sequence (launches, dispatch gaps, collectives)"}
-            pmc5 = os.path.join(ROOT, "profiles", "r03_c5_pmc_traffic.json")
-            if os.path.exists(pmc5) and count == 8_000_000 and n_steps == 252:
+            import glob
+            cand = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_c5_pmc_traffic.json")))   # the latest round's
+            pmc5 = cand[-1] if cand else ""
+            if pmc5 and count == 8_000_000 and n_steps == 252:
                 try:
                     j5 = json.load(open(pmc5))
                     out["roofline"]["traffic"] = j5["generator"]["hbm_bytes_per_launch"]
-                    out["roofline"]["traffic_source"] = ("profiles/r03_c5_pmc_traffic.json (committed: rocprofv3 --pmc WRITE_SIZE / "
-                                                         "FETCH_SIZE passes of this command, tools/profile_r03.sh; not re-measured here)")
+                    out["roofline"]["traffic_source"] = (f"profiles/{os.path.basename(pmc5)} (committed: rocprofv3 --pmc WRITE_SIZE / "
+                                                         "FETCH_SIZE passes of this command, tools/profile_r0N.sh; not re-measured here)")
                     if one_launch:
                         out["roofline"]["lsm"]["traffic"] = j5["lsm_one_launch"]["hbm_bytes_per_launch"]
                     elif "lsm_per_date_launch" in j5:
