@@ -745,7 +745,7 @@ __device__ __forceinline__ void lsm_accumulate(double (&m)[3 * NB - 1], const Ls
 __device__ __forceinline__ double lsm_select(unsigned long long mask, double a, double b) {
     int lo, hi;
     asm("s_nop 1\n\tv_cndmask_b32_e64 %0, %2, %3, %6\n\tv_cndmask_b32_e64 %1, %4, %5, %6"
-        : "=&v"(lo), "=&v"(hi)
+        : "=&v"(lo), "=v"(hi)   // (lo is written while the second instruction's inputs are still to be read; hi is written last)
         : "v"(__double2loint(b)), "v"(__double2loint(a)), "v"(__double2hiint(b)), "v"(__double2hiint(a)), "s"(mask));
     return __hiloint2double(hi, lo);
 }
