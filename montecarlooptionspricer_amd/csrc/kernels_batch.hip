@@ -449,6 +449,7 @@ static int run_batch_chunk(mcg_ctx* ctx, std::vector<BatchRow>& h, BatchArgs a, 
     const size_t smem_w = ((size_t)2 * mphi_max + (size_t)max_steps + 1 + (size_t)m_max) * sizeof(double);
     size_t smem_p = 0;  // largest over the transform sizes present (the staging part does not grow with Mz)
     for (int m = 1; m <= m_max; m <<= 1) smem_p = std::max(smem_p, rb_smem_bytes(m, std::min(m, max_steps)));
+    smem_p += (size_t)study_switch("MCG_BATCH_PATHS_EXTRA_LDS_KB", 0) << 10;  // (A/B builds: fewer workgroups per CU -- how much does the generator live off its occupancy?)
     const size_t smem_c = ((size_t)max_steps + 1) * sizeof(double);
     // workgroups per row: enough for the row with the fewest pairs per workgroup (the largest Mz)
     const int n_pairs = (a.n_paths + 1) / 2;
