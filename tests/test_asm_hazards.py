@@ -67,6 +67,20 @@ _Z1kv:
 	v_fma_f64 v[4:5], v[4:5], v[6:7], s[40:41]
 	;;#ASMEND
 """)
+    bad_trans = tmp_path / "bad_trans.s"
+    bad_trans.write_text("""
+_Z1kv:
+	v_rsq_f64_e32 v[10:11], v[2:3]
+	;;#ASMSTART
+	v_fma_f64 v[4:5], v[10:11], v[6:7], s[40:41]
+	;;#ASMEND
+	v_rcp_f64_e32 v[12:13], v[2:3]
+	v_mul_f64 v[0:1], v[0:1], v[0:1]
+	;;#ASMSTART
+	v_fma_f64 v[4:5], v[12:13], v[6:7], s[40:41]
+	;;#ASMEND
+""")
+    assert len(chk.check_trans(str(bad_trans))) == 1          # the first asm FMA only: the second has a wait state in between
     assert len(chk.check_wide_stores(str(bad_store))) == 1 and chk.check_wide_stores(str(ok_store)) == []
     found = chk.check(str(bad_sgpr))
     assert len({f[1] for f in found}) == 3, found     # three asm statements: the mask, the restored constant, the store's base (3 < 5 wait states)

@@ -18,6 +18,9 @@ build the generator's next instruction overwrote half of the data pair: rows 0, 
 foreign low or high word in a quarter of the lanes (relative error 2^-33 = 1.2e-10, or percent) while the price chain in
 the registers stayed right.  The store's asm statement now carries its own `s_nop 1`.
 
+A third member of the family is checked as well: the result of a transcendental VALU instruction read by an asm VALU
+instruction in the very next wait state (gfx940+ forwarding hazard).
+
 Usage: check_asm_hazards.py file.s [...]   -> lists every asm statement that reads an SGPR too soon after a VALU write;
 exit code 1 if any."""
 import re
@@ -105,6 +108,40 @@ def check_wide_stores(path):
     return bad
 
 
+TRANS = re.compile(r"^\s*v_(?:rcp|rsq|sqrt|exp|log|sin|cos)(?:_iflag|_clamp|_legacy)?_f(?:16|32|64)(?:_e32|_e64)?\s+(v\d+|v\[\d+:\d+\])")
+
+
+def check_trans(path):
+    """gfx940+: the result of a transcendental VALU instruction (v_rcp / v_rsq / v_sqrt / v_exp / v_log / v_sin / v_cos) must
+    not be read by a non-transcendental VALU instruction in the very next wait state; asm statements that read such a
+    register right behind its producer are listed."""
+    bad = []
+    lines = open(path, errors="ignore").read().splitlines()
+    kernel, in_asm, pending = "?", False, None   # pending: (vgprs, line) of a trans op issued in the previous wait state
+    for n, line in enumerate(lines, 1):
+        t = line.strip()
+        head = t.split(";")[0].strip()
+        if head.endswith(":") and head.startswith("_Z"):
+            kernel = head[:-1]
+        if "#ASMSTART" in t:
+            in_asm = True
+            continue
+        if "#ASMEND" in t:
+            in_asm = False
+            continue
+        if not is_insn(line):
+            continue
+        body = t.split(";")[0]
+        if in_asm and pending and body.startswith("v_") and not TRANS.match(body):
+            ops = body.split(None, 1)[1] if " " in body else ""
+            src = ops.split(",", 1)[1] if "," in ops else ""
+            if vregs(src) & pending[0]:
+                bad.append((path, n, kernel, body, sorted(vregs(src) & pending[0]), pending[1]))
+        m = TRANS.match(body)
+        pending = (vregs(m.group(1)), n) if m else None
+    return bad
+
+
 def check(path):
     bad = []
     lines = open(path, errors="ignore").read().splitlines()
@@ -144,13 +181,16 @@ def check(path):
 
 
 if __name__ == "__main__":
-    allbad, stores = [], []
+    allbad, stores, trans = [], [], []
     for f in sys.argv[1:]:
         allbad += check(f)
         stores += check_wide_stores(f)
+        trans += check_trans(f)
     for path, n, kernel, t, r, age, need in allbad:
         print(f"{path}:{n}: {kernel}: asm `{t}` reads s{r} {age} wait state(s) after a VALU write (needs {need})")
     for path, ln, kernel, txt, regs_, age, n, body in stores:
         print(f"{path}:{ln}: {kernel}: asm `{txt}`: its data v{regs_} is overwritten {age} wait state(s) later by `{body}` (line {n}; needs 2)")
-    print(f"{len(allbad) + len(stores)} hazard(s) in {len(sys.argv) - 1} file(s)")
-    sys.exit(1 if allbad or stores else 0)
+    for path, n, kernel, body, regs_, ln in trans:
+        print(f"{path}:{n}: {kernel}: asm `{body}` reads v{regs_}, the result of the transcendental instruction one line up (line {ln}; needs 1 wait state)")
+    print(f"{len(allbad) + len(stores) + len(trans)} hazard(s) in {len(sys.argv) - 1} file(s)")
+    sys.exit(1 if allbad or stores or trans else 0)
