@@ -26,7 +26,11 @@ plus "roofline", "cpu_baseline" (N=1 only) and "extra.configs":
     timed after the C2 loop without any exchange ("none": every rank prices its own shard, the baseline) and through each
     collective in turn -- the node mailbox in host memory ("shm"), the same in peer-mapped device memory ("ipc") and the
     built-in RCCL communicator ("rccl") -- with the slowest and the fastest rank's ms per pass, the collective that
-    actually ran and the number of ranks its communicator has SEEN.
+    actually ran and the number of ranks its communicator has SEEN.  Where they run is `--c5-rows`: in a child process per
+    rank (`child`: 2 x N GPU processes meanwhile) or in the rank processes themselves (`inline`: N), `auto` = child while
+    2 x N fits under the pool's process guard as measured, else inline.  Either way the headline cannot be lost to them:
+    rank 0 hands its line to a guardian process (LastWill, forked before anything touches the GPU) as soon as the
+    headline is complete and again after every row; the guardian prints it when rank 0 ends -- however it ends.
 """
 from __future__ import annotations
 
@@ -339,12 +343,85 @@ class Gpu:
         return torch.cuda.device_count()
 
 
+def agree(flags, dist, torch, dev) -> list:
+    """Element-wise AND of `flags` over the ranks (one all-reduce).  Every rank enters it -- from its except branch too."""
+    t = torch.tensor([1 if f else 0 for f in flags], device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return [int(x) == 1 for x in t.tolist()]
+
+
 def everyone(ok: bool, dist, torch, dev) -> bool:
     """True iff `ok` on EVERY rank.  Every rank enters it -- from its except branch too -- so it doubles as the point where
-    the ranks of a step that may fail locally meet again, whatever happened to them."""
-    t = torch.tensor([1 if ok else 0], device=dev)
-    dist.all_reduce(t, op=dist.ReduceOp.MIN)
-    return int(t.item()) == 1
+    the ranks of a step that may fail locally meet again.  That is sound only where the step itself cannot leave a peer
+    inside ANOTHER collective for good: set-up steps (nothing collective inside), and passes over the node mailbox (shm /
+    ipc: the segment barrier times out, the peers raise and arrive here too).  A pass over the built-in RCCL communicator or
+    over torch.distributed is not bounded like that -- see c5_sharded_rows.phase for what a failing rank does there."""
+    return agree([ok], dist, torch, dev)[0]
+
+
+class LastWill:
+    """Rank 0 of an N > 1 run: a guardian process, forked before anything touches the GPU, that owns the job's ONE JSON
+    line.  The rank sends it the line as soon as the headline is complete ("WILL", re-sent after every C5 row) and the
+    finished line at the end ("FINAL"); when the pipe closes -- the rank returned, raised, was killed by the launcher after
+    a peer died, or took a device fault in a C5 row -- the guardian prints FINAL, or else the last WILL with an "aborted"
+    note.  Nothing after the headline can cost the line any more, whatever the C5 rows do."""
+
+    def __init__(self, json_out):
+        import signal
+        r, w = os.pipe()
+        self.pid = os.fork()
+        if self.pid == 0:
+            code = 0
+            try:
+                os.close(w)
+                for sg in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+                    signal.signal(sg, signal.SIG_IGN)
+                will = final = None
+                with os.fdopen(r, "r") as f:
+                    for ln in f:
+                        if not ln.endswith("\n"):
+                            break                      # (the rank died inside a write)
+                        if ln.startswith("WILL "):
+                            will = ln[5:]
+                        elif ln.startswith("FINAL "):
+                            final = ln[6:]
+                line = final
+                if line is None and will is not None:
+                    j = json.loads(will)
+                    j["aborted"] = ("rank 0 ended before the line was finished (a peer rank failed and the launcher ended the job, or "
+                                    "a C5 row took the process down); the headline was complete, extra.configs holds the rows that were")
+                    line = json.dumps(j)
+                if line:
+                    json_out.write(line.rstrip("\n") + "\n")
+                    json_out.flush()
+            except BaseException:   # noqa: BLE001
+                code = 1
+            finally:
+                os._exit(code)
+        os.close(r)
+        self._w = os.fdopen(w, "w")
+
+    def update(self, out: dict):
+        self._w.write("WILL " + json.dumps(out) + "\n")
+        self._w.flush()
+
+    def final(self, out: dict):
+        self._w.write("FINAL " + json.dumps(out) + "\n")
+        self._w.flush()
+        self._w.close()
+        os.waitpid(self.pid, 0)
+
+
+GPU_PROCESS_GUARD = 6   # what the pool's process guard allowed on the builder's one-GPU box (DESIGN 6); a node's is not stated
+
+
+def c5_rows_mode(args, world: int) -> str:
+    """child: every rank starts a child process for the C5 rows while it still holds the device (2 x world GPU processes; a
+    fault in a row cannot touch the parent).  inline: the rows run in the rank processes, after the headline is safe with
+    the guardian (world GPU processes).  auto: child where 2 x world fits under the process guard measured, else inline."""
+    if args.c5_rows != "auto":
+        return args.c5_rows
+    return "child" if 2 * world <= GPU_PROCESS_GUARD else "inline"
 
 
 def install_collective(eng, mc, want: str, dist, torch, rank: int, world: int, dev="cuda") -> str:
@@ -404,39 +481,55 @@ def install_collective(eng, mc, want: str, dist, torch, rank: int, world: int, d
     return got
 
 
-def c5_sharded_rows(args, mc, N, dist, torch, device, stream, rank, world, hw=Gpu, make_engine=None) -> list:
+def c5_sharded_rows(args, mc, N, dist, torch, device, stream, rank, world, hw=Gpu, make_engine=None, on_row=None,
+                    deadline=None) -> list:
     """BASELINE.json configs[4] on this run's N ranks, after the headline loop: rBergomi (H = 0.1, eta = 1.9) American put,
     LSM order 2, 252 steps, --c5-paths (8M) paths per GPU of ONE Philox stream, timed through each collective of
     --c5-collectives in turn on a fresh context.  One untimed pass, then 3 timed between barriers; per row: the slowest
     and the fastest rank's ms per pass, the collective that ran, what its communicator has seen (mcg_comm_info), the
     launches of the LSM sweep per pass (1 = the one-launch sweep exchanged inside the kernel) and the global price.
-    A row is a sequence of local phases; after each the ranks meet in everyone(): a rank that raised is there too, so the
-    row is recorded as failed on ALL ranks at once instead of some of them waiting in the next collective."""
+    A row is a sequence of local phases; after each the ranks meet in agree(): a rank that raised is there too, so the
+    row is recorded as failed on ALL ranks at once -- WHERE the peers can get there: set-up phases and passes over the node
+    mailbox (its barrier times out).  A rank that raises inside a pass over the built-in RCCL communicator or over
+    torch.distributed leaves its peers inside an all-reduce that never completes (or, worse, would pair its own agreement
+    all-reduce with their data all-reduce): there it ends the job instead -- exit code 17, the launcher (or the parents of
+    the child job) take the peers down, the rows finished so far and the headline are already with rank 0's guardian.
+    `deadline` (time.time() value): once any rank is past it the remaining rows are abandoned by all ranks together."""
     from montecarlooptionspricer_amd.sharding import shard_range
     rows, reps, steps = [], 3, 252
     total = args.c5_paths * world
     begin, count = shard_range(total, rank, world, align=2)
     dev = torch.device("cuda", device) if hw is Gpu else torch.device("cpu")
     make_engine = make_engine or (lambda: mc.PathEngine(device, stream=stream))
+    out_of_time = False
     for want in [c for c in args.c5_collectives.split(",") if c]:
+        if out_of_time:
+            break
         e5, err, row = None, None, None
         if args.rehearsal:
             os.environ["MCG_REHEARSAL_ROW"] = want   # (read by the rehearsal's failure injection only)
+        st = {"unbounded": False}
 
         def phase(fn):
-            """Run a local step; every rank then learns whether it worked everywhere."""
-            nonlocal err
+            """Run a local step; every rank then learns whether it worked everywhere (and whether there is time left)."""
+            nonlocal err, out_of_time
             ok = True
             if err is None:
                 try:
                     fn()
                 except Exception as ex:   # noqa: BLE001
                     err, ok = f"{type(ex).__name__}: {ex}", False
+                    if st["unbounded"]:
+                        print(f"bench: rank {rank} failed inside a pass over '{st.get('got')}' ({err}); its peers cannot leave that "
+                              "collective, so this rank ends the job (exit code 17)", file=sys.stderr, flush=True)
+                        os._exit(17)
             else:
                 ok = False
-            return everyone(ok, dist, torch, dev)
-
-        st = {}
+            in_time = deadline is None or time.time() < deadline
+            ok, in_time = agree([ok, in_time], dist, torch, dev)
+            if not in_time:
+                out_of_time = True
+            return ok and in_time
 
         def setup():
             nonlocal e5
@@ -470,7 +563,9 @@ def c5_sharded_rows(args, mc, N, dist, torch, device, stream, rank, world, hw=Gp
                 st["got"] = "none (every rank prices its own shard alone: a local price, the baseline the routes below add their exchange to)" \
                     if want == "none" else install_collective(e5, mc, want, dist, torch, rank, world, dev)
                 st["info"] = e5.comm_info()
+                st["unbounded"] = st["got"].startswith(("rccl", "torch"))
             good = good and phase(warm) and phase(timed)
+            st["unbounded"] = False
             if good:
                 t = torch.tensor([st["mine"], -st["mine"]], dtype=torch.float64, device=dev)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -490,6 +585,9 @@ def c5_sharded_rows(args, mc, N, dist, torch, device, stream, rank, world, hw=Gp
                     "rank0_generator_ms_per_pass": gen_ms / reps, "rank0_lsm_sweep_ms_per_pass": sw_ms / reps,
                     "rank0_lsm_sweep_launches_per_pass": sw_n // reps,
                     "lsm_one_launch": e5.lsm_one_launch_enabled() and sw_n // reps <= 2, "rank0_stats": mc.stats()}
+            elif out_of_time:
+                row = {"config": "C5", "collective_requested": want,
+                       "error": "the wall-clock budget of the C5 rows was used up: this row and the remaining ones were abandoned by all ranks together"}
             else:
                 row = {"config": "C5", "collective_requested": want,
                        "error": err or "a peer rank failed in this row (its own stderr says why); all ranks abandoned it together"}
@@ -499,14 +597,24 @@ def c5_sharded_rows(args, mc, N, dist, torch, device, stream, rank, world, hw=Gp
             if e5 is not None:
                 e5.close()
         rows.append(row)
+        if on_row is not None:
+            on_row(rows)
     return rows
 
 
-def c5_rows_in_child_job(args, dist, rank: int, world: int):
+def c5_rows_in_child_job(args, dist, torch, rank: int, world: int, budget_s: float):
     """Every rank of this job starts `bench.py --c5-child` as a child process (same RANK / LOCAL_RANK / WORLD_SIZE, a
-    rendezvous port of its own); rank 0 returns the rows its child printed, or one row that says what went wrong."""
+    rendezvous port of its own) and the parents WATCH the children together: four times a second they exchange (over a gloo
+    group of their own: no device work beside the children's timing) who is still running and who has failed -- a child
+    that could not be started (spawn refused), one that exited non-zero, or the budget running out.  On the first failure
+    every parent kills its child: no parent waits for a child whose peer is gone.  Rank 0's child prints each finished row
+    as a line of its own, so the rows before a failure are kept.  Returns (on rank 0) the rows plus, after a failure, one
+    row that says what went wrong."""
     import socket
     import subprocess
+    import tempfile
+    from datetime import timedelta
+    mon = dist.new_group(backend="gloo", timeout=timedelta(seconds=120))
     box = [None]
     if rank == 0:
         with socket.socket() as sk:
@@ -519,21 +627,71 @@ def c5_rows_in_child_job(args, dist, rank: int, world: int):
         if k.startswith("TORCHELASTIC_") or k in ("TORCH_NCCL_ASYNC_ERROR_HANDLING",):
             env.pop(k)
     cmd = [sys.executable, os.path.abspath(__file__), "--c5-child", "--gpus", str(world), "--backend", args.backend,
-           "--c5-paths", str(args.c5_paths), "--c5-collectives", args.c5_collectives] + (["--rehearsal"] if args.rehearsal else [])
-    rows = None
+           "--c5-paths", str(args.c5_paths), "--c5-collectives", args.c5_collectives, "--c5-budget", str(budget_s)] + (["--rehearsal"] if args.rehearsal else [])
+    fo, fe = tempfile.TemporaryFile("w+"), tempfile.TemporaryFile("w+")
+    proc, why = None, None
     try:
-        p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
-        if rank == 0:
-            lines = [ln for ln in p.stdout.splitlines() if ln.startswith("[")]
-            if p.returncode == 0 and lines:
-                rows = json.loads(lines[-1])
-            else:
-                rows = [{"config": "C5", "error": f"child job failed (exit code {p.returncode})", "stderr_tail": p.stderr[-1500:]}]
-    except subprocess.TimeoutExpired:
-        if rank == 0:
-            rows = [{"config": "C5", "error": "child job timed out after 900 s"}]
+        if os.environ.get("MCG_BENCH_SPAWN_FAIL") in (str(rank), "all"):   # test hook: the pool refuses the process
+            raise OSError(11, "Resource temporarily unavailable (injected)")
+        proc = subprocess.Popen(cmd, env=env, stdout=fo, stderr=fe, text=True)
+    except OSError as e:
+        why = f"rank {rank}: the child process could not be started ({e})"
+        print("bench: " + why, file=sys.stderr, flush=True)
+    t_end = time.time() + budget_s + 60.0   # (the child abandons its rows at budget_s by itself; this is for one that hangs)
+    failed_any = False
+    while True:
+        rc = proc.poll() if proc is not None else 1
+        failed = proc is None or (rc is not None and rc != 0) or time.time() > t_end
+        t = torch.tensor([1 if failed else 0, 1 if (proc is not None and rc is None) else 0])
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=mon)
+        if int(t[0]):
+            failed_any = True
+            if proc is not None and proc.poll() is None:
+                proc.kill()
+            break
+        if not int(t[1]):
+            break
+        time.sleep(0.25)
+    if proc is not None:
+        try:
+            proc.wait(timeout=30)
+        except subprocess.TimeoutExpired:
+            pass
+    rows = None
+    if rank == 0:
+        fo.seek(0)
+        rows = [json.loads(ln[4:]) for ln in fo.read().splitlines() if ln.startswith("ROW ")]
+        if failed_any:
+            fe.seek(0)
+            rc = proc.returncode if proc is not None else None
+            rows.append({"config": "C5", "error": why or (f"child job failed (exit code {rc})" if rc not in (None, 0, -9) else
+                                                          "child job ended by its parents: a peer rank's child failed, could not be started, or "
+                                                          f"the job ran past {budget_s + 60:.0f} s (every rank's own stderr says which)"),
+                         "stderr_tail": fe.read()[-1500:]})
     dist.barrier()
     return rows
+
+
+def c5_rows_inline(args, mc, N, dist, torch, device, stream, rank, world, hw, make_engine, will, out, budget_s: float):
+    """The C5 rows in the rank processes themselves (world GPU processes, not 2 x world).  The headline is with the guardian
+    already; every finished row is sent after it.  A wall-clock budget: past it the ranks abandon the remaining rows
+    together (checked in every agreement); a rank still inside a row a minute after that -- a collective that never
+    returns -- ends the job (exit code 18), which the guardian's line survives."""
+    import threading
+    dog = threading.Timer(budget_s + 60.0, lambda: (print(f"bench: rank {rank}: the inline C5 rows hang past their budget; ending the job",
+                                                          file=sys.stderr, flush=True), os._exit(18)))
+    dog.daemon = True
+    dog.start()
+
+    def on_row(rows):
+        if will is not None:
+            out.setdefault("extra", {})["configs"] = list(rows)
+            will.update(out)
+    try:
+        return c5_sharded_rows(args, mc, N, dist, torch, device, stream, rank, world, hw, make_engine, on_row=on_row,
+                               deadline=time.time() + budget_s)
+    finally:
+        dog.cancel()
 
 
 def main() -> None:
@@ -558,6 +716,12 @@ def main() -> None:
     ap.add_argument("--rehearsal", action="store_true",
                     help="control-flow rehearsal of an N > 1 run on CPU ranks (gloo; tests/bench_rehearsal.py stands in for the GPU "
                          "and the engine): every collective of this script runs, nothing is computed or timed, the line says so")
+    ap.add_argument("--c5-rows", default=os.environ.get("MCG_BENCH_C5_ROWS", "auto"), choices=["auto", "child", "inline", "off"],
+                    help="where the C5 rows of an N > 1 run are timed: child = a child process per rank (2 x N GPU processes while they "
+                         "run; a fault there cannot touch the parent), inline = in the rank processes after the headline is safe with rank "
+                         "0's guardian (N GPU processes), off = not at all; auto = child while 2 x N <= %d, else inline" % GPU_PROCESS_GUARD)
+    ap.add_argument("--c5-budget", type=float, default=float(os.environ.get("MCG_BENCH_C5_BUDGET", "600")),
+                    help="wall-clock seconds for all C5 rows of an N > 1 run; past it the ranks abandon the remaining rows together")
     ap.add_argument("--c5-child", action="store_true",
                     help="(internal) this process is one rank of the child job that times the C5 rows of an N > 1 run")
     args = ap.parse_args()
@@ -575,6 +739,9 @@ def main() -> None:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # rank 0 of an N > 1 job hands its line to a guardian process, forked HERE: before torch is imported, before anything
+    # has touched the GPU, while this process has one thread
+    will = LastWill(json_out) if (world > 1 and rank == 0 and not args.c5_child) else None
 
     import torch
 
@@ -610,9 +777,12 @@ def main() -> None:
         if os.environ.get("MCG_BENCH_C5_CHILD_FAIL") == "1":   # test hook: the child job dies; the parent's line must survive it
             os._exit(3)
         stream = hw.current_stream_handle()
-        rows = c5_sharded_rows(args, mc, N, dist, torch, device, stream, rank, world, hw, make_engine)
-        if rank == 0:
-            print(json.dumps(rows), file=json_out, flush=True)
+
+        def row_out(rows):   # each finished row at once: what is done stays done if a later row takes the job down
+            if rank == 0:
+                print("ROW " + json.dumps(rows[-1]), file=json_out, flush=True)
+        c5_sharded_rows(args, mc, N, dist, torch, device, stream, rank, world, hw, make_engine, on_row=row_out,
+                        deadline=time.time() + args.c5_budget)
         dist.barrier()
         dist.destroy_process_group()
         return
@@ -708,15 +878,31 @@ def main() -> None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev_name)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    mode = c5_rows_mode(args, world) if (dist is not None and args.config == "c2" and not args.no_extra) else "off"
+
+    def c5_rows_after(out):
+        """BASELINE.json configs[4] at this N, through every collective in turn (all ranks take part; rank 0 reports) -- AFTER
+        the headline dict is complete and with rank 0's guardian: these routes have not run on more than one GPU, and
+        whatever goes wrong in them -- an exception, a time-out, a refused process, a device fault -- must not cost the line."""
+        if mode == "off":
+            return None
+        if will is not None:
+            will.update(out)
+        eng.trim()
+        if mode == "child":
+            return c5_rows_in_child_job(args, dist, torch, rank, world, args.c5_budget)
+        return c5_rows_inline(args, mc, N, dist, torch, device, stream, rank, world, hw, make_engine, will, out, args.c5_budget)
+
     if args.rehearsal:   # nothing was computed or timed: say what ran, and stop
-        c5_rows = c5_rows_in_child_job(args, dist, rank, world) if not args.no_extra else None
+        out = {"rehearsal": True, "metric": "Mpaths/sec at 252 steps", "value": None, "unit": "Mpaths/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "data": "none (control-flow rehearsal on CPU ranks: nothing computed, nothing timed)",
+               "config": {"workload": "the N > 1 control flow of this script", "paths_per_gpu": args.paths, "global_paths": total_paths,
+                          "collective": collective, "comm": eng.comm_info(), "c5_rows": mode},
+               "ids_counted": price, "ids_summed": se}     # every rank's shard went through the collective once
+        c5_rows = c5_rows_after(out)
         if rank == 0:
-            print(json.dumps({"rehearsal": True, "metric": "Mpaths/sec at 252 steps", "value": None, "unit": "Mpaths/s", "n_gpus": world,
-                              "steps": args.steps, "warmup": args.warmup, "data": "none (control-flow rehearsal on CPU ranks: nothing computed, nothing timed)",
-                              "config": {"workload": "the N > 1 control flow of this script", "paths_per_gpu": args.paths, "global_paths": total_paths,
-                                         "collective": collective, "comm": eng.comm_info()},
-                              "ids_counted": price, "ids_summed": se,     # every rank's shard went through the collective once
-                              "extra": {"configs": c5_rows}}), file=json_out, flush=True)
+            out["extra"] = {"configs": c5_rows}
+            will.final(out)
         eng.close()
         dist.barrier()
         dist.destroy_process_group()
@@ -839,19 +1025,20 @@ def main() -> None:
                 out["extra"]["c2_cold_first_launch_ms"] = cold_ms
             except Exception as e:
                 out["extra"] = {"configs": [], "error": str(e)}
-    # BASELINE.json configs[4] at this N, through every collective in turn (all ranks take part; rank 0 reports)
-    # They run in a CHILD job (every rank starts one child process; the children form their own process group): these
-    # routes have never run on more than one GPU, and whatever goes wrong in them -- an exception, a time-out, a device
-    # fault that takes the process with it -- must not cost the headline line, which is complete at this point.
     c5_rows = None
-    if dist is not None and args.config == "c2" and not args.no_extra:
-        eng.trim()
-        c5_rows = c5_rows_in_child_job(args, dist, rank, world)
+    if mode != "off":
+        if rank == 0:
+            out["config"]["comm"] = eng.comm_info()
+            out["config"]["c5_rows"] = mode
+        c5_rows = c5_rows_after(out if rank == 0 else None)
     if rank == 0:
         if c5_rows is not None:
             out.setdefault("extra", {})["configs"] = c5_rows
         out["config"]["comm"] = eng.comm_info()
-        print(json.dumps(out), file=json_out, flush=True)
+        if will is not None:
+            will.final(out)
+        else:
+            print(json.dumps(out), file=json_out, flush=True)
     eng.timing_enable(False)
     eng.close()
     if dist is not None:

@@ -12,7 +12,10 @@ Failure injection (MCG_REHEARSAL_FAIL = comma-separated):
   shm_init:<rank>     that rank's init_shm raises            -> all ranks fall to rccl together
   rccl_id             rank 0 cannot create the RCCL id       -> all ranks raise together, fall to torch
   rccl_probe:<rank>   that rank cannot load librccl          -> nobody enters ncclCommInitRank, all fall to torch
-  pass:<rank>:<want>  that rank raises in the passes of the C5 row <want> -> the row fails on ALL ranks, the next row runs
+  pass:<rank>:<want>  that rank raises in the passes of the C5 row <want> -> over the node mailbox (shm, ipc): the row fails on
+                      ALL ranks, the next row runs; over the RCCL / torch route (unbounded: the peers cannot leave their
+                      all-reduce) the rank ends the job with exit code 17 and the line survives with rank 0's guardian
+MCG_BENCH_SPAWN_FAIL = <rank>: that rank's child process of `--c5-rows child` cannot be started (bench.py's own hook)
 """
 import ctypes as C
 import os

@@ -237,4 +237,33 @@ def test_bench_headline_survives_a_failing_c5_child_job():
     out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
     assert out["n_gpus"] == 2 and out["value"] > 0 and out["parity"]["abs_err_over_std_err"] < 4
     rows = out["extra"]["configs"]
-    assert len(rows) == 1 and "child job failed (exit code 3)" in rows[0]["error"]
+    # (whichever parent sees its child's exit code 3 first has every parent end its child: rank 0's row says one or the other)
+    assert len(rows) == 1 and ("child job failed (exit code 3)" in rows[0]["error"] or "child job ended by its parents" in rows[0]["error"])
+    assert out["config"]["c5_rows"] == "child"
+
+
+def test_bench_two_ranks_with_the_c5_rows_inline():
+    """`--c5-rows inline` (what `auto` picks from four ranks on, where a child process per rank would put 2 x N processes on
+    the GPUs): the rows run in the two rank processes themselves after the headline went to rank 0's guardian; same rows,
+    same prices as the single-rank run, one JSON line, exit code 0."""
+    root = os.path.dirname(HERE)
+    c2_paths, c5_paths = 500_000, 200_000
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--backend", "gloo", "--paths", str(c2_paths), "--c5-paths", str(c5_paths), "--c5-rows", "inline", "--c5-collectives", "none,ipc,rccl"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-4000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out["config"]["c5_rows"] == "inline" and "aborted" not in out and out["value"] > 0
+    rows = out["extra"]["configs"]
+    assert [r["collective_requested"] for r in rows] == ["none", "ipc", "rccl"] and all("error" not in r for r in rows), rows
+    e = mc.PathEngine(0)
+    P = e.rbergomi(SEED, RB["S0"], RB["r"], RB["xi"], RB["H"], RB["eta"], RB["rho"], DT, 252, 2 * c5_paths)
+    want = e.price_lsm(P, RB["r"], 100.0, 252 * DT, DT, False, 2)
+    P.free()
+    e.close()
+    for r in rows[1:]:
+        assert abs(r["price"] - want[0]) <= 1e-9 * want[0] and r["comm"]["n_ranks"] == 2, r

@@ -1,0 +1,53 @@
+#!/bin/bash
+# The GPU-box sessions of this repo, one script (it replaces the one-off tools/gpu_r4?.sh of round 4):
+#     gpurun --timeout N -- 'tools/gpu_task.sh <task> [tag] [args...]'
+# Every task writes under gpurun_out/<tag>_*; steps are joined so that a step killed at its time limit ends the session.
+#   suite      the whole GPU test suite (one process), slowest tests listed
+#   tests K    pytest -m gpu -k "K"
+#   bench      the driver's default line (bench.py, N = 1) -> <tag>_bench.json
+#   limiter    PMC passes that attribute the headline kernel's non-issue cycles (tools/pmc_passes.py, C2 command)
+#   stats      rocprofv3 --kernel-trace --stats of the default bench -> <tag>_stats/
+#   ab A B [configs] [reps]   tools/ab_libs.sh between two built libraries
+#   two-rank   bench.py with two ranks sharing the card (gloo), inline / child / off C5 rows
+set -o pipefail
+export TMPDIR=/tmp
+task=${1:?task}; T=${2:-r5}; shift; shift || true
+O=gpurun_out
+mkdir -p $O
+guard() { rc=$?; if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "step killed at its limit (rc=$rc): stopping"; exit $rc; fi; return $rc; }
+C2="python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extra"
+case $task in
+suite)
+  timeout -k 10 1000 python -m pytest tests -m gpu -q --durations=8 > $O/${T}_pytest.log 2>&1; rc=$?; echo "pytest rc=$rc"; tail -14 $O/${T}_pytest.log; exit $rc ;;
+tests)
+  timeout -k 10 900 python -m pytest tests -m gpu -q -x -k "$1" > $O/${T}_pytest.log 2>&1; rc=$?; echo "pytest rc=$rc"; tail -14 $O/${T}_pytest.log; exit $rc ;;
+bench)
+  timeout -k 10 900 python3 bench.py "$@" > $O/${T}_bench.json 2> $O/${T}_bench.err; rc=$?; echo "bench rc=$rc"; tail -3 $O/${T}_bench.err; head -c 1500 $O/${T}_bench.json; exit $rc ;;
+limiter)
+  timeout -k 10 1100 python3 tools/pmc_passes.py --tag ${T}_c2lim --kernels k_gbm_paths,k_probe_write \
+    --group "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" \
+    --group "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_FLAT GRBM_GUI_ACTIVE" \
+    --group "SQ_INST_CYCLES_VMEM_WR SQ_INST_CYCLES_SALU SQ_INST_CYCLES_SMEM SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS GRBM_GUI_ACTIVE" \
+    --group "SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_VMEM_WR_TA_DATA_FIFO_FULL SQ_INST_LEVEL_VMEM SQ_LEVEL_WAVES SQ_IFETCH SQ_IFETCH_LEVEL GRBM_GUI_ACTIVE" \
+    --group "SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_BRANCH SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE" \
+    --group "TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_FLAT_WRITE_WAVEFRONTS_sum GRBM_GUI_ACTIVE" \
+    --group "TCP_PENDING_STALL_CYCLES_sum TCP_WRITE_TAGCONFLICT_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum TCP_TCC_WRITE_REQ_sum GRBM_GUI_ACTIVE" \
+    --group "TCP_GATE_EN1_sum TCP_GATE_EN2_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_TCC_WRITE_REQ_LATENCY_sum GRBM_GUI_ACTIVE" \
+    --group "TCC_BUSY_sum TCC_CYCLE_sum TCC_WRITE_sum TCC_REQ_sum GRBM_GUI_ACTIVE" \
+    --group "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_WRREQ_STALL_sum TCC_TOO_MANY_EA_WRREQS_STALL_sum GRBM_GUI_ACTIVE" \
+    --group "TCC_EA0_WRREQ_DRAM_CREDIT_STALL_sum TCC_EA0_WRREQ_LEVEL_sum TCC_TAG_STALL_sum TCC_SRC_FIFO_FULL_sum GRBM_GUI_ACTIVE" \
+    --group "TCC_EA0_WRREQ_GMI_CREDIT_STALL_sum TCC_EA0_WRREQ_IO_CREDIT_STALL_sum TCC_NORMAL_WRITEBACK_sum TCC_STREAMING_REQ_sum GRBM_GUI_ACTIVE" \
+    -- $C2 2>&1 | tee $O/${T}_c2lim.log; guard ;;
+stats)
+  timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${T}_stats -- python3 bench.py "$@" > $O/${T}_stats.log 2>&1; rc=$?; echo "stats rc=$rc"; tail -2 $O/${T}_stats.log; exit $rc ;;
+ab)
+  timeout -k 10 900 tools/ab_libs.sh ${3:-c2} ${4:-4} $1 $2 2>&1 | tee $O/${T}_ab.log; guard ;;
+two-rank)
+  for mode in inline child off; do
+    timeout -k 10 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29611 \
+      bench.py --gpus 2 --steps 3 --warmup 1 --backend gloo --paths 2000000 --c5-paths 1000000 --c5-rows $mode "$@" \
+      > $O/${T}_two_rank_$mode.json 2> $O/${T}_two_rank_$mode.err; rc=$?; echo "two-rank $mode rc=$rc"; guard || exit $rc
+    head -c 600 $O/${T}_two_rank_$mode.json; echo
+  done ;;
+*) echo "unknown task $task"; exit 2 ;;
+esac
