@@ -103,6 +103,61 @@ def cpu_baseline(n_steps: int, budget_s: float = 15.0) -> dict:
     return out
 
 
+def _timed_chunks(fn, sample, budget_s: float, what: str, kind: str) -> dict:
+    """`fn(sample[:n]) -> (threads, seconds, checksum)` prices a resident [n][m] sample in driver rows of 250 paths under
+    omp dynamic (oracle/ref_harness.cpp: ref_pricer_chunks_omp, oracle/mcg_oracle.cpp: orc_pricer_chunks_omp).  A pilot
+    sizes the sample to the budget; the sample is re-priced until ~the budget is spent."""
+    n0 = min(len(sample), 4000)
+    th, sec, _ = fn(sample[:n0])
+    n = int(min(len(sample), max(n0, n0 / max(sec, 1e-6) * budget_s))) // 250 * 250
+    done, spent = 0, 0.0
+    while spent < 0.8 * budget_s:
+        th, sec, _ = fn(sample[:n])
+        done, spent = done + n, spent + sec
+    return {"value": done / spent / 1e6, "unit": "Mpaths/s", "cores": int(th), "kind": kind,
+            "sample": f"{what}: {done} paths ({n}-path sample of the row's matrix shape, 51 columns, priced {done // n}x) in driver rows of 250 "
+                      f"paths, one PredictOptionPrice call per row under omp parallel for schedule(dynamic) (PredictionGen.cpp:542-546, :719), {spent:.1f} s"}
+
+
+def cpu_baselines_widened(budget_s: float = 3.0) -> dict:
+    """CPU baselines beside the rows of extra.configs that have none of their own (missing #3), each bounded to
+    ~budget_s of wall time on all host cores: the compiled reference ("reference") for AsymptoticAnalysis and
+    BranchingProcesses, this repo's restatement ("port": LSMPricer.cpp and MartingaleOptimizationPricer.cpp need Eigen, which
+    the image lacks) for LSM and MartingaleOptimization, and whole driver rows (generation + four pricers; reference +
+    port mixed, reported as "port").  Reported baselines, not targets."""
+    import numpy as np
+
+    from oracle.binding import Oracle, Reference, have_ref, synthetic_history
+    orc = Oracle()
+    ref = Reference() if have_ref() else None
+    sample = np.ascontiguousarray(orc.paths_gbm(SEED, 100.0, 0.04, 0.2, 0.02, 50, 0, 60_000).T)   # [n][51]: the C3 matrix's law
+    out = {}
+    arg = (250, 0.04, 100.0, 1.0, 0.02, False)
+    out["lsm"] = _timed_chunks(lambda m: orc.pricer_chunks_omp("lsm", m, *arg, 2), sample, budget_s,
+                               "LSM::PredictOptionPrice (restated: oracle/mcg_oracle.cpp orc_lsm_price, order 2, put)", "port")
+    out["martingale"] = _timed_chunks(lambda m: orc.pricer_chunks_omp("martingale", m, *arg, 2), sample, budget_s,
+                                      "MartingaleOptimization::PredictOptionPrice (restated: orc_martingale_price, order 2, 5 iterations, put)", "port")
+    if ref is not None:
+        out["asymptotic"] = _timed_chunks(lambda m: ref.pricer_chunks_omp("asymptotic", m, *arg, 0.2, 0.0), sample, budget_s,
+                                          "AsymptoticAnalysis::PredictOptionPrice (compiled reference, put, sigma 0.2)", "reference")
+        out["branching"] = _timed_chunks(lambda m: ref.pricer_chunks_omp("branching", m, *arg, 0.2, 0.0, 10), sample, budget_s,
+                                         "BranchingProcesses::PredictOptionPrice (compiled reference, put, 10 branches, 50 exercise dates)", "reference")
+        hist = synthetic_history(1001, seed=42)
+        rs = np.random.RandomState(0)
+
+        def rows(n):
+            st = rs.randint(5, 127, size=n)
+            return ref.driver_rows_omp(hist, st, float(hist[-1]) * rs.uniform(0.9, 1.1, size=n), rs.randint(0, 2, size=n), 250, 0.2, 0.08, orc)
+        th, sec, _ = rows(64)
+        n = int(max(64, min(64 / max(sec, 1e-6) * budget_s * 1.5, 2_000_000)))
+        th, sec, _ = rows(n)
+        out["driver_rows"] = {"value": n / sec, "unit": "rows/s", "cores": int(th), "kind": "port",
+                              "sample": f"{n} driver rows (RoughVolatility::GenerateStockPricePaths on a 1001-point synthetic history, 250 paths x 5-126 "
+                                        "steps, then AsymptoticAnalysis and BranchingProcesses of the compiled reference and the restated LSM and "
+                                        f"MartingaleOptimization), omp parallel for schedule(dynamic) over rows as PredictionGen.cpp:542-823, {sec:.1f} s"}
+    return out
+
+
 def reference_parity(eng, mc, ref_price: dict, n_steps: int, seed: int) -> dict:
     """|price - ref| / MC-std-err against the compiled reference itself: the engine prices the same contract
     (rBergomi with the parameters the reference estimates from the same history, same step count, K = S0) and is
@@ -170,7 +225,7 @@ def valu_profile(name: str):
         return None
 
 
-def extra_configs(eng, N) -> list:
+def extra_configs(eng, N, baselines=None) -> list:
     """C3, C4 and the C5 shard on this GPU, once each (one untimed pass, then 3 timed for the wall time and 3 more with
     per-kernel HIP events), after the headline loop: ms per pass, Mpaths/s, the dominant kernel's average launch time and what it achieves against the HBM roofline
     (SURVEY 8d algorithmic bytes) and against the VALU issue rate (instruction count from the committed PMC profile)."""
@@ -224,20 +279,33 @@ def extra_configs(eng, N) -> list:
             tot, cnt = eng.timing_get(k)
             if cnt:
                 kernels[kname] = {"ms_per_pass": tot / reps, "launches_per_pass": cnt // reps}
-        for kname, b in alg.items():  # against the HBM roofline, by SURVEY 8(d)'s algorithmic bytes
+        # Against the HBM roofline by the bytes each kernel MOVES.  Generators: SURVEY 8(d)'s 8 (steps + 1) B per path, all
+        # written (counters: 1.00x, profiles/*_pmc_traffic.json).  LSM sweep: what the one-launch kernels stream by construction
+        # -- every row once with the values in registers (8 B per path and date, k_lsm_coop, <= 2.09M paths = 512 workgroups x
+        # 4096) or twice through the LDS ring (16 B, k_lsm_big: counters 32.47 GB against 32.26, profiles/r04_c5_pmc_traffic.json);
+        # V never touches memory.  SURVEY 8(d)'s 40 B per path and date is the two-pass formulation's traffic, which these
+        # kernels do not generate: it is kept for context only and no fraction is formed with it.
+        for kname, b in alg.items():
             if kname in kernels:
-                kernels[kname]["algorithmic_bytes_per_pass"] = b
-                kernels[kname]["hbm_frac"] = b / (kernels[kname]["ms_per_pass"] * 1e-3) / 1e9 / HBM_PEAK_GBS
-        if "lsm_sweep" in kernels:
-            # what the one-launch sweeps are designed to move: 8 B per path and date with the row kept in registers
-            # (<= 2.09M paths = 512 workgroups x 4096), 16 B when it streams through the LDS ring (k_lsm_big); V never touches memory
-            moved = (8.0 if paths <= 2_097_152 else 16.0) * steps * paths
-            kernels["lsm_sweep"]["design_bytes_per_pass"] = moved
-            kernels["lsm_sweep"]["hbm_frac_of_design_bytes"] = moved / (kernels["lsm_sweep"]["ms_per_pass"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+                moved = b
+                if kname == "lsm_sweep":
+                    kernels[kname]["survey_two_pass_bytes_per_pass"] = b
+                    moved = (8.0 if paths <= 2_097_152 else 16.0) * steps * paths
+                kernels[kname]["bytes_moved_per_pass"] = moved
+                kernels[kname]["hbm_frac"] = moved / (kernels[kname]["ms_per_pass"] * 1e-3) / 1e9 / HBM_PEAK_GBS
         dom = max(alg, key=lambda k: kernels.get(k, {}).get("ms_per_pass", 0.0))
         row = {"config": name, "paths": paths, "ms_per_pass": ms, "Mpaths_per_s": paths / ms / 1e3,
                "price": res[0], "std_err": res[1], "kernels": kernels, "dominant_kernel": dom,
-               "dominant_kernel_ms_per_pass": kernels[dom]["ms_per_pass"], "hbm_frac": kernels[dom].get("hbm_frac")}
+               "dominant_kernel_ms_per_pass": kernels[dom]["ms_per_pass"], "hbm_frac": kernels[dom].get("hbm_frac"),
+               "bound": "valu-issue (fp64; generation_valu_issue_frac)" if dom == "rbergomi" else "hbm"}
+        if dom == "lsm_sweep" and paths <= 2_097_152:
+            # one launch, one grid-wide exchange of the regression moments per exercise date: at 1M paths a date's 8 MB stream in
+            # ~1 us and the exchange costs several -- the sweep is bound by that latency, not by HBM
+            row["bound"] = "latency (one grid-wide moment exchange per exercise date inside the launch)"
+            row["us_per_exercise_date"] = kernels[dom]["ms_per_pass"] * 1e3 / steps
+        if baselines and "lsm_sweep" in kernels and "lsm" in baselines:
+            row["cpu_baseline"] = dict(baselines["lsm"], gpu_comparable="paths / kernels.lsm_sweep.ms_per_pass",
+                                       gpu_value=paths / kernels["lsm_sweep"]["ms_per_pass"] / 1e3)
         if "rbergomi" in kernels:  # the generator is issue-bound: VALU instructions x 4 cycles against SIMD-cycles available
             vp = valu_profile("c4" if steps == 512 else "c5gen")
             if vp and vp.get("paths"):
@@ -250,7 +318,7 @@ def extra_configs(eng, N) -> list:
     return out
 
 
-def widening_configs(eng, N, mc) -> list:
+def widening_configs(eng, N, mc, baselines=None) -> list:
     """SURVEY 8(f) rows in this round's terms: the three other pricers of the reference's driver on the C3 matrix
     (GBM, 1M paths x 50 dates, device-resident) and the batched driver rows (20 000 option rows x 250 rBergomi paths, four
     prices each), once each after one untimed pass: device ms of the pricer's kernels (HIP events), the bytes its
@@ -262,17 +330,17 @@ def widening_configs(eng, N, mc) -> list:
     P = eng.gbm(SEED, 100.0, 0.04, 0.2, dt, steps, n)
     ex = list(range(steps))       # the driver passes 0..steps-1 (PredictionGen.cpp:780-783)
     specs = [
-        ("AsymptoticAnalysis::PredictOptionPrice (put, sigma 0.2, dividend 0) on the C3 matrix", N.K_ASYM,
+        ("asymptotic", "AsymptoticAnalysis::PredictOptionPrice (put, sigma 0.2, dividend 0) on the C3 matrix", N.K_ASYM,
          lambda: eng.price_asymptotic(P, 0.04, 100.0, 1.0, dt, False, 0.2, 0.0), mat,
          "one read of the matrix (k_asym_scan)"),
-        ("MartingaleOptimization::PredictOptionPrice (put, order 2, 5 iterations) on the C3 matrix", N.K_MARTINGALE,
+        ("martingale", "MartingaleOptimization::PredictOptionPrice (put, order 2, 5 iterations) on the C3 matrix", N.K_MARTINGALE,
          lambda: eng.price_martingale(P, 0.04, 100.0, 1.0, dt, False, 2, 5)[0], 2.0 * mat + 8.0 * n,
          "two reads of the matrix (primal + moments, dual) and one of row 0"),
-        ("BranchingProcesses::PredictOptionPrice (put, 10 branches, 50 exercise dates) on the C3 matrix", N.K_BRANCHING,
+        ("branching", "BranchingProcesses::PredictOptionPrice (put, 10 branches, 50 exercise dates) on the C3 matrix", N.K_BRANCHING,
          lambda: eng.price_branching(P, 0.04, 100.0, 1.0, dt, False, 10, ex, SEED)[0], 3.0 * mat + 8.0 * 10 * steps * n,
          "suffix maxima: read S, write F; bounds: read S + 10 random 8-byte gathers in F per path and date (rows of F are 8 MB: L2 / MALL hits, counted as moved)"),
     ]
-    for name, kid, fn, moved, what in specs:
+    for key, name, kid, fn, moved, what in specs:
         fn()
         eng.synchronize()
         eng.timing_reset()
@@ -284,7 +352,10 @@ def widening_configs(eng, N, mc) -> list:
         ms, cnt = eng.timing_get(kid)
         out.append({"config": name, "paths": n, "ms_per_call": wall, "price": price,
                     "kernel_ms_per_call": ms / reps, "launches_per_call": cnt // reps, "bytes_moved_per_call": moved,
-                    "bytes_moved": what, "hbm_frac": moved / (ms / reps * 1e-3) / 1e9 / HBM_PEAK_GBS})
+                    "bytes_moved": what, "hbm_frac": moved / (ms / reps * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "Mpaths_per_s_of_device_time": n / (ms / reps) / 1e3})
+        if baselines and key in baselines:
+            out[-1]["cpu_baseline"] = dict(baselines[key], gpu_comparable="Mpaths_per_s_of_device_time")
     P.free()
     rs = np.random.RandomState(0)   # the row mix of tools/bench_rows.py: 5..126 steps, calls and puts around the money
     rows = []
@@ -315,6 +386,8 @@ def widening_configs(eng, N, mc) -> list:
                 "hbm_frac": moved / (ms / reps * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "note": "latency- and issue-bound small-row work: the HBM fraction is reported, not the bound",
                 "mean_prices": [float(x) for x in pr.mean(axis=0)]})
+    if baselines and "driver_rows" in baselines:
+        out[-1]["cpu_baseline"] = dict(baselines["driver_rows"], gpu_comparable="rows_per_s")
     return out
 
 
@@ -986,10 +1059,9 @@ def main() -> None:
             out["roofline"]["lsm"] = {
                 "sweep_ms_per_pass": sweep_ms / per_pass, "sweep_launches_per_pass": sweep_n // per_pass,
                 "solve_ms_per_pass": solve_ms / per_pass, "solve_launches_per_pass": solve_n // per_pass,
-                "algorithmic_bytes_per_pass": 40.0 * n_steps * count,   # 40 B per path and date
-                "hbm_frac": 40.0 * n_steps * count / max(sweep_ms / per_pass * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS,
-                "design_bytes_per_pass": design,   # what this execution shape moves: 16 B one-launch (k_lsm_big), 32 B per-date kernels
-                "hbm_frac_of_design_bytes": design / max(sweep_ms / per_pass * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS,
+                "survey_two_pass_bytes_per_pass": 40.0 * n_steps * count,   # SURVEY 8(d)'s formulation; context only, not what is moved
+                "bytes_moved_per_pass": design,   # what this execution shape moves: 16 B one-launch (k_lsm_big), 32 B per-date kernels
+                "hbm_frac": design / max(sweep_ms / per_pass * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS,
                 "shape": "one launch (V in registers; beyond 2.09M paths the matrix streams through an LDS-DMA ring)" if one_launch
                          else "per-date route: one kernel + one all-reduce of 8 moments per exercise date; sweep_ms is the span of the "
                               "queued sequence (launches, dispatch gaps, collectives)"}
@@ -1021,7 +1093,13 @@ def main() -> None:
         if world == 1 and dist is None and args.config == "c2" and not args.no_extra:
             try:
                 out["parity"]["rough_regime_vs_reference_sample"] = rough_regime_parity(eng)
-                out["extra"] = {"configs": extra_configs(eng, N) + widening_configs(eng, N, mc)}
+                base = None
+                if not args.no_cpu_baseline:
+                    try:
+                        base = cpu_baselines_widened()
+                    except Exception as e:   # noqa: BLE001 -- reported baselines, never required
+                        print(f"bench: CPU baselines of the widened rows failed ({e})", file=sys.stderr)
+                out["extra"] = {"configs": extra_configs(eng, N, base) + widening_configs(eng, N, mc, base)}
                 out["extra"]["c2_cold_first_launch_ms"] = cold_ms
             except Exception as e:
                 out["extra"] = {"configs": [], "error": str(e)}

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../../include/mcgpu.h"
+#include "../../include/mcgpu_debug.h"
 
 namespace mcg {
 

@@ -331,6 +331,17 @@ class Oracle:
     def num_threads(self):
         return int(self.L.orc_num_threads())
 
+    def pricer_chunks_omp(self, which, row_major, chunk, r, K, maturity, dt, is_call, poly_order=2):
+        """CPU baseline ("port"): which = "lsm" | "martingale" over a resident [n][m] sample in the driver's rows of `chunk`
+        paths under omp dynamic.  -> (threads, seconds, sum of prices)."""
+        a = np.ascontiguousarray(row_major, dtype=np.float64)
+        self.L.orc_pricer_chunks_omp.argtypes = [C.c_int, _dp, C.c_long, C.c_int, C.c_int] + [C.c_double] * 4 + [C.c_int, C.c_int, _dp, _dp]
+        self.L.orc_pricer_chunks_omp.restype = C.c_int
+        sec, chk = C.c_double(), C.c_double()
+        th = self.L.orc_pricer_chunks_omp({"lsm": 0, "martingale": 1}[which], _p(a), a.shape[0], a.shape[1], chunk, r, K, maturity, dt,
+                                          int(bool(is_call)), poly_order, C.byref(sec), C.byref(chk))
+        return th, sec.value, chk.value
+
 
 class Reference:
     """The reference's own compiled path engine (oracle/_ref/libmcref.so)."""
@@ -470,6 +481,37 @@ class Reference:
         out = np.zeros(2)
         D.ref_row_features(_p(h), len(h), _p(out))
         return out[0], out[1]
+
+    def pricer_chunks_omp(self, which, row_major, chunk, r, K, maturity, dt, is_call, sigma=0.2, dividend=0.0, num_branches=10):
+        """CPU baseline ("reference"): which = "asymptotic" | "branching" of the compiled reference over a resident [n][m]
+        sample in the driver's rows of `chunk` paths under omp dynamic.  -> (threads, seconds, sum of prices)."""
+        a = np.ascontiguousarray(row_major, dtype=np.float64)
+        f = self.L.ref_pricer_chunks_omp
+        f.argtypes = [C.c_int, _dp, C.c_long, C.c_int, C.c_int] + [C.c_double] * 4 + [C.c_int, C.c_double, C.c_double, C.c_int, _dp, _dp]
+        f.restype = C.c_int
+        sec, chk = C.c_double(), C.c_double()
+        th = f({"asymptotic": 0, "branching": 1}[which], _p(a), a.shape[0], a.shape[1], chunk, r, K, maturity, dt, int(bool(is_call)),
+               sigma, dividend, num_branches, C.byref(sec), C.byref(chk))
+        return th, sec.value, chk.value
+
+    def driver_rows_omp(self, hist, steps, strikes, is_call, paths_per_row, sigma, dividend, oracle=None):
+        """CPU baseline of whole driver rows (generation + four pricers per row, PredictionGen.cpp:719-791) under omp
+        dynamic; LSM and MartingaleOptimization run through `oracle` (an Oracle: the restatement; the reference's need
+        Eigen).  -> (threads, seconds, sums of the four prices)."""
+        h = np.ascontiguousarray(hist, dtype=np.float64)
+        st = np.ascontiguousarray(steps, dtype=np.int32)
+        k = np.ascontiguousarray(strikes, dtype=np.float64)
+        ic = np.ascontiguousarray(is_call, dtype=np.int32)
+        f = self.L.ref_driver_rows_omp
+        ip = C.POINTER(C.c_int)
+        f.argtypes = [_dp, C.c_size_t, ip, _dp, ip, C.c_long, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_void_p, _dp, _dp]
+        f.restype = C.c_int
+        lsm = C.cast(oracle.L.orc_lsm_price, C.c_void_p) if oracle is not None else None
+        mart = C.cast(oracle.L.orc_martingale_price, C.c_void_p) if oracle is not None else None
+        sec, sums = C.c_double(), np.zeros(4)
+        th = f(_p(h), len(h), st.ctypes.data_as(ip), _p(k), ic.ctypes.data_as(ip), len(st), paths_per_row, sigma, dividend, lsm, mart,
+               C.byref(sec), _p(sums))
+        return th, sec.value, sums
 
     def generate_paths_omp(self, hist, steps, total_paths, chunk):
         h = np.ascontiguousarray(hist, dtype=np.float64)

@@ -990,6 +990,36 @@ void orc_row_features(const double* hist, size_t n, double* out2) {
     out2[1] = sum;                                         // :344
 }
 
+// CPU baseline of bench.py's LSM (C3) and MartingaleOptimization rows, "kind": "port": this restatement over a resident
+// sample cut into the driver's rows of `chunk` paths (250, src/core/PredictionGen.cpp:719), one call per row under
+// `omp parallel for schedule(dynamic)` (:542-546).  which = 0: orc_lsm_price (LSMPricer.cpp:19-102), 1:
+// orc_martingale_price (MartingaleOptimizationPricer.cpp:21-189, 5 iterations).  paths: row-major [n_total][m].
+int orc_pricer_chunks_omp(int which, const double* row_major, long n_total, int m, int chunk, double r, double K,
+                          double maturity, double dt, int is_call, int poly_order, double* seconds, double* checksum) {
+    const long n_chunks = n_total / chunk;
+    double acc = 0.0;
+    int threads = 1;
+#ifdef _OPENMP
+    threads = omp_get_max_threads();
+    const double t0 = omp_get_wtime();
+#endif
+#pragma omp parallel for schedule(dynamic) reduction(+ : acc)
+    for (long c = 0; c < n_chunks; ++c) {
+        const double* p = row_major + (size_t)c * chunk * m;
+        double v = 0.0, lo = 0.0, up = 0.0;
+        const int rc = which == 0 ? orc_lsm_price(p, (size_t)m, 1, chunk, m, r, K, maturity, dt, is_call, poly_order, &v, nullptr)
+                                  : orc_martingale_price(p, (size_t)m, 1, chunk, m, r, K, maturity, dt, is_call, poly_order, 5, &v, &lo, &up);
+        if (rc == 0) acc += v;
+    }
+#ifdef _OPENMP
+    *seconds = omp_get_wtime() - t0;
+#else
+    *seconds = 0.0;
+#endif
+    *checksum = acc;
+    return threads;
+}
+
 int orc_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

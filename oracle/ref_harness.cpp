@@ -327,4 +327,112 @@ int ref_branching_price(const double* row_major, long n, int m, double r, double
     }
 }
 
+// ---- CPU baselines of bench.py's widened rows, timed the way the reference's driver runs its pricers:
+// `#pragma omp parallel for schedule(dynamic)` over option rows, 250 paths per row (src/core/PredictionGen.cpp:542-546,
+// :719), every pricer a fresh object per row (:566-570), the pricers' own parallel loops nested and therefore serial.
+
+// One pricer of the compiled reference over a resident sample: the [n_total][m] matrix is cut into rows of `chunk` paths
+// (built as vector<vector<double>> BEFORE the clock starts: in the driver they come out of the generator like that), each
+// priced by one PredictOptionPrice call.  which = 0: AsymptoticAnalysis (AsymptoticAnalysisPricer.cpp:38-113), 1:
+// BranchingProcesses (BranchingProcessPricer.cpp:12-134; exercise times 0..m-2 as :780-783).  seconds = wall time of the
+// parallel loop, checksum = sum of the prices.  Returns the number of threads.
+int ref_pricer_chunks_omp(int which, const double* row_major, long n_total, int m, int chunk, double r, double strike,
+                          double maturity, double dt, int is_call, double sigma, double dividend, int num_branches,
+                          double* seconds, double* checksum) {
+    const long n_chunks = n_total / chunk;
+    std::vector<std::vector<std::vector<double>>> rows((size_t)n_chunks);
+    for (long c = 0; c < n_chunks; ++c) {
+        rows[c].resize((size_t)chunk);
+        for (int i = 0; i < chunk; ++i) {
+            const double* src = row_major + ((size_t)c * chunk + i) * m;
+            rows[c][i].assign(src, src + m);
+        }
+    }
+    std::vector<int> times((size_t)std::max(m - 1, 0));
+    for (int i = 0; i + 1 < m; ++i) times[i] = i;
+    double acc = 0.0;
+    int threads = 1;
+#ifdef _OPENMP
+    threads = omp_get_max_threads();
+    const double t0 = omp_get_wtime();
+#endif
+#pragma omp parallel for schedule(dynamic) reduction(+ : acc)
+    for (long c = 0; c < n_chunks; ++c) {
+        try {
+            if (which == 0) {
+                AsymptoticAnalysis aa;
+                acc += aa.PredictOptionPrice(rows[c], r, strike, maturity, dt, is_call != 0, sigma, dividend);
+            } else {
+                BranchingProcesses bp;
+                acc += bp.PredictOptionPrice(rows[c], r, strike, maturity, dt, is_call != 0, num_branches, times);
+            }
+        } catch (const std::exception&) {
+        }
+    }
+#ifdef _OPENMP
+    *seconds = omp_get_wtime() - t0;
+#else
+    *seconds = 0.0;
+#endif
+    *checksum = acc;
+    return threads;
+}
+
+// Whole driver rows (PredictionGen.cpp:719-791): GenerateStockPricePaths(hist, steps, paths_per_row), the finiteness scan,
+// then the four pricers.  AsymptoticAnalysis and BranchingProcesses are the compiled reference; LSMPricer.cpp and
+// MartingaleOptimizationPricer.cpp need Eigen and cannot be built here, so those two calls go through `lsm` / `mart`:
+// pointers to the repo's CPU restatement (orc_lsm_price / orc_martingale_price in oracle/libmcgoracle.so), fed the row's
+// matrix flattened.  seconds = wall time of the parallel loop, sums4 = sum of each pricer's price over the rows.
+typedef int (*lsm_fn_t)(const double*, size_t, size_t, long, int, double, double, double, double, int, int, double*, double*);
+typedef int (*mart_fn_t)(const double*, size_t, size_t, long, int, double, double, double, double, int, int, int, double*, double*, double*);
+int ref_driver_rows_omp(const double* hist, size_t n, const int* steps, const double* strike, const int* is_call, long n_rows,
+                        int paths_per_row, double sigma, double dividend, void* lsm, void* mart, double* seconds, double* sums4) {
+    std::vector<double> h(hist, hist + n);
+    const lsm_fn_t lsm_price = (lsm_fn_t)lsm;
+    const mart_fn_t mart_price = (mart_fn_t)mart;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int threads = 1;
+#ifdef _OPENMP
+    threads = omp_get_max_threads();
+    const double t0 = omp_get_wtime();
+#endif
+#pragma omp parallel for schedule(dynamic) reduction(+ : a0, a1, a2, a3)
+    for (long row = 0; row < n_rows; ++row) {
+        const int st = steps[row];
+        const double r = 0.04, dt = 1.0 / 252.0, maturity = st / 252.0;   // (:700-702)
+        try {
+            RoughVolatility rv;
+            AsymptoticAnalysis aa;
+            BranchingProcesses bp;
+            auto paths = rv.GenerateStockPricePaths(h, st, paths_per_row);
+            bool valid = !paths.empty();
+            for (const auto& p : paths)
+                for (double px : p) valid = valid && std::isfinite(px);
+            if (!valid) continue;
+            std::vector<int> times((size_t)st);
+            for (int i = 0; i < st; ++i) times[i] = i;
+            a0 += aa.PredictOptionPrice(paths, r, strike[row], maturity, dt, is_call[row] != 0, sigma, dividend);
+            a1 += bp.PredictOptionPrice(paths, r, strike[row], maturity, dt, is_call[row] != 0, 10, times);
+            if (lsm_price && mart_price) {
+                std::vector<double> flat((size_t)paths_per_row * (st + 1));
+                for (int i = 0; i < paths_per_row; ++i) std::copy(paths[i].begin(), paths[i].end(), flat.begin() + (size_t)i * (st + 1));
+                double v = 0.0, lo = 0.0, up = 0.0;
+                if (lsm_price(flat.data(), (size_t)(st + 1), 1, paths_per_row, st + 1, r, strike[row], maturity, dt, is_call[row], 2, &v, nullptr) == 0) a2 += v;
+                if (mart_price(flat.data(), (size_t)(st + 1), 1, paths_per_row, st + 1, r, strike[row], maturity, dt, is_call[row], 2, 5, &v, &lo, &up) == 0) a3 += v;
+            }
+        } catch (const std::exception&) {
+        }
+    }
+#ifdef _OPENMP
+    *seconds = omp_get_wtime() - t0;
+#else
+    *seconds = 0.0;
+#endif
+    sums4[0] = a0;
+    sums4[1] = a1;
+    sums4[2] = a2;
+    sums4[3] = a3;
+    return threads;
+}
+
 }  // extern "C"

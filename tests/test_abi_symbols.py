@@ -12,8 +12,8 @@ from montecarlooptionspricer_amd import _native
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared():
-    src = open(os.path.join(ROOT, "include", "mcgpu.h")).read()
+def _declared(header="mcgpu.h"):
+    src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     names = set(re.findall(r"\b(mcg_[a-z0-9_]+)\s*\(", src))
     names.discard("mcg_allreduce_fn")
@@ -26,6 +26,16 @@ def test_every_declared_symbol_is_exported():
     assert len(names) >= 25
     missing = [n for n in names if not hasattr(L, n)]
     assert not missing, missing
+
+
+def test_the_drop_in_header_holds_the_product_abi_only():
+    """include/mcgpu.h is what a maintainer of the reference binds: no test hook in it.  The mcg_debug_* hooks live in
+    include/mcgpu_debug.h (same library; every one of them exported too)."""
+    L = mc.load_library()
+    assert not [n for n in _declared() if n.startswith("mcg_debug_")]
+    hooks = _declared("mcgpu_debug.h")
+    assert len(hooks) >= 9 and all(n.startswith("mcg_debug_") for n in hooks), hooks
+    assert not [n for n in hooks if not hasattr(L, n)]
 
 
 def test_version_and_error_channel():

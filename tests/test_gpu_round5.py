@@ -1,0 +1,75 @@
+"""Round 5 (run with -m gpu on an MI355X): Longstaff-Schwartz against the oracle ELEMENT-WISE AT BASELINE.json's sizes --
+C3's million paths through the register-resident one-launch sweep, and eight million rBergomi paths (the C5 shard's
+count) through the streaming one-launch sweep -- where rounds 1-4 compared at <= 20 000 paths and checked the large shapes
+through properties (missing #4).  Reference: src/models/LSMPricer.cpp:19-102."""
+import numpy as np
+import pytest
+
+import montecarlooptionspricer_amd as mc
+from montecarlooptionspricer_amd import _native as N
+from oracle.binding import Oracle
+
+pytestmark = pytest.mark.gpu
+
+SEED, DT = 20251031, 1.0 / 252.0
+RB = dict(S0=100.0, r=0.04, xi=0.04, H=0.1, eta=1.9, rho=-0.9)
+
+
+@pytest.fixture()
+def eng():
+    e = mc.PathEngine(0)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def orc():
+    return Oracle()
+
+
+def _one_launch_sweeps(eng):
+    ms, n = eng.timing_get(N.K_LSM_SWEEP)
+    return n
+
+
+def test_c3_full_size_matches_oracle(eng, orc):
+    """BASELINE.json configs[2] at full size, the variant bench.py times: 1M GBM paths x 50 exercise dates, order 2, ONE launch
+    (k_lsm_coop: every path's value in a register for the whole sweep).  The device matrix is downloaded and priced by the
+    oracle's restatement of LSMPricer.cpp:42-95 (min-norm least squares by Jacobi SVD on up to 1M x 3 per date): 1e-8."""
+    P = eng.gbm(SEED, 100.0, 0.04, 0.2, 0.02, 50, 1_000_000)
+    eng.timing_enable(True)
+    eng.timing_reset()
+    got, se = eng.price_lsm(P, 0.04, 100.0, 1.0, 0.02, False, 2)
+    assert eng.lsm_one_launch_enabled() and _one_launch_sweeps(eng) == 1
+    eng.timing_enable(False)
+    S = P.to_host_step_major()
+    P.free()
+    assert S.shape == (51, 1_000_000)
+    want = orc.lsm_price(S, 0.04, 100.0, 1.0, 0.02, False, 2)
+    assert abs(got - want) <= 1e-8 * want, (got, want)
+    assert 6.0 < got < 7.0 and 0 < se < 0.01
+
+
+def test_c5_shard_size_last_dates_match_oracle(eng, orc):
+    """The C5 shard's eight million rBergomi paths (H = 0.1, eta = 1.9, 252 steps) through the streaming one-launch sweep
+    (k_lsm_big: rows through the LDS ring, beyond 2.09M paths) against the oracle on the SAME numbers.  The oracle's
+    sweep over all 252 dates of 8M paths would take minutes, so the comparison runs on the matrix's last nine rows (steps
+    244..252: the dates whose in-the-money sets are widest) as an eight-date problem of its own -- uploaded again through
+    mcg_paths_from_host, priced by the device and by the oracle: 1e-8."""
+    n = 8_000_000
+    P = eng.rbergomi(SEED, RB["S0"], RB["r"], RB["xi"], RB["H"], RB["eta"], RB["rho"], DT, 252, n)
+    S = P.to_host_step_major()
+    P.free()
+    tail = np.ascontiguousarray(S[-9:])              # step-major [9][n]
+    del S
+    assert tail.shape == (9, n) and np.isfinite(tail).all()
+    Q = eng.from_host(np.ascontiguousarray(tail.T))  # the class API's layout: [n][9]
+    eng.timing_enable(True)
+    eng.timing_reset()
+    got, se = eng.price_lsm(Q, RB["r"], 100.0, 8 * DT, DT, False, 2)
+    assert eng.lsm_one_launch_enabled() and _one_launch_sweeps(eng) == 1
+    eng.timing_enable(False)
+    Q.free()
+    want = orc.lsm_price(tail, RB["r"], 100.0, 8 * DT, DT, False, 2)
+    assert abs(got - want) <= 1e-8 * want, (got, want)
+    assert got > 0 and se > 0

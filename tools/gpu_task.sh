@@ -5,7 +5,9 @@
 #   suite      the whole GPU test suite (one process), slowest tests listed
 #   tests K    pytest -m gpu -k "K"
 #   bench      the driver's default line (bench.py, N = 1) -> <tag>_bench.json
-#   limiter    PMC passes that attribute the headline kernel's non-issue cycles (tools/pmc_passes.py, C2 command)
+#   limiter    PMC passes that attribute the headline kernel's non-issue cycles (tools/pmc_passes.py, C2 command).  No TA_*
+#              counters: a pass with TA_TA_BUSY_sum / TA_*_STALLED_BY_TC_CYCLES_sum never returned on this pool (r5a: killed
+#              by the pass time-out after 240 s; the SQ passes before it take 2 s each)
 #   stats      rocprofv3 --kernel-trace --stats of the default bench -> <tag>_stats/
 #   ab A B [configs] [reps]   tools/ab_libs.sh between two built libraries
 #   two-rank   bench.py with two ranks sharing the card (gloo), inline / child / off C5 rows
@@ -30,7 +32,6 @@ limiter)
     --group "SQ_INST_CYCLES_VMEM_WR SQ_INST_CYCLES_SALU SQ_INST_CYCLES_SMEM SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS GRBM_GUI_ACTIVE" \
     --group "SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_VMEM_WR_TA_DATA_FIFO_FULL SQ_INST_LEVEL_VMEM SQ_LEVEL_WAVES SQ_IFETCH SQ_IFETCH_LEVEL GRBM_GUI_ACTIVE" \
     --group "SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_BRANCH SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE" \
-    --group "TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_FLAT_WRITE_WAVEFRONTS_sum GRBM_GUI_ACTIVE" \
     --group "TCP_PENDING_STALL_CYCLES_sum TCP_WRITE_TAGCONFLICT_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum TCP_TCC_WRITE_REQ_sum GRBM_GUI_ACTIVE" \
     --group "TCP_GATE_EN1_sum TCP_GATE_EN2_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_TCC_WRITE_REQ_LATENCY_sum GRBM_GUI_ACTIVE" \
     --group "TCC_BUSY_sum TCC_CYCLE_sum TCC_WRITE_sum TCC_REQ_sum GRBM_GUI_ACTIVE" \
