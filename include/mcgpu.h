@@ -101,7 +101,11 @@ int mcg_comm_init_shm(mcg_ctx* ctx, const char* name, int n_ranks, int rank);
  * reducing workgroup then PUSHES its moments into every peer's mailbox and polls local memory only.  Taken into use
  * only if every rank got through allocation, export, open and an in-kernel ping over the mappings; otherwise all
  * ranks stay on the host mailbox together (status MCG_OK, *active = 0).  enable = 0 goes back to the host mailbox.
- * The host segment keeps serving the barrier, the flags and the host all-reduce. */
+ * The host segment keeps serving the barrier, the flags and the host all-reduce.
+ * Lifetime: a rank's mailbox outlives every peer that maps it.  Between processes the IPC mapping sees to that by itself;
+ * rank THREADS of one process use the owner's pointer as it stands, so the library counts them in the segment and a rank
+ * that finalises (or switches back) waits up to 5 s for its borrowers to let go before it frees the mailbox -- and keeps it
+ * allocated if one never does.  Finalise the ranks of a job together, as one would leave any collective. */
 int mcg_comm_shm_peer_mailbox(mcg_ctx* ctx, int enable, int* active);
 
 /* What collective this ctx holds and how many ranks it has SEEN: kind 0 none, 1 callback (mcg_set_allreduce),
@@ -204,7 +208,9 @@ typedef struct mcg_row {
  * then AsymptoticAnalysis, BranchingProcesses(num_branches, exercise dates 0..n_steps-1), LSM(poly_order) and
  * MartingaleOptimization(poly_order, max_iterations) on them.  out[4*i + {0,1,2,3}] = the four prices of row i
  * in the driver's column order (asymPrice, branchPrice, lsmPriceVal, martinPrice, :809-814).  Rows the driver
- * would answer with zeros (no steps, degenerate estimates, sigma <= 0, strike <= 0) get zeros.
+ * would answer with zeros (no steps, degenerate estimates, sigma <= 0, strike <= 0, an inf / nan among the row's generated
+ * paths: :739-777 -- the row kernels scan every row's block for it) get zeros; every other row gets what its pricers
+ * returned, finite or not (:809-816).
  * Row i uses Philox path ids (i << 32) + p of `seed`: its prices equal the single-contract entry points
  * called with path_begin = i << 32 -- and a row of more than 1020 steps (four years of trading days) IS priced through
  * them, after the batch, one row at a time -- as is every row of a call with n_paths > 256 or poly_order > 4 (the row
@@ -284,9 +290,13 @@ int mcg_timing_get(mcg_ctx* ctx, int kernel /* enum mcg_kernel */, double* total
  * adjacent paths per lane, one nontemporal 16-byte store per step, rows n_paths apart).  The ceiling the generator's
  * achieved GB/s is set against, measured in the same process on the same board (boards differ by ~10 %). */
 int mcg_probe_write_ceiling(mcg_ctx* ctx, int64_t n_paths, int n_steps, int reps, double* gb_per_s, double* ms_per_launch);
-/* Shader clock of the most recent GBM generator launch on this ctx, stamped inside the kernel by a few workgroups spread
- * over the grid (s_memtime / s_memrealtime around each one's whole life): median in GHz, number of stamps, and the
- * lowest / highest.  The generator is power-limited; its clock under load is what separates two boards. */
+/* Shader clock of a GBM generator launch, stamped inside the kernel by a few workgroups spread over the grid (s_memtime /
+ * s_memrealtime around each one's whole life).  A measurement aid, OFF by default: mcg_generator_clock_arm(ctx, 1) makes the
+ * NEXT launches of the GBM generator on this ctx stamp (one memset of the 1 KiB stamp buffer ahead of each, a few scalar
+ * reads in ~40 workgroups), ..._arm(ctx, 0) ends it; launches that are not armed pass no stamp buffer and queue nothing
+ * extra.  mcg_generator_clock returns the median in GHz, the number of stamps (0: the last launch was not armed, or too
+ * small to stamp) and the lowest / highest.  The generator is power-limited; its clock under load is what separates boards. */
+int mcg_generator_clock_arm(mcg_ctx* ctx, int on);
 int mcg_generator_clock(mcg_ctx* ctx, double* ghz_median, int* n_stamps, double* ghz_min, double* ghz_max);
 
 /* Process-wide event counters (all contexts, all threads): what ran and what fell back. */

@@ -102,6 +102,7 @@ def load_library():
     newer("mcg_debug_batch_budget", [vp, C.c_size_t])
     newer("mcg_debug_peer_decision", [C.c_int] * 4)
     newer("mcg_probe_write_ceiling", [vp, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)])
+    newer("mcg_generator_clock_arm", [vp, C.c_int])
     newer("mcg_generator_clock", [vp, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)])
     newer("mcg_row_features", [C.POINTER(C.c_double), C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_double)])
     newer("mcg_row_build", [C.POINTER(C.c_double), C.c_size_t, C.c_double, C.c_double, C.c_double, C.c_int, C.c_double,

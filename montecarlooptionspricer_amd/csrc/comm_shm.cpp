@@ -60,6 +60,13 @@ struct ShmHeader {
     // cannot be opened by the process that exported it, and need not be -- the owner's pointer is valid in the peer as it
     // stands (one address space), peer access between the two devices is all it takes
     uint64_t owner_pid[SHM_MAX_RANKS], owner_ptr[SHM_MAX_RANKS];
+    // "the same process" = the same pid AND the same per-process random token (two containers sharing /dev/shm can hold
+    // equal pids; a foreign pointer must never be dereferenced)
+    uint64_t owner_token[SHM_MAX_RANKS];
+    // ranks that currently hold rank r's OWN pointer (same-process borrowers).  An IPC mapping keeps the owner's memory
+    // alive until every opener has closed it; a borrowed pointer does not -- so the owner frees its mailbox only once
+    // this count is back at zero (peer_release), and leaks it rather than free it under a borrower that never lets go.
+    std::atomic<uint32_t> borrowers[SHM_MAX_RANKS];
 };
 static_assert(sizeof(ShmHeader) % 64 == 0, "mailbox starts cache-line aligned");
 static_assert(sizeof(hipIpcMemHandle_t) <= 64, "IPC handle fits its slot");
@@ -87,7 +94,15 @@ struct ShmComm {
 
 namespace {
 
-constexpr uint32_t SHM_MAGIC = 0x4D434755u;  // "MCGU" (layout of round 4)
+constexpr uint32_t SHM_MAGIC = 0x4D434756u;  // "MCGV" (layout of round 5: owner_token, borrowers)
+
+uint64_t process_token() {  // one random word per process, never written anywhere but into the segment's owner_token
+    static const uint64_t t = [] {
+        std::random_device rd;
+        return (((uint64_t)rd() << 32) ^ (uint64_t)rd()) | 1ull;
+    }();
+    return t;
+}
 constexpr int SHM_FLAG_SLOT = 63;            // entry of a rank's host slot row that carries shm_sum_flag's integer
 
 size_t mailbox_bytes() { return (size_t)SHM_MAX_ROUNDS * SHM_MAX_RANKS * SHM_ROW_DOUBLES * sizeof(double); }
@@ -338,11 +353,22 @@ bool peer_map_allowed(bool same_process, bool bus_id_resolves, bool same_device,
 
 static void peer_release(ShmComm* c) {
     for (int r = 0; r < SHM_MAX_RANKS; ++r) {
-        if (c->peer_map[r] && r != c->rank && !c->peer_borrowed[r]) (void)hipIpcCloseMemHandle(c->peer_map[r]);
+        if (c->peer_map[r] && r != c->rank) {
+            if (c->peer_borrowed[r]) c->hdr->borrowers[r].fetch_sub(1, std::memory_order_acq_rel);  // (our kernels are done: callers synchronise the stream first)
+            else (void)hipIpcCloseMemHandle(c->peer_map[r]);
+        }
         c->peer_map[r] = nullptr;
         c->peer_borrowed[r] = false;
     }
-    if (c->peer_own) (void)hipFree(c->peer_own);
+    if (c->peer_own) {
+        // Same-process rank threads hold this pointer as it stands.  Lifetime rule (mcgpu.h, mcg_comm_init_shm): a rank's
+        // mailbox outlives every peer that maps it -- enforced here: wait (bounded) for the borrowers to let go, and if one
+        // never does, keep the megabyte allocated rather than free memory a peer's sweep or ping may still store into.
+        const auto t0 = std::chrono::steady_clock::now();
+        while (c->hdr->borrowers[c->rank].load(std::memory_order_acquire) != 0 && since(t0) < 5.0) sched_yield();
+        if (c->hdr->borrowers[c->rank].load(std::memory_order_acquire) == 0) (void)hipFree(c->peer_own);
+        else std::fprintf(stderr, "mcgpu: rank %d's peer mailbox is still borrowed by a rank thread after 5 s; not freed\n", c->rank);
+    }
     c->peer_own = nullptr;
     c->peer_active = false;
 }
@@ -354,6 +380,7 @@ void shm_release(mcg_ctx* ctx) {
         ctx->allreduce = nullptr;
         ctx->allreduce_user = nullptr;
     }
+    if (c->registered) (void)hipStreamSynchronize(ctx->stream);  // (this rank's own pushes into borrowed mailboxes are over)
     peer_release(c);
     if (c->registered) (void)hipHostUnregister(c->base);
     if (c->pinned) (void)hipHostFree(c->pinned);
@@ -452,6 +479,7 @@ extern "C" int mcg_comm_shm_peer_mailbox(mcg_ctx* ctx, int enable, int* active) 
                 c->hdr->pci_bus_id[c->rank][0] = 0;
             }
             c->hdr->owner_pid[c->rank] = (uint64_t)getpid();
+            c->hdr->owner_token[c->rank] = process_token();
             c->hdr->owner_ptr[c->rank] = (uint64_t)(uintptr_t)p;
             c->peer_own = (double*)p;
             c->peer_memory_kind = names[k];
@@ -472,7 +500,7 @@ extern "C" int mcg_comm_shm_peer_mailbox(mcg_ctx* ctx, int enable, int* active) 
     c->peer_map[c->rank] = c->peer_own;
     for (int r = 0; r < c->n_ranks && ok; ++r) {
         if (r == c->rank) continue;
-        const bool same_process = c->hdr->owner_pid[r] == (uint64_t)getpid();
+        const bool same_process = c->hdr->owner_pid[r] == (uint64_t)getpid() && c->hdr->owner_token[r] == process_token();
         int peer_dev = -1, can = 0;
         const bool resolves = c->hdr->pci_bus_id[r][0] && hipDeviceGetByPCIBusId(&peer_dev, c->hdr->pci_bus_id[r]) == hipSuccess;
         if (!resolves) (void)hipGetLastError();
@@ -494,6 +522,7 @@ extern "C" int mcg_comm_shm_peer_mailbox(mcg_ctx* ctx, int enable, int* active) 
             if (ok) {
                 c->peer_map[r] = (double*)(uintptr_t)c->hdr->owner_ptr[r];
                 c->peer_borrowed[r] = true;
+                c->hdr->borrowers[r].fetch_add(1, std::memory_order_acq_rel);
             }
             continue;
         }

@@ -48,6 +48,7 @@ struct BatchArgs {
     double* S;      // the rows' matrix blocks (BatchRow::off)
     const double2* log_tab;
     double* out;    // [n_rows][4]: asymptotic, branching, lsm, martingale (chunk-local row order)
+    double* bad;    // [n_rows]: != 0 when the row's path block holds a non-finite price (the driver zeroes such a row, PredictionGen.cpp:752-777)
     int num_branches, max_iterations;
 };
 
@@ -238,13 +239,20 @@ __global__ __launch_bounds__(256) void k_batch_branching(BatchArgs a) {
     // run = F[j][p] = max_{k >= j, k < n_dates} disc_k payoff_k, floored at 0; start at j = n_cols - 1 (the last column,
     // which is no exercise date of the driver's list but counts as a later column)
     double run = 0.0;
+    // This walk reads EVERY column of the row's block once: it also answers the driver's scan for inf / nan in the paths
+    // (PredictionGen.cpp:752-777), which sends a row to ",0,0,0,0,0,0" before any pricer sees it.
+    bool finite = true;
     {
         const int j = n_cols - 1;
-        if (j < n_dates) run = fmax(run, dsc[j] * payoff_of(call, col[(int64_t)j * BATCH_LD], row.strike));
+        const double s_last = col[(int64_t)j * BATCH_LD];
+        finite = isfinite(s_last);
+        if (j < n_dates) run = fmax(run, dsc[j] * payoff_of(call, s_last, row.strike));
     }
     double lower = 0.0, upper = 0.0;
     for (int e = row.n_steps - 1; e >= 0; --e) {  // exercise date index == column index; run == F[e+1][p] here
-        const double now = dsc[e] * payoff_of(call, col[(int64_t)e * BATCH_LD], row.strike);
+        const double s_e = col[(int64_t)e * BATCH_LD];
+        finite = finite && isfinite(s_e);
+        const double now = dsc[e] * payoff_of(call, s_e, row.strike);
         const bool is_date = !(e * a.dt > row.maturity);  // (:94-96: the reference stops at the first date beyond maturity)
         double* mine = frow[e & 1];
         mine[p] = run;
@@ -268,6 +276,7 @@ __global__ __launch_bounds__(256) void k_batch_branching(BatchArgs a) {
         }
         if (e < n_dates && now > run) run = now;
     }
+    if (live && !finite) a.bad[blockIdx.x] = 1.0;  // (any number of threads may say so)
     double v[2] = {live ? lower : 0.0, live ? upper : 0.0};
     block_sum<2, 4>(v, red);
     if (threadIdx.x == 0) a.out[4 * (int64_t)blockIdx.x + 1] = 0.5 * (v[0] + v[1]) / (double)a.n_paths;
@@ -412,7 +421,7 @@ namespace {
 
 // Device workspace one row needs in a chunk: its matrix block, its amplitudes + compensator, its image and its four prices.
 size_t row_workspace_bytes(int n_steps, int M) {
-    return ((size_t)BATCH_LD * (size_t)(n_steps + 1) + (size_t)M + (size_t)n_steps + 4) * sizeof(double) + sizeof(BatchRow);
+    return ((size_t)BATCH_LD * (size_t)(n_steps + 1) + (size_t)M + (size_t)n_steps + 5) * sizeof(double) + sizeof(BatchRow);
 }
 
 // LDS class of a row: the row kernels' dynamic LDS is sized by the longest row of a LAUNCH, so the rare long rows (Mz >= 256:
@@ -423,7 +432,8 @@ constexpr int N_LDS_CLASSES = 4;
 }  // namespace
 
 // The six launches for ONE chunk of rows (h: their device images, already with offsets); prices into out[4 * h[k].id ...].
-static int run_batch_chunk(mcg_ctx* ctx, std::vector<BatchRow>& h, BatchArgs a, double* d_S, double* d_small, int poly_order, double* out) {
+static int run_batch_chunk(mcg_ctx* ctx, std::vector<BatchRow>& h, BatchArgs a, double* d_S, double* d_small, int poly_order, double* out,
+                           unsigned char* priced) {
     const int64_t n = (int64_t)h.size();
     int max_steps = 1, m_max = 1;
     int64_t off = 0, woff = 0;
@@ -437,13 +447,14 @@ static int run_batch_chunk(mcg_ctx* ctx, std::vector<BatchRow>& h, BatchArgs a, 
     }
     a.S = d_S;
     a.out = d_small;
-    a.w = d_small + 4 * n;
+    a.bad = d_small + 4 * n;
+    a.w = d_small + 5 * n;
     a.rows = reinterpret_cast<const BatchRow*>(a.w + woff + (woff & 1));
     a.n_rows = n;
     a.max_steps = max_steps;
     a.m_max = m_max;
     hipError_t e = hipMemcpyAsync((void*)a.rows, h.data(), sizeof(BatchRow) * (size_t)n, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(a.out, 0, 4 * sizeof(double) * (size_t)n, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(a.out, 0, 5 * sizeof(double) * (size_t)n, ctx->stream);  // (prices and the rows' flags)
     if (e != hipSuccess) return fail(MCG_ERR_HIP, "batch upload failed: %s", hipGetErrorString(e));
     const int mphi_max = 2 * m_max >= 2 ? 2 * m_max : 2;
     const size_t smem_w = ((size_t)2 * mphi_max + (size_t)max_steps + 1 + (size_t)m_max) * sizeof(double);
@@ -472,12 +483,16 @@ static int run_batch_chunk(mcg_ctx* ctx, std::vector<BatchRow>& h, BatchArgs a, 
         }
     }
     e = hipGetLastError();
-    std::vector<double> four((size_t)n * 4);
-    if (e == hipSuccess) e = hipMemcpyAsync(four.data(), a.out, 4 * sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream);
+    std::vector<double> four((size_t)n * 5);
+    if (e == hipSuccess) e = hipMemcpyAsync(four.data(), a.out, 5 * sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // (also: the host vector `h` has outlived its upload)
     if (e != hipSuccess) return fail(MCG_ERR_HIP, "batch run failed: %s", hipGetErrorString(e));
-    for (int64_t k = 0; k < n; ++k)
-        for (int c = 0; c < 4; ++c) out[4 * h[(size_t)k].id + c] = four[(size_t)(4 * k + c)];
+    for (int64_t k = 0; k < n; ++k) {
+        const int64_t i = (int64_t)h[(size_t)k].id;
+        const bool bad = four[(size_t)(4 * n + k)] != 0.0;  // inf / nan among the row's paths: zeros, like the driver (:752-777)
+        for (int c = 0; c < 4; ++c) out[4 * i + c] = bad ? 0.0 : four[(size_t)(4 * k + c)];
+        if (bad && priced) priced[i] = 0;
+    }
     return MCG_OK;
 }
 
@@ -539,7 +554,7 @@ int run_batch_rows(mcg_ctx* ctx, const mcg_row* rows, int64_t n_rows, int n_path
                 ++ch.end;
             }
             const size_t nr = ch.end - ch.begin;
-            ch.doubles_small = 4 * nr + w + 2 + (sizeof(BatchRow) * nr + 7) / 8;
+            ch.doubles_small = 5 * nr + w + 2 + (sizeof(BatchRow) * nr + 7) / 8;
             max_S = std::max(max_S, ch.bytes_S);
             max_small = std::max(max_small, ch.doubles_small);
             plan.push_back(ch);
@@ -595,7 +610,7 @@ int run_batch_rows(mcg_ctx* ctx, const mcg_row* rows, int64_t n_rows, int n_path
                 while (d.M < d.n_steps) d.M <<= 1;
                 h.push_back(d);
             }
-            rc = run_batch_chunk(ctx, h, a, (double*)S, (double*)small, poly_order, out);
+            rc = run_batch_chunk(ctx, h, a, (double*)S, (double*)small, poly_order, out, priced);
             if (rc) break;
             g_stats.batch_chunks.fetch_add(1, std::memory_order_relaxed);
             g_stats.batch_rows.fetch_add((int64_t)h.size(), std::memory_order_relaxed);

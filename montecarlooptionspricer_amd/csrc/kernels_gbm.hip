@@ -311,12 +311,13 @@ int launch_gbm(mcg_ctx* ctx, mcg_paths* P, uint64_t seed, double S0, double r, d
     a.is_call = is_call;
     a.partials = ctx->partials;
     a.log_tab = (const double2*)ctx->log_tab;
-    // shader-clock stamps: one workgroup in every 2^shift, the smallest shift that needs at most GBM_CLK_SLOTS slots
+    // shader-clock stamps (armed launches only, mcg_generator_clock_arm): one workgroup in every 2^shift, the smallest shift
+    // that needs at most GBM_CLK_SLOTS slots
     a.clk = nullptr;
     a.clk_first = 0;
     a.clk_shift = 0;
     ctx->clk_slots_used = 0;
-    if (ctx->clk_stamps && n_blocks >= 64) {
+    if (ctx->clk_armed && ctx->clk_stamps && n_blocks >= 64) {
         unsigned shift = 2;
         while (((n_blocks - 1) >> shift) >= GBM_CLK_SLOTS) ++shift;
         a.clk = ctx->clk_stamps;

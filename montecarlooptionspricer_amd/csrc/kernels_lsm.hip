@@ -1555,9 +1555,10 @@ int run_lsm(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double maturit
     MCG_HIP(hipMemsetD32Async((hipDeviceptr_t)a.partials, (int)LSM_SENTINEL32, 2 * ((size_t)grid + LSM_DATE_MAX_GROUPS) * (size_t)nm, ctx->stream));
 
     // Exactly M launches when no date asks for a re-fit, one more per date that does (orders >= 4: every date with a path
-    // in the money).  The host queues M, reads the state back and queues what is left -- one launch per remaining date,
-    // again and again until the sweep is through (a batch advances the sweep by at least half its launches) -- so no
-    // launch, and sharded no collective, is ever spent on a sweep that is already over.
+    // in the money).  The host queues M, reads the state back and queues what is left -- one launch per remaining date plus
+    // the share of second launches the dates behind it took -- until the sweep is through (a batch advances the sweep by at
+    // least half its launches); at order 2 no launch, and sharded no collective, is spent on a sweep that is already over, at
+    // higher orders at most the few the estimate overshoots by.
     int dates_left = M, progress = 2 * M + 1;  // progress: launches the sweep still needs at least, x 2 (must fall with every batch)
     int64_t batch = M;
     bool first = true;
@@ -1592,9 +1593,17 @@ int run_lsm(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double maturit
         const int half_done = (int)ctx->h_scalars[SC_LSM_STATE + LSM_ST_PHASE] == LSM_PH_REFINED ? 1 : 0;  // its re-fit's moments are in
         if (2 * left - half_done >= progress) return fail(MCG_ERR_HIP, "LSM per-date sweep did not advance (%d dates left)", left);
         progress = 2 * left - half_done;
-        g_stats.lsm_per_date_refits.fetch_add(batch - (dates_left - left), std::memory_order_relaxed);
+        const int64_t dates_done = dates_left - left, second_launches = batch - dates_done;
+        g_stats.lsm_per_date_refits.fetch_add(second_launches, std::memory_order_relaxed);
         dates_left = left;
-        batch = dates_left;  // (a date that is re-fitted takes two: the next read-back tells)
+        // The next batch: one launch per remaining date PLUS as many second launches as the dates just swept took on
+        // average (orders >= 4 re-fit every date with a path in the money: a batch of `left` launches would cover half of
+        // what is left, and the sweep would end after ~log2(M) read-backs, each a host synchronisation and, sharded, one more
+        // collective -- ADVICE r4).  With the ratio carried over the sweep ends after two or three batches; a launch past the
+        // end returns at once (k_lsm_date: j < 0) and is counted with the second launches.  Order 2: the ratio is 0.
+        const int64_t extra = dates_done > 0 && study_switch("MCG_LSM_DATE_ADAPTIVE", 1)
+                                  ? std::min<int64_t>(left, (second_launches * left + dates_done - 1) / dates_done) : 0;
+        batch = dates_left + extra;
     }
 
     {

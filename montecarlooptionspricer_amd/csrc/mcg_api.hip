@@ -618,30 +618,47 @@ int mcg_batch_price_rows(mcg_ctx* ctx, const mcg_row* rows, int64_t n_rows, int 
     if (n_rows > (int64_t)1 << 31) return fail(MCG_ERR_INVALID, "too many rows for one call (row ids are 32 bits of the Philox counter)");
     if (n_rows == 0) return MCG_OK;
     MCG_HIP(hipSetDevice(ctx->device));
-    return run_batch_rows(ctx, rows, n_rows, n_paths, r, dt, num_branches, poly_order, max_iterations, seed, out, nullptr);
+    try {  // (the planner's host vectors: nothing may leave an extern "C" entry point as an exception)
+        return run_batch_rows(ctx, rows, n_rows, n_paths, r, dt, num_branches, poly_order, max_iterations, seed, out, nullptr);
+    } catch (const std::exception& e) {
+        return fail(MCG_ERR_OOM, "mcg_batch_price_rows: %s", e.what());
+    }
 }
 
 int mcg_batch_price_rows6(mcg_ctx* ctx, const mcg_row* rows, const double* features2, int64_t n_rows, int n_paths, double r,
                           double dt, int num_branches, int poly_order, int max_iterations, uint64_t seed, double* out6) {
     if (!ctx || !out6) return fail(MCG_ERR_INVALID, "ctx/out6 is NULL");
     if (n_rows < 0 || (n_rows > 0 && !rows)) return fail(MCG_ERR_INVALID, "bad rows");
-    if (n_rows == 0) return MCG_OK;
-    std::vector<double> four((size_t)n_rows * 4);
-    std::vector<unsigned char> priced((size_t)n_rows);
-    // (the argument checks are mcg_batch_price_rows's)
+    // (the argument checks are mcg_batch_price_rows's -- all of them BEFORE anything is allocated)
     if (n_paths < 1) return fail(MCG_ERR_INVALID, "n_paths must be >= 1 (got %d)", n_paths);
     if (poly_order < 0 || poly_order > 15) return fail(MCG_ERR_INVALID, "poly_order must be in [0,15] (got %d)", poly_order);
     if (max_iterations <= 0) return fail(MCG_ERR_INVALID, "MartingaleOptimization: maxIterations must be positive.");
     if (!(dt > 0.0)) return fail(MCG_ERR_INVALID, "dt must be > 0");
     if (n_rows > (int64_t)1 << 31) return fail(MCG_ERR_INVALID, "too many rows for one call (row ids are 32 bits of the Philox counter)");
+    if (n_rows == 0) return MCG_OK;
+    std::vector<double> four;
+    std::vector<unsigned char> priced;
+    try {  // nothing may leave an extern "C" entry point as an exception
+        four.resize((size_t)n_rows * 4);
+        priced.resize((size_t)n_rows);
+    } catch (const std::exception&) {
+        return fail(MCG_ERR_OOM, "mcg_batch_price_rows6: no host memory for %lld rows", (long long)n_rows);
+    }
     MCG_HIP(hipSetDevice(ctx->device));
-    int rc = run_batch_rows(ctx, rows, n_rows, n_paths, r, dt, num_branches, poly_order, max_iterations, seed, four.data(), priced.data());
+    int rc;
+    try {
+        rc = run_batch_rows(ctx, rows, n_rows, n_paths, r, dt, num_branches, poly_order, max_iterations, seed, four.data(), priced.data());
+    } catch (const std::exception& e) {
+        return fail(MCG_ERR_OOM, "mcg_batch_price_rows6: %s", e.what());
+    }
     if (rc) return rc;
     for (int64_t i = 0; i < n_rows; ++i) {
         const double* p = &four[(size_t)i * 4];
         double* o = out6 + 6 * i;
-        // PredictionGen.cpp:739-805: a row whose paths or pricers fail is written as ",0,0,0,0,0,0" -- features included
-        const bool ok = priced[(size_t)i] && std::isfinite(p[0]) && std::isfinite(p[1]) && std::isfinite(p[2]) && std::isfinite(p[3]);
+        // PredictionGen.cpp:739-805: a row the driver skips, or whose paths hold an inf / nan (the row kernels' scan of the row's
+        // block, run_batch_chunk), is written as ",0,0,0,0,0,0" -- features included; every other row carries what its
+        // pricers returned, finite or not, as the driver prints it (:809-816)
+        const bool ok = priced[(size_t)i] != 0;
         for (int c = 0; c < 4; ++c) o[c] = ok ? p[c] : 0.0;
         o[4] = ok && features2 ? features2[2 * i] : 0.0;
         o[5] = ok && features2 ? features2[2 * i + 1] : 0.0;
@@ -666,6 +683,12 @@ int mcg_probe_write_ceiling(mcg_ctx* ctx, int64_t n_paths, int n_steps, int reps
     if (n_paths < 512 || n_steps < 1 || reps < 1 || reps > 1000) return fail(MCG_ERR_INVALID, "bad probe shape");
     MCG_HIP(hipSetDevice(ctx->device));
     return probe_write_ceiling(ctx, n_paths, n_steps, reps, gb_per_s, ms_per_launch);
+}
+
+int mcg_generator_clock_arm(mcg_ctx* ctx, int on) {
+    if (!ctx) return fail(MCG_ERR_INVALID, "ctx is NULL");
+    ctx->clk_armed = on != 0;
+    return MCG_OK;
 }
 
 int mcg_generator_clock(mcg_ctx* ctx, double* ghz_median, int* n_stamps, double* ghz_min, double* ghz_max) {

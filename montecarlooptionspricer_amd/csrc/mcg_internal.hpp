@@ -96,6 +96,7 @@ struct mcg_ctx {
     size_t lsm_v_cap = 0;
     unsigned long long* clk_stamps = nullptr;  // [GBM_CLK_SLOTS][2] {shader cycles, 100 MHz ticks} of the last GBM launch's stamping workgroups
     int clk_slots_used = 0;
+    bool clk_armed = false;                    // mcg_generator_clock_arm: only armed launches stamp (and pay the memset ahead of them)
     double* log_tab = nullptr;   // device copy of fm::LOG_TAB_HOST + fm::SINCOS_TAB_HOST + fm::EXP2_TAB_HOST (34 KiB), staged to LDS
 
     // collective

@@ -329,8 +329,12 @@ class PathEngine:
         check(self._L.mcg_probe_write_ceiling(self._ctx, int(n_paths), int(n_steps), int(reps), C.byref(g), C.byref(ms)))
         return g.value, ms.value
 
+    def generator_clock_arm(self, on: bool = True) -> None:
+        """The next GBM generator launches stamp their shader clock (off by default; mcg_generator_clock_arm)."""
+        check(self._L.mcg_generator_clock_arm(self._ctx, 1 if on else 0))
+
     def generator_clock(self) -> dict:
-        """Shader clock of the last GBM generator launch, stamped in-kernel (mcg_generator_clock)."""
+        """Shader clock of the last ARMED GBM generator launch, stamped in-kernel (mcg_generator_clock)."""
         med, lo, hi, n = C.c_double(), C.c_double(), C.c_double(), C.c_int()
         check(self._L.mcg_generator_clock(self._ctx, C.byref(med), C.byref(n), C.byref(lo), C.byref(hi)))
         return {"GHz_median": med.value, "GHz_min": lo.value, "GHz_max": hi.value, "stamping_workgroups": n.value}

@@ -171,6 +171,9 @@ class RehearsalEngine:
     def trim(self):
         pass
 
+    def generator_clock_arm(self, on=True):
+        pass
+
     def generator_clock(self):
         return None
 

@@ -199,12 +199,17 @@ def test_write_ceiling_probe_and_in_kernel_clock(eng):
     gbs, ms = eng.probe_write_ceiling(4_000_000, 252, reps=3)
     assert 2500.0 < gbs < 8000.0 and abs(gbs - 8.0 * 253 * 4_000_000 / (ms * 1e-3) / 1e9) < 1e-6 * gbs
     P = eng.gbm(SEED, 100.0, 0.04, 0.2, DT, 252, 4_000_000, payoff=(100.0, True))
+    assert eng.generator_clock()["stamping_workgroups"] == 0      # a measurement aid, off unless armed
+    P.free()
+    eng.generator_clock_arm(True)
+    P = eng.gbm(SEED, 100.0, 0.04, 0.2, DT, 252, 4_000_000, payoff=(100.0, True))
     c = eng.generator_clock()
     P.free()
     assert c["stamping_workgroups"] >= 16 and 0.5 < c["GHz_min"] <= c["GHz_median"] <= c["GHz_max"] < 2.7, c
     tiny = eng.gbm(SEED, 100.0, 0.04, 0.2, DT, 16, 1000)     # too few workgroups to stamp: zeros, not stale values
     assert eng.generator_clock()["stamping_workgroups"] == 0
     tiny.free()
+    eng.generator_clock_arm(False)
 
 
 def test_bench_line_attributes_its_own_variance():

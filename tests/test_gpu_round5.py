@@ -73,3 +73,21 @@ def test_c5_shard_size_last_dates_match_oracle(eng, orc):
     want = orc.lsm_price(tail, RB["r"], 100.0, 8 * DT, DT, False, 2)
     assert abs(got - want) <= 1e-8 * want, (got, want)
     assert got > 0 and se > 0
+
+
+def test_batch_row_with_non_finite_paths_is_zeroed_like_the_driver(eng):
+    """PredictionGen.cpp:752-777: a row whose generated paths hold an inf or a nan is written as ",0,0,0,0,0,0" before any
+    pricer sees it.  The row kernels scan every row's block (the BranchingProcesses walk reads all its columns anyway) and
+    flag such a row: four zeros from mcg_batch_price_rows, six from mcg_batch_price_rows6 -- while its neighbours keep what
+    their pricers returned (a price-finiteness proxy decided this before)."""
+    good = dict(S0=100.0, xi=0.04, H=0.3, eta=0.05, rho=-0.3, strike=100.0, maturity=60 / 252.0, sigma=0.2, dividend=0.08,
+                n_steps=60, is_call=0)
+    huge = dict(good, S0=1.7e308, strike=1.7e308)        # half its paths rise above DBL_MAX within a few steps
+    rows = [good, huge, dict(good, is_call=1)]
+    four = eng.batch_price_rows(rows, seed=5)
+    assert np.all(four[1] == 0.0), four[1]
+    assert np.all(np.isfinite(four[0])) and np.all(four[0] > 0) and np.all(four[2] > 0)
+    alone = eng.batch_price_rows([good], seed=5)
+    assert np.array_equal(alone[0], four[0])              # a flagged neighbour changes nothing
+    six = eng.batch_price_rows(rows, seed=5, features=np.array([[0.2, 0.01]] * 3))
+    assert np.all(six[1] == 0.0) and six[0][4] == 0.2 and six[2][5] == 0.01

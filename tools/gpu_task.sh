@@ -10,6 +10,7 @@
 #              by the pass time-out after 240 s; the SQ passes before it take 2 s each)
 #   stats      rocprofv3 --kernel-trace --stats of the default bench -> <tag>_stats/
 #   ab A B [configs] [reps]   tools/ab_libs.sh between two built libraries
+#   perdate    tools/bench_perdate.py, product against the study build with MCG_LSM_DATE_ADAPTIVE=0
 #   two-rank   bench.py with two ranks sharing the card (gloo), inline / child / off C5 rows
 set -o pipefail
 export TMPDIR=/tmp
@@ -50,5 +51,9 @@ two-rank)
       > $O/${T}_two_rank_$mode.json 2> $O/${T}_two_rank_$mode.err; rc=$?; echo "two-rank $mode rc=$rc"; guard || exit $rc
     head -c 600 $O/${T}_two_rank_$mode.json; echo
   done ;;
+perdate)   # the per-date route's batches at order 5, adaptive (product) against one launch per remaining date (study build)
+  timeout -k 10 300 python3 tools/bench_perdate.py 2>&1 | tee $O/${T}_perdate.log; guard || exit $?
+  export MCG_LIB=$PWD/montecarlooptionspricer_amd/lib/libmcgpu_study.so MCG_LSM_DATE_ADAPTIVE=0
+  timeout -k 10 300 python3 tools/bench_perdate.py 2>&1 | sed 's/^/one-per-date batches: /' | tee -a $O/${T}_perdate.log; guard ;;
 *) echo "unknown task $task"; exit 2 ;;
 esac
