@@ -243,6 +243,141 @@ __global__ __launch_bounds__(256, BR_WGS_PER_CU) void k_branch_date(BranchArgs a
     }
 }
 
+// ONE EXERCISE DATE per launch, rows of MANY slices (round 5; beyond four slices = more than a million paths): the walk
+// over the slices with every index tested in every pass costs a load instruction per index and pass however few lanes
+// take part (4M x 50, 16 slices: 44.7 ms that way, 29.6 in one launch with 8 slices).  Here every thread SORTS its
+// 4 QUADS PPT indices by slice first -- a counting sort into its own column of an LDS array (bins[pos][thread]: no two
+// threads share an entry, no atomics, no barrier), the sixteen counters packed six bits each into two 64-bit registers
+// -- and then walks the slices in order, gathering from its bin exactly the indices that fall into the slice: a pass costs
+// as many load instructions as the fullest bin among the wave's lanes (~9 of 40 entries at sixteen slices) instead of 40,
+// and every lane of the device is still in the same slice or two of the row at a time.  The owner of a gathered value (which
+// of the thread's four paths) rides in the top two bits of the stored index -- rows of up to 2^30 - 2 paths -- and the value
+// is added to that path's sum in the thread's own LDS cell (ds_add_f64 on a private address: program order, deterministic;
+// selecting among PPT register sums costs four compare-select-add groups per gathered value instead).
+// The sum over a path's branches is formed in slice order -- like k_branch_bounds / k_branch_date, not in branch order.
+// What bounds this kernel is how many paths are RESIDENT at a time: every generation of resident workgroups pulls every slice
+// of the row into the L2 of every XCD once (4M x 50: 32 MB x 8 XCDs per generation and date), so the bins hold the
+// num_branches indices a path really has (dynamic LDS, 40 B per path at the driver's 10 branches + 8 B of sum), four paths
+// per thread: 48 KiB per workgroup, three per CU, 786 432 paths per generation (three paths per thread: 38 KiB, 589 824).
+// Three or four paths per thread (run_branching picks per shape: the generation whose LAST launch is fuller -- a nearly
+// empty generation still pulls the whole row through every L2).
+inline size_t brb_lds_bytes(int num_branches, int ppt) { return (size_t)256 * ((size_t)num_branches * ppt * sizeof(uint32_t) + 4 * sizeof(double)); }
+template <int QUADS, int PPT>
+__global__ __launch_bounds__(256, 3) void k_branch_date_binned(BranchArgs a, int64_t p0, int e, double2* state, int first_date,
+                                                               int slice_shift, int n_slices) {
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    static_assert(12 * PPT <= 63 && PPT <= 4, "bin positions are six-bit fields; the owner is two bits");
+    extern __shared__ double brb_lds[];
+    double (*sums)[256] = reinterpret_cast<double (*)[256]>(brb_lds);                // [owner][thread]
+    uint32_t (*bins)[256] = reinterpret_cast<uint32_t (*)[256]>(brb_lds + 4 * 256);  // [pos][thread], pos < num_branches PPT
+    const bool call = a.is_call != 0;
+    const uint32_t n32 = (uint32_t)a.n;
+    const double inv_b = 1.0 / (double)a.num_branches;
+    const int t_idx = a.ex[e];
+    const double* rowS = a.S + (int64_t)t_idx * a.ld;
+    const bool branch = n_slices > 0;  // (no continuation at the list's last date nor at an index on the last column)
+    const double* rowF = a.F + (int64_t)(branch ? t_idx + 1 : t_idx) * a.ld;
+    const double dsc = a.disc[t_idx];
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    const unsigned tid = threadIdx.x;
+    int64_t p[PPT];
+    bool live[PPT];
+    double now[PPT];
+    v2d st[PPT];
+    // six-bit fields: slices 0..9 in lo, 10..15 in hi
+    uint64_t f_lo = 0, f_hi = 0;
+    auto field_shift = [](uint32_t sl) { return 6u * (sl >= 10u ? sl - 10u : sl); };
+    auto bump = [&](uint32_t sl) -> uint32_t {  // returns the field's value, then adds one to it
+        const bool up = sl >= 10u;
+        const uint32_t sh = field_shift(sl);
+        const uint32_t old = (uint32_t)((up ? f_hi : f_lo) >> sh) & 63u;
+        const uint64_t one = 1ull << sh;
+        f_lo += up ? 0ull : one;
+        f_hi += up ? one : 0ull;
+        return old;
+    };
+    uint32_t idx[PPT][4 * QUADS];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) sums[q][tid] = 0.0;
+#pragma unroll
+    for (int q = 0; q < PPT; ++q) {
+        p[q] = p0 + (int64_t)blockIdx.x * 256 + threadIdx.x + q * stride;
+        live[q] = p[q] < a.n;
+        if (!live[q]) p[q] = a.n - 1;
+        st[q] = first_date ? v2d{0.0, 0.0} : __builtin_nontemporal_load(reinterpret_cast<const v2d*>(state) + p[q]);
+        now[q] = dsc * payoff_of(call, __builtin_nontemporal_load(rowS + p[q]), a.K);
+        if (branch) {  // (wave-uniform)
+            const PhiloxLane rng = philox_lane_setup(a.path_begin + (uint64_t)p[q], STREAM_BRANCH, a.k1);
+#pragma unroll
+            for (int k = 0; k < QUADS; ++k) {
+                const Philox4 w = philox4x32_10_lane(rng, (uint32_t)(e * QUADS + k), a.k0, a.k1);
+                const uint32_t ws[4] = {w.w0, w.w1, w.w2, w.w3};
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    idx[q][4 * k + s] = __umulhi(ws[s], n32);
+                    if (4 * k + s < a.num_branches) (void)bump(idx[q][4 * k + s] >> slice_shift);  // count
+                }
+            }
+        }
+    }
+    if (branch) {
+        // counts -> first positions (exclusive prefix over the slices)
+        {
+            uint64_t o_lo = 0, o_hi = 0;
+            uint32_t run = 0;
+#pragma unroll
+            for (uint32_t sl = 0; sl < 16u; ++sl) {
+                const uint32_t sh = field_shift(sl);
+                const uint32_t c = (uint32_t)((sl >= 10u ? f_hi : f_lo) >> sh) & 63u;
+                if (sl >= 10u) o_hi |= (uint64_t)run << sh;
+                else o_lo |= (uint64_t)run << sh;
+                run += c;
+            }
+            f_lo = o_lo;
+            f_hi = o_hi;
+        }
+        // place: afterwards every field holds the END of its slice's bin
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+#pragma unroll
+            for (int b = 0; b < 4 * QUADS; ++b) {
+                if (b < a.num_branches) {
+                    const uint32_t pos = bump(idx[q][b] >> slice_shift);
+                    bins[pos][tid] = idx[q][b] | ((uint32_t)q << 30);
+                }
+            }
+        }
+        // walk the slices; within a slice four entries of the bin per trip (all four loads in flight together).  One thread's
+        // LDS accesses execute in program order: its reads of bins[] see its own writes, its adds to sums[] line up.
+        uint32_t pos = 0;
+#pragma unroll 1
+        for (uint32_t sl = 0; sl < (uint32_t)n_slices; ++sl) {
+            const uint32_t end = (uint32_t)((sl >= 10u ? f_hi : f_lo) >> field_shift(sl)) & 63u;
+            while (__builtin_amdgcn_ballot_w64(pos < end) != 0ull) {
+                uint32_t w[4];
+                double v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) w[u] = pos + u < end ? bins[pos + u][tid] : 0xFFFFFFFFu;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = w[u] != 0xFFFFFFFFu ? rowF[w[u] & 0x3FFFFFFFu] : 0.0;
+#pragma unroll
+                for (int u = 0; u < 4; ++u)  // (an empty entry adds 0.0 to the fourth path's cell)
+                    __hip_atomic_fetch_add(&sums[w[u] >> 30][tid], v[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                pos = pos + 4u < end ? pos + 4u : end;
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < PPT; ++q) {
+        if (!(st[q].x > 0.0) && now[q] > 0.0) st[q].x = now[q];  // :62-65, first positive discounted payoff
+        double better = now[q];
+        const double cont = sums[q][tid] * inv_b;
+        if (branch && cont > better) better = cont;
+        if (better > st[q].y) st[q].y = better;
+        if (live[q]) __builtin_nontemporal_store(st[q], reinterpret_cast<v2d*>(state) + p[q]);
+    }
+}
+
 // sum of {lower, upper} over the paths -> partials[grid][2]
 __global__ __launch_bounds__(256) void k_branch_finish(const double2* state, int64_t n, double* partials) {
     __shared__ double red[2 * 4];
@@ -379,7 +514,51 @@ int run_branching(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double m
     int64_t n_partials = (int64_t)bgrid * n_launches;
     void* state = nullptr;
     size_t state_bytes = 0;
-    if (n_slices > 1 && n_slices <= BR_DATE_MAX_SLICES && quads >= 1 && quads <= 3 && !ex.empty()) {
+    // Rows of more than four slices (more than a million paths), up to 2^30 - 2 paths: per-date launches of the BINNED
+    // kernel (k_branch_date_binned: every thread walks its indices sorted by slice), sixteen slices of >= 2 MB.
+    int bshift = BR_SLICE_SHIFT;
+    while ((((P->n_paths > 0 ? P->n_paths : 1) - 1) >> bshift) + 1 > 16) ++bshift;
+    const int b_slices = (int)((((P->n_paths > 0 ? P->n_paths : 1) - 1) >> bshift) + 1);
+    const bool binned = b_slices > BR_DATE_MAX_SLICES && quads >= 1 && quads <= 3 && !ex.empty() && P->n_paths < ((int64_t)1 << 30) - 1 &&
+                        study_switch("MCG_BRANCH_BINNED", 1) != 0;
+    if (binned) {
+        // Paths per thread: a generation is three resident workgroups per CU of 256 x PPT paths, and a launch that is nearly
+        // empty still walks -- and pulls through every XCD's L2 -- the whole row.  A/B on one board (round 5): 4M x 50
+        // 21.4 ms at three paths per thread (6.8 generations) against 23.4 at four (5.1); 2M x 50 8.76 against 8.12
+        // (3.4 / 2.5 generations).  So: whichever leaves the fuller last generation.
+        const double gen4 = (double)P->n_paths / (double)((int64_t)ctx->n_cus * 3 * 256 * 4), gen3 = (double)P->n_paths / (double)((int64_t)ctx->n_cus * 3 * 256 * 3);
+        const int ppt = std::ceil(gen3) - gen3 < std::ceil(gen4) - gen4 ? 3 : 4;
+        const int64_t per_wg_b = 256 * (int64_t)ppt;
+        const size_t lds_b = brb_lds_bytes(num_branches, ppt);  // <= 56 KiB (twelve branches, four paths); 48 KiB at the driver's ten
+        const int wgs_per_cu = (int)std::min<size_t>(3, ((size_t)160 << 10) / lds_b);
+        const int ggrid = (int)std::max<int64_t>(1, std::min<int64_t>((P->n_paths + per_wg_b - 1) / per_wg_b, (int64_t)ctx->n_cus * wgs_per_cu));
+        typedef void (*BinnedKernel)(BranchArgs, int64_t, int, double2*, int, int, int);
+        static const BinnedKernel kern[3][2] = {{k_branch_date_binned<1, 3>, k_branch_date_binned<1, 4>},
+                                                {k_branch_date_binned<2, 3>, k_branch_date_binned<2, 4>},
+                                                {k_branch_date_binned<3, 3>, k_branch_date_binned<3, 4>}};
+        const BinnedKernel k = kern[quads - 1][ppt - 3];
+        if (lds_b > ((size_t)48 << 10)) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
+        const int64_t per_launch_b = (int64_t)ggrid * per_wg_b;
+        const int64_t n_launches_b = std::max<int64_t>(1, (P->n_paths + per_launch_b - 1) / per_launch_b);
+        state_bytes = (size_t)P->n_paths * sizeof(double2);
+        rc = pool_alloc(ctx, state_bytes, &state);
+        if (rc) {
+            pool_release(ctx, Fbuf, P->bytes);
+            return rc;
+        }
+        {
+            TimedLaunch t(ctx, MCG_K_BRANCHING, (int64_t)ex.size() * n_launches_b + 1);
+            for (int e = 0; e < (int)ex.size(); ++e) {
+                const int t_idx = ex[(size_t)e];
+                const bool branch = t_idx < ex_last && t_idx + 1 < n_cols;
+                const int ns = branch ? b_slices : 0;
+                for (int64_t l = 0; l < n_launches_b; ++l)
+                    hipLaunchKernelGGL(k, dim3(ggrid), dim3(256), lds_b, ctx->stream, a, l * per_launch_b, e, (double2*)state, e == 0, bshift, ns);
+            }
+            hipLaunchKernelGGL(k_branch_finish, dim3(grid), dim3(256), 0, ctx->stream, (const double2*)state, P->n_paths, ctx->partials);
+        }
+        n_partials = grid;
+    } else if (n_slices > 1 && n_slices <= BR_DATE_MAX_SLICES && quads >= 1 && quads <= 3 && !ex.empty()) {
         // Rows of two to four slices: one launch per exercise date, bounds in `state`.  A/B on one board, 1M x 50: 5.55 ms
         // (one launch, no slices) -> 5.25 (one launch, slices: 42 % L2 hits) -> 2.83 (per-date launches).  A pass costs
         // ~40 cycles per wave-load however few lanes take part, so rows of many slices lose what the hits gain (4M x 50,

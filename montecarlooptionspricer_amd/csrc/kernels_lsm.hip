@@ -1599,10 +1599,13 @@ int run_lsm(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double maturit
         // The next batch: one launch per remaining date PLUS as many second launches as the dates just swept took on
         // average (orders >= 4 re-fit every date with a path in the money: a batch of `left` launches would cover half of
         // what is left, and the sweep would end after ~log2(M) read-backs, each a host synchronisation and, sharded, one more
-        // collective -- ADVICE r4).  With the ratio carried over the sweep ends after two or three batches; a launch past the
-        // end returns at once (k_lsm_date: j < 0) and is counted with the second launches.  Order 2: the ratio is 0.
-        const int64_t extra = dates_done > 0 && study_switch("MCG_LSM_DATE_ADAPTIVE", 1)
-                                  ? std::min<int64_t>(left, (second_launches * left + dates_done - 1) / dates_done) : 0;
+        // collective -- ADVICE r4).  With the ratio carried over the sweep ends after three or four batches; should a batch
+        // overshoot, a launch past the end returns at once (k_lsm_date: j < 0) and is counted with the second launches.
+        // Order 2: the ratio is 0.
+        // (rounded DOWN, and only while at least 16 dates are left: the estimate should fall short by a few launches, which
+        //  the next, small batch picks up, rather than overshoot; the last dates go one launch per date as before)
+        const int64_t extra = dates_done > 0 && left >= 16 && study_switch("MCG_LSM_DATE_ADAPTIVE", 1)
+                                  ? std::min<int64_t>(left, second_launches * left / dates_done) : 0;
         batch = dates_left + extra;
     }
 

@@ -307,18 +307,22 @@ def test_eight_rank_threads_equal_single_rank(tmp_path, mode):
     (300_001, 8, 10, "all"),        # 3 slices: one launch per exercise date (k_branch_date<3>)
     (524_289, 6, 7, "sparse"),      # 3 slices, two Philox blocks per path and date, a sparse exercise list
     (300_001, 6, 3, "shuffled"),    # a list that is not ascending: its LAST entry, not its largest, ends the branching
-    (1_100_000, 5, 10, "all"),      # 5 slices: beyond the per-date launches' range, ONE launch that walks the slices
+    (1_100_000, 5, 10, "all"),      # 5 slices: beyond k_branch_date's range -- round 5: k_branch_date_binned (indices sorted by slice per thread)
+    (4_000_001, 4, 10, "all"),      # 16 slices of 2 MB (the shape VERDICT r4 names, fewer dates): binned, six launches per date
+    (1_300_000, 4, 7, "sparse4"),   # binned with two Philox blocks per path and date, a sparse list
+    (2_500_000, 3, 3, "all"),       # binned with one block (three of its four indices used)
     (300_001, 5, 13, "all"),        # more than twelve branches: indices are not kept, no slices
 ])
 def test_branching_rows_beyond_one_slice_match_oracle(n_paths, steps, branches, ex_kind):
-    """k_branch_date / the sliced k_branch_bounds against the oracle in philox mode (the same resampling draws): the
-    slices only change WHEN an index is gathered, and the order in which a path's branch values are summed."""
+    """k_branch_date / k_branch_date_binned / the sliced k_branch_bounds against the oracle in philox mode (the same
+    resampling draws): the slices only change WHEN an index is gathered, and the order in which a path's branch values are
+    summed."""
     from oracle.binding import Oracle
     orc = Oracle()
     e = mc.PathEngine(0)
     P = e.gbm(SEED, 100.0, 0.04, 0.3, DT, steps, n_paths, path_begin=6)
     host = P.to_host_step_major()
-    ex = {"all": np.arange(steps), "sparse": np.array([0, 2, 3, 5]), "shuffled": np.array([4, 1, 5, 0, 2])}[ex_kind].astype(np.int32)
+    ex = {"all": np.arange(steps), "sparse": np.array([0, 2, 3, 5]), "shuffled": np.array([4, 1, 5, 0, 2]), "sparse4": np.array([0, 1, 3])}[ex_kind].astype(np.int32)
     for is_call, maturity in ((False, steps * DT), (True, (steps - 1.5) * DT)):
         got = e.price_branching(P, 0.04, 100.0, maturity, DT, is_call, branches, ex, seed=41)
         want = orc.branching_price(host, 0.04, 100.0, maturity, DT, is_call, branches, ex, 41, mode="philox", path_begin=6)

@@ -6,7 +6,9 @@ sys.path.insert(0,'.')
 import montecarlooptionspricer_amd as mc
 from montecarlooptionspricer_amd import _native as N
 e=mc.PathEngine(0); e.timing_enable(True)
-for n,steps in ((1_000_000,50),(4_000_000,50),(250_000,252)):
+import os
+shapes=[tuple(int(x) for x in s.split("x")) for s in os.environ.get("BRANCH_SHAPES","1000000x50,4000000x50,250000x252").split(",")]
+for n,steps in shapes:
     P=e.gbm(20251031,100.0,0.04,0.2,1.0/steps,steps,n)
     ex=list(range(steps))
     e.price_branching(P,0.04,100.0,1.0,1.0/steps,False,10,ex,7)

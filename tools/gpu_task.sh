@@ -10,6 +10,8 @@
 #              by the pass time-out after 240 s; the SQ passes before it take 2 s each)
 #   stats      rocprofv3 --kernel-trace --stats of the default bench -> <tag>_stats/
 #   ab A B [configs] [reps]   tools/ab_libs.sh between two built libraries
+#   tool / toolstats   a dev tool under tools/ (bench_branching.py, bench_rows.py, ...) plainly / under rocprofv3 --stats
+#   pmc        counter passes (SQ / LDS / TCC / TCP groups) of named kernels under a dev tool
 #   perdate    tools/bench_perdate.py, product against the study build with MCG_LSM_DATE_ADAPTIVE=0
 #   two-rank   bench.py with two ranks sharing the card (gloo), inline / child / off C5 rows
 set -o pipefail
@@ -51,6 +53,26 @@ two-rank)
       > $O/${T}_two_rank_$mode.json 2> $O/${T}_two_rank_$mode.err; rc=$?; echo "two-rank $mode rc=$rc"; guard || exit $rc
     head -c 600 $O/${T}_two_rank_$mode.json; echo
   done ;;
+tool)      # a dev tool under tools/ plainly, its output kept: gpu_task.sh tool <tag> bench_branching.py [args]
+  timeout -k 10 600 python3 tools/"$@" 2>&1 | tee $O/${T}_tool.log; guard ;;
+toolstats) # ... and under rocprofv3 --kernel-trace --stats (the per-kernel table is printed)
+  timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${T}_toolstats -- python3 tools/"$@" > $O/${T}_toolstats.log 2>&1; guard || exit $?
+  python3 - <<PY
+import csv, glob
+f = sorted(glob.glob("$O/${T}_toolstats/*/*kernel_stats.csv"))[-1]
+for r in list(csv.DictReader(open(f)))[:14]:
+    print("%-90s calls %6s  avg %10.1f us  total %9.3f ms" % (r["Name"][:90], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e6))
+PY
+  ;;
+pmc)       # counters of a gather / latency-bound kernel: gpu_task.sh pmc <tag> <kernel substrings> <tool.py> [args]
+  K=$1; shift
+  timeout -k 10 900 python3 tools/pmc_passes.py --tag ${T}_pmc --kernels "$K" \
+    --group "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE" \
+    --group "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_FLAT SQ_INSTS_VMEM_RD SQ_INST_LEVEL_VMEM GRBM_GUI_ACTIVE" \
+    --group "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum GRBM_GUI_ACTIVE" \
+    --group "TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum TCP_TOTAL_CACHE_ACCESSES_sum GRBM_GUI_ACTIVE" \
+    --group "TCC_REQ_sum TCC_READ_sum TCC_BUSY_sum TCC_CYCLE_sum GRBM_GUI_ACTIVE" \
+    -- python3 tools/"$@" 2>&1 | tee $O/${T}_pmc.log; guard ;;
 perdate)   # the per-date route's batches at order 5, adaptive (product) against one launch per remaining date (study build)
   timeout -k 10 300 python3 tools/bench_perdate.py 2>&1 | tee $O/${T}_perdate.log; guard || exit $?
   export MCG_LIB=$PWD/montecarlooptionspricer_amd/lib/libmcgpu_study.so MCG_LSM_DATE_ADAPTIVE=0
