@@ -517,7 +517,33 @@ def c5_rows_mode(args, world: int) -> str:
     return "child" if 2 * world <= GPU_PROCESS_GUARD else "inline"
 
 
-def install_collective(eng, mc, want: str, dist, torch, rank: int, world: int, dev="cuda") -> str:
+def rccl_forms_in_time(make_scratch, rank: int, world: int, bcast, limit_s: float) -> bool:
+    """Form the built-in RCCL communicator on a scratch context in a thread; True iff it formed within limit_s."""
+    import threading
+    box = {}
+
+    def work():
+        try:
+            e = make_scratch()
+            e.init_rccl(rank, world, bcast)
+            box["eng"] = e
+        except Exception as ex:   # noqa: BLE001
+            box["err"] = ex
+    t = threading.Thread(target=work, daemon=True)
+    t.start()
+    t.join(limit_s)
+    if t.is_alive():
+        print(f"bench: rank {rank}: the built-in RCCL communicator did not form within {limit_s:.0f} s; falling back to torch.distributed",
+              file=sys.stderr, flush=True)
+        return False
+    if "err" in box:
+        print(f"bench: built-in RCCL communicator unavailable ({box['err']}); using torch.distributed", file=sys.stderr)
+        return False
+    box["eng"].close()
+    return True
+
+
+def install_collective(eng, mc, want: str, dist, torch, rank: int, world: int, dev="cuda", scratch=None) -> str:
     """Give `eng` the collective `want` ("ipc", "shm", "rccl", "torch") -- every rank ends up on the SAME one: a set-up
     that fails on any rank sends all of them one step down (ipc -> shm -> rccl -> torch).  Returns what is installed.
     No rank can be left alone in a collective: whatever a rank does before a broadcast cannot fail (the segment's name is
@@ -559,10 +585,19 @@ def install_collective(eng, mc, want: str, dist, torch, rank: int, world: int, d
             print(f"bench: librccl unavailable on rank {rank} ({e})", file=sys.stderr)
             ok = False
         if everyone(ok, dist, torch, dev):
-            try:
-                eng.init_rccl(rank, world, bcast)
-            except mc.McgError as e:       # communicator set-up failed on this node: use torch's, and say so
-                print(f"bench: built-in RCCL communicator unavailable ({e}); using torch.distributed", file=sys.stderr)
+            # ncclCommInitRank with more than one rank has never run in this repo's history (every GPU box had one GPU): a
+            # communicator that does not FORM must cost the run its collective, not its line.  So it is formed once on a
+            # scratch context inside a time box; only if every rank's formed in time does the real context get its own.  A
+            # scratch context that is still inside ncclCommInitRank when the box closes is abandoned (daemon thread).
+            ok = rccl_forms_in_time(scratch or (lambda: mc.PathEngine(eng.device)), rank, world, bcast,
+                                    float(os.environ.get("MCG_BENCH_RCCL_INIT_LIMIT", "90")))
+            if everyone(ok, dist, torch, dev):
+                try:
+                    eng.init_rccl(rank, world, bcast)
+                except mc.McgError as e:       # communicator set-up failed on this node: use torch's, and say so
+                    print(f"bench: built-in RCCL communicator unavailable ({e}); using torch.distributed", file=sys.stderr)
+                    ok = False
+            else:
                 ok = False
         else:
             ok = False
@@ -654,7 +689,7 @@ def c5_sharded_rows(args, mc, N, dist, torch, device, stream, rank, world, hw=Gp
             if good:
                 # (install_collective agrees among the ranks inside; an exception there is the same on every rank)
                 st["got"] = "none (every rank prices its own shard alone: a local price, the baseline the routes below add their exchange to)" \
-                    if want == "none" else install_collective(e5, mc, want, dist, torch, rank, world, dev)
+                    if want == "none" else install_collective(e5, mc, want, dist, torch, rank, world, dev, scratch=make_engine)
                 st["info"] = e5.comm_info()
                 st["unbounded"] = st["got"].startswith(("rccl", "torch"))
             good = good and phase(warm) and phase(timed)
@@ -893,7 +928,7 @@ def main() -> None:
         collective = args.collective
         if collective == "auto":   # c5: the in-kernel mailbox in peer memory (xGMI on a node) first; it falls back by itself
             collective = "ipc" if args.config == "c5" else "rccl"
-        collective = install_collective(eng, mc, collective, dist, torch, rank, world, dev_name)
+        collective = install_collective(eng, mc, collective, dist, torch, rank, world, dev_name, scratch=make_engine)
 
     if args.config == "c2":
         k_main = N.K_GBM

@@ -139,6 +139,51 @@ def test_committed_bench_line_has_the_contract_fields():
     assert rows["C5"]["kernels"]["lsm_sweep"]["launches_per_pass"] == 1          # the 8M shard runs the one-launch sweep
 
 
+def _fractions(obj, path=""):
+    """every (path, value) whose key says it is a fraction"""
+    if isinstance(obj, dict):
+        for k, v in obj.items():
+            if isinstance(v, (int, float)) and not isinstance(v, bool) and ("frac" in k):
+                yield f"{path}/{k}", v
+            else:
+                yield from _fractions(v, f"{path}/{k}")
+    elif isinstance(obj, list):
+        for i, v in enumerate(obj):
+            yield from _fractions(v, f"{path}[{i}]")
+
+
+def test_committed_round5_line_fractions_are_fractions_and_rows_carry_cpu_baselines():
+    """VERDICT r4, next #2, on the line bench.py printed on the GPU box in round 5 (profiles/r05_bench_n1.json): no value
+    called a fraction exceeds 1 (the LSM sweep's is formed with the bytes the kernel MOVES; SURVEY's 40 B two-pass figure is
+    carried for context only), C3 is named latency-bound at its ~0.17, and every widened row has a CPU baseline beside it --
+    the compiled reference where it compiles, the restatement where it needs Eigen."""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    j = json.load(open(os.path.join(root, "profiles", "r05_bench_n1.json")))
+    fr = list(_fractions(j))
+    assert len(fr) >= 12
+    for where, v in fr:
+        assert 0.0 <= v <= 1.05, (where, v)        # (frac_of_board_ceiling: the probe's own scatter allows a percent or two over 1)
+        assert v <= 1.0 or where.endswith("frac_of_board_ceiling"), (where, v)
+    rows = j["extra"]["configs"]
+    c3 = next(r for r in rows if r["config"].startswith("C3"))
+    assert c3["bound"].startswith("latency") and 0.1 < c3["hbm_frac"] < 0.25 and c3["dominant_kernel"] == "lsm_sweep"
+    sweep = c3["kernels"]["lsm_sweep"]
+    assert sweep["bytes_moved_per_pass"] == 8.0 * 50 * 1_000_000 and sweep["survey_two_pass_bytes_per_pass"] == 40.0 * 50 * 1_000_000
+    c5 = next(r for r in rows if r["config"].startswith("C5"))
+    assert c5["kernels"]["lsm_sweep"]["bytes_moved_per_pass"] == 16.0 * 252 * 8_000_000 and c5["bound"].startswith("valu-issue")
+    kinds = {}
+    for r in rows:
+        if "cpu_baseline" in r:
+            b = r["cpu_baseline"]
+            assert b["value"] > 0 and b["cores"] >= 1 and b["kind"] in ("reference", "port") and len(b["sample"]) > 40, r["config"]
+            kinds[r["config"].split(":")[0][:22]] = b["kind"]
+    assert kinds.get("AsymptoticAnalysis") == "reference" and kinds.get("BranchingProcesses") == "reference"
+    assert kinds.get("MartingaleOptimization") == "port" and kinds.get("C3") == "port" and kinds.get("mcg_batch_price_rows") == "port"
+    assert j["config"]["untimed_ramp_launches"] == 12 and j["extra"]["c2_cold_first_launch_ms"] > j["roofline"]["kernel_avg_ms"]
+
+
 def test_committed_c5_bench_lines():
     """The C5 lines (bench.py --config c5): one launch of the LSM sweep without a collective, the per-date kernels with
     one all-reduce of 8 moments per exercise date when the built-in RCCL communicator is installed; same price."""
