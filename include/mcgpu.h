@@ -203,7 +203,7 @@ typedef struct mcg_row {
     int is_call;
 } mcg_row;
 
-/* Prices n_rows option rows in five launches per chunk of rows (one chunk unless the rows' workspace exceeds the memory
+/* Prices n_rows option rows in six launches per chunk of rows (one chunk unless the rows' workspace exceeds the memory
  * budget, see below): n_paths (the driver uses 250) rBergomi paths per row,
  * then AsymptoticAnalysis, BranchingProcesses(num_branches, exercise dates 0..n_steps-1), LSM(poly_order) and
  * MartingaleOptimization(poly_order, max_iterations) on them.  out[4*i + {0,1,2,3}] = the four prices of row i

@@ -1,15 +1,13 @@
 // Batched driver rows: the per-row work of the reference's production caller
 // (/root/reference/src/core/PredictionGen.cpp:700-791 -- 250 rBergomi paths, then AsymptoticAnalysis,
 // BranchingProcesses(10 branches, exercise dates 0..steps-1), LSM(polyOrder 2), MartingaleOptimization(2))
-// for MANY option rows in five launches (per chunk of rows, run_batch_rows) instead of ~15 launches and ~8 host
+// for MANY option rows in six launches (per chunk of rows, run_batch_rows) instead of ~15 launches and ~8 host
 // synchronisations per row:
 //   k_batch_weights    one workgroup per row: lambda -> |phi_k|^2 -> spectral amplitudes a_k and compensator
 //                      (the host/volterra.cpp math, done with a direct DFT against an LDS table of roots of unity)
 //   k_batch_paths      a few workgroups per row: the FFT generator of rbergomi_device.hpp
-//   k_batch_branching / _lsm / _martingale    one workgroup per row (n_paths <= 256: one path per thread), all
-//                      reductions inside the workgroup, regression solves on thread 0; AsymptoticAnalysis rides on the
-//                      martingale kernel's primal scan (round 5: the same columns, the same discount factors -- until then a
-//                      kernel, and a read of every row's block, of its own)
+//   k_batch_asym / _branching / _lsm / _martingale    one workgroup per row (n_paths <= 256: one path per
+//                      thread), all reductions inside the workgroup, regression solves on thread 0
 // Row c uses Philox path ids (c << 32) + p, so its four prices equal those of the single-contract entry
 // points called with path_begin = c << 32 (up to the ~1e-13 difference between the device DFT and the host FFT
 // in the amplitudes).  Matrix layout: every row owns ONE contiguous block of (n_steps + 1) x 256 doubles, step-major
@@ -147,6 +145,67 @@ __global__ __launch_bounds__(256) void k_batch_paths(BatchArgs a, int blocks_per
     }
 }
 
+// ---- AsymptoticAnalysis (AsymptoticAnalysisPricer.cpp:38-113), one workgroup per row ------------
+__global__ __launch_bounds__(256) void k_batch_asym(BatchArgs a) {
+    extern __shared__ double sm[];  // bnd[n_cols], disc[n_cols]
+    __shared__ double red[2 * 4];
+    const BatchRow row = a.rows[blockIdx.x];
+    if (!row.valid) return;
+    const int n_cols = row.n_steps + 1;
+    double* bnd = sm;
+    double* dsc = sm + (a.max_steps + 1);
+    const bool call = row.is_call != 0;
+    for (int j = threadIdx.x; j < n_cols; j += 256) {
+        const double t = j * a.dt;
+        const double eps = row.maturity - t;
+        double b = row.strike;
+        if (!(eps < 1e-10)) {
+            const double hw = 0.5 * row.sigma * sqrt(eps * log(1.0 / eps));
+            if (call) {
+                b = row.strike - hw;
+                if (eps < 0.01) b += 0.5 * (row.dividend - a.r) * eps;
+            } else {
+                b = row.strike + hw;
+                if (eps < 0.01) b -= 0.5 * (a.r - row.dividend) * eps;
+            }
+        }
+        bnd[j] = b;
+        dsc[j] = exp(-a.r * t);
+    }
+    __syncthreads();
+    double v[2] = {0.0, 0.0};
+    const int p = threadIdx.x;
+    if (p < a.n_paths) {
+        const double* col = a.S + row.off + p;
+        double best = 0.0;
+        int n_scan = 0;  // the reference scans until the first date beyond the maturity (:62-64)
+        while (n_scan < n_cols && !(n_scan * a.dt > row.maturity)) ++n_scan;
+        // a thread's scan is a chain of dependent-looking loads (one row of the block per date): four at a time are in flight
+        for (int j0 = 0; j0 < n_scan; j0 += 4) {
+            double S4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) S4[u] = col[(int64_t)min(j0 + u, n_scan - 1) * BATCH_LD];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + u;
+                const double S = S4[u];
+                if (j >= n_scan || isnan(S) || isinf(S)) continue;
+                const bool in = call ? (S > bnd[j]) : (S < bnd[j]);
+                if (in) {
+                    const double d = dsc[j] * payoff_of(call, S, row.strike);
+                    if (d > best) best = d;
+                }
+            }
+        }
+        if (!isnan(best) && !isinf(best)) {
+            v[0] = best;
+            v[1] = 1.0;
+        }
+    }
+    block_sum<2, 4>(v, red);
+    if (threadIdx.x == 0) a.out[4 * (int64_t)blockIdx.x + 0] = v[1] > 0.0 ? v[0] / v[1] : 0.0;
+}
+
 // ---- BranchingProcesses (BranchingProcessPricer.cpp:12-134), exercise dates 0..steps-1 ----------
 // One workgroup per row, one path per thread.  The reference's continuation at date e averages, over `numBranches`
 // uniformly resampled paths, the best discounted payoff over all LATER columns (:104-121) = the suffix maximum
@@ -238,12 +297,11 @@ __global__ __launch_bounds__(256) void k_batch_lsm(BatchArgs a) {
     if ((threadIdx.x & 63) == 0) a.out[4 * r_idx + 2] = sum_v / (double)a.n_paths;
 }
 
-// ---- MartingaleOptimization (MartingaleOptimizationPricer.cpp:21-189) and, on its primal scan, AsymptoticAnalysis
-// (AsymptoticAnalysisPricer.cpp:38-113) -----------------------------------------------------------
+// ---- MartingaleOptimization (MartingaleOptimizationPricer.cpp:21-189) ----------------------------
 template <int NB>
 __global__ __launch_bounds__(256) void k_batch_martingale(BatchArgs a) {
     constexpr int NM = 3 * NB - 1;
-    extern __shared__ double sm[];  // disc[n_cols] with the maturity clamp | AsymptoticAnalysis's boundary bnd[n_cols]
+    extern __shared__ double sm[];  // disc[n_cols] with the maturity clamp
     __shared__ double red[(NM + 1) * 4];
     __shared__ double sm_mom[32];
     __shared__ double sm_coef[LSM_COEF_STRIDE];
@@ -255,28 +313,10 @@ __global__ __launch_bounds__(256) void k_batch_martingale(BatchArgs a) {
     const bool call = row.is_call != 0;
     const double invK = 1.0 / row.strike;
     double* dsc = sm;
-    double* bnd = sm + (a.max_steps + 1);
     for (int j = threadIdx.x; j < n_cols; j += 256) {
-        const double t_j = j * a.dt;
-        double t = t_j;
+        double t = j * a.dt;
         if (t > row.maturity) t = row.maturity;
         dsc[j] = exp(-a.r * t);
-        // AsymptoticAnalysis's exercise boundary at date j (AsymptoticAnalysisPricer.cpp:8-36; k_batch_asym): this kernel's
-        // primal scan reads every column up to the maturity once -- the very scan AsymptoticAnalysis makes (:62-64 stops at the
-        // first date beyond the maturity, where the clamp above is not active yet, so dsc[j] is its discount factor too)
-        const double eps = row.maturity - t_j;
-        double b = row.strike;
-        if (!(eps < 1e-10)) {
-            const double hw = 0.5 * row.sigma * sqrt(eps * log(1.0 / eps));
-            if (call) {
-                b = row.strike - hw;
-                if (eps < 0.01) b += 0.5 * (row.dividend - a.r) * eps;
-            } else {
-                b = row.strike + hw;
-                if (eps < 0.01) b -= 0.5 * (a.r - row.dividend) * eps;
-            }
-        }
-        bnd[j] = b;
     }
     __syncthreads();
     int n_dates = 0;
@@ -284,27 +324,19 @@ __global__ __launch_bounds__(256) void k_batch_martingale(BatchArgs a) {
     const int p = threadIdx.x;
     const bool live = p < a.n_paths;
     const double* col = a.S + row.off + (live ? p : 0);
-    double asym[2] = {0.0, 0.0};  // AsymptoticAnalysis: this path's best discounted payoff inside the exercise region, and 1 if it counts
     double m[NM + 1];
     double xs[2] = {0.0, 0.0}, ys[2] = {0.0, 0.0};  // this path's two regression samples (kept for a re-fit)
 #pragma unroll
     for (int q = 0; q <= NM; ++q) m[q] = 0.0;
     if (live) {
-        double best = 0.0, best_a = 0.0;
+        double best = 0.0;
         int stop = 0;
         for (int j = 0; j < n_dates; ++j) {
-            const double S = col[(int64_t)j * BATCH_LD];
-            const double d = payoff_of(call, S, row.strike) * dsc[j];
+            const double d = payoff_of(call, col[(int64_t)j * BATCH_LD], row.strike) * dsc[j];
             if (d > best) {
                 best = d;
                 stop = j;
             }
-            // AsymptoticAnalysisPricer.cpp:66-84: non-finite prices are skipped, the payoff counts inside the exercise region
-            if (!(isnan(S) || isinf(S)) && (call ? (S > bnd[j]) : (S < bnd[j])) && d > best_a) best_a = d;
-        }
-        if (!isnan(best_a) && !isinf(best_a)) {  // :86-92
-            asym[0] = best_a;
-            asym[1] = 1.0;
         }
         m[NM] = best;
         const int other = (stop + n_cols / 2) % n_cols;
@@ -324,9 +356,6 @@ __global__ __launch_bounds__(256) void k_batch_martingale(BatchArgs a) {
             }
         }
     }
-    block_sum<2, 4>(asym, red);  // (the same two sums in the same order as k_batch_asym's: the same bits)
-    if (threadIdx.x == 0) a.out[4 * (int64_t)blockIdx.x + 0] = asym[1] > 0.0 ? asym[0] / asym[1] : 0.0;
-    __syncthreads();  // red is reused
     block_sum<NM + 1, 4>(m, red);
     if (threadIdx.x == 0) {
 #pragma unroll
@@ -385,7 +414,7 @@ __global__ __launch_bounds__(256) void k_batch_martingale(BatchArgs a) {
 template <int NB>
 static void launch_row_regressions(mcg_ctx* ctx, const BatchArgs& a, size_t smem_cols) {
     hipLaunchKernelGGL(k_batch_lsm<NB>, dim3((unsigned)((a.n_rows + 3) / 4)), dim3(256), 0, ctx->stream, a);
-    hipLaunchKernelGGL(k_batch_martingale<NB>, dim3((unsigned)a.n_rows), dim3(256), 2 * smem_cols, ctx->stream, a);  // disc | bnd
+    hipLaunchKernelGGL(k_batch_martingale<NB>, dim3((unsigned)a.n_rows), dim3(256), smem_cols, ctx->stream, a);
 }
 
 namespace {
@@ -443,6 +472,7 @@ static int run_batch_chunk(mcg_ctx* ctx, std::vector<BatchRow>& h, BatchArgs a, 
         if (smem_p > 48 * 1024)
             (void)hipFuncSetAttribute((const void*)k_batch_paths, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_p);
         hipLaunchKernelGGL(k_batch_paths, dim3((unsigned)(n * bpr)), dim3(256), smem_p, ctx->stream, a, bpr);
+        hipLaunchKernelGGL(k_batch_asym, dim3((unsigned)n), dim3(256), 2 * smem_c, ctx->stream, a);
         hipLaunchKernelGGL(k_batch_branching, dim3((unsigned)n), dim3(256), smem_c, ctx->stream, a);
         switch (poly_order + 1) {
             case 1: launch_row_regressions<1>(ctx, a, smem_c); break;
