@@ -395,14 +395,16 @@ def widening_configs(eng, N, mc, baselines=None) -> list:
     wall = (time.perf_counter() - t0) / reps * 1e3
     ms, cnt = eng.timing_get(N.K_BATCH)
     cols = sum(r["n_steps"] + 1 for r in rows)
-    # paths written once and read by each of the four pricers; branching additionally writes and re-reads F
-    moved = 8.0 * 250 * cols * (1 + 4 + 2)
+    # row blocks written once by the generator; read once each by AsymptoticAnalysis, BranchingProcesses (its suffix maxima stay in
+    # registers / LDS since round 3) and LSM, twice by MartingaleOptimization (primal and dual scan)
+    moved = 8.0 * 250 * cols * (1 + 5)
     out.append({"config": "mcg_batch_price_rows: 20 000 driver rows x 250 rBergomi paths (5-126 steps), four prices per row",
                 "rows": len(rows), "ms_per_call": wall, "rows_per_s": len(rows) / wall * 1e3, "kernel_ms_per_call": ms / reps,
                 "rows_per_s_of_device_time": len(rows) / (ms / reps) * 1e3, "launches_per_call": 6 * cnt // reps, "chunks_per_call": cnt // reps,
                 "timed": "mcg_batch_price_rows on a prebuilt array of mcg_row (upload, kernels, download, scatter); device time = the chunks' kernel spans",
                 "bytes_moved_per_call": moved,
-                "bytes_moved": "row matrices written once, read by the four pricers, F of the branching rows written and read",
+                "bytes_moved": "row blocks written once by the generator, read once each by AsymptoticAnalysis, BranchingProcesses and LSM, twice by "
+                               "MartingaleOptimization (primal and dual scan)",
                 "hbm_frac": moved / (ms / reps * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "note": "latency- and issue-bound small-row work: the HBM fraction is reported, not the bound",
                 "mean_prices": [float(x) for x in pr.mean(axis=0)]})
