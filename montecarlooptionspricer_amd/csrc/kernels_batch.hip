@@ -100,7 +100,14 @@ __global__ __launch_bounds__(256) void k_batch_weights(BatchArgs a) {
 }
 
 // ---- paths -----------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_batch_paths(BatchArgs a, int blocks_per_row) {
+#ifndef MCG_BATCH_PATHS_WAVES
+#define MCG_BATCH_PATHS_WAVES 2
+#endif
+// CLS = the LDS class of the launch's rows (lds_class: Mz <= 128 / 256 / 512 / 1024): a launch holds rows of ONE class, and its
+// kernel only the transforms that class can need -- the register count of the Mz = 1024 variant is not what the many short
+// rows of the driver (Mz <= 128) should pay for.
+template <int CLS>
+__global__ __launch_bounds__(256, MCG_BATCH_PATHS_WAVES) void k_batch_paths(BatchArgs a, int blocks_per_row) {
     extern __shared__ double smem[];
     __shared__ fm::Tables tabs;
     const int64_t r_idx = blockIdx.x / blocks_per_row;
@@ -134,14 +141,19 @@ __global__ __launch_bounds__(256) void k_batch_paths(BatchArgs a, int blocks_per
     g.ticket = nullptr;
     double la, lb;
     bool va, vb, lead;
-    switch (row.M) {  // wave-uniform
-        case 32: rb_generate_fft<0 + 3 - RB_LT_DEFAULT, RB_LT_DEFAULT>(g, sub, smem, &tabs, la, lb, va, vb, lead); break;
-        case 64: rb_generate_fft<1 + 3 - RB_LT_DEFAULT, RB_LT_DEFAULT>(g, sub, smem, &tabs, la, lb, va, vb, lead); break;
-        case 128: rb_generate_fft<2 + 3 - RB_LT_DEFAULT, RB_LT_DEFAULT>(g, sub, smem, &tabs, la, lb, va, vb, lead); break;
-        case 256: rb_generate_fft<3 + 3 - RB_LT_DEFAULT, RB_LT_DEFAULT>(g, sub, smem, &tabs, la, lb, va, vb, lead); break;
-        case 512: rb_generate_fft<4 + 3 - RB_LT_DEFAULT, RB_LT_DEFAULT>(g, sub, smem, &tabs, la, lb, va, vb, lead); break;
-        case 1024: rb_generate_fft<5 + 3 - RB_LT_DEFAULT, RB_LT_DEFAULT>(g, sub, smem, &tabs, la, lb, va, vb, lead); break;
-        default: rb_generate_small(g, sub, smem, &tabs, la, lb, va, vb, lead); break;
+    if constexpr (CLS == 0) {
+        switch (row.M) {  // wave-uniform
+            case 32: rb_generate_fft<0 + 3 - RB_LT_DEFAULT, RB_LT_DEFAULT>(g, sub, smem, &tabs, la, lb, va, vb, lead); break;
+            case 64: rb_generate_fft<1 + 3 - RB_LT_DEFAULT, RB_LT_DEFAULT>(g, sub, smem, &tabs, la, lb, va, vb, lead); break;
+            case 128: rb_generate_fft<2 + 3 - RB_LT_DEFAULT, RB_LT_DEFAULT>(g, sub, smem, &tabs, la, lb, va, vb, lead); break;
+            default: rb_generate_small(g, sub, smem, &tabs, la, lb, va, vb, lead); break;
+        }
+    } else if constexpr (CLS == 1) {
+        rb_generate_fft<3 + 3 - RB_LT_DEFAULT, RB_LT_DEFAULT>(g, sub, smem, &tabs, la, lb, va, vb, lead);
+    } else if constexpr (CLS == 2) {
+        rb_generate_fft<4 + 3 - RB_LT_DEFAULT, RB_LT_DEFAULT>(g, sub, smem, &tabs, la, lb, va, vb, lead);
+    } else {
+        rb_generate_fft<5 + 3 - RB_LT_DEFAULT, RB_LT_DEFAULT>(g, sub, smem, &tabs, la, lb, va, vb, lead);
     }
 }
 
@@ -469,9 +481,11 @@ static int run_batch_chunk(mcg_ctx* ctx, std::vector<BatchRow>& h, BatchArgs a, 
     {
         TimedLaunch t(ctx, MCG_K_BATCH);
         hipLaunchKernelGGL(k_batch_weights, dim3((unsigned)n), dim3(256), smem_w, ctx->stream, a);
-        if (smem_p > 48 * 1024)
-            (void)hipFuncSetAttribute((const void*)k_batch_paths, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_p);
-        hipLaunchKernelGGL(k_batch_paths, dim3((unsigned)(n * bpr)), dim3(256), smem_p, ctx->stream, a, bpr);
+        typedef void (*PathsKernel)(BatchArgs, int);
+        static const PathsKernel paths_kernel[N_LDS_CLASSES] = {k_batch_paths<0>, k_batch_paths<1>, k_batch_paths<2>, k_batch_paths<3>};
+        const PathsKernel pk = paths_kernel[lds_class(m_max)];  // (a chunk holds rows of one class, run_batch_rows)
+        if (smem_p > 48 * 1024) (void)hipFuncSetAttribute((const void*)pk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_p);
+        hipLaunchKernelGGL(pk, dim3((unsigned)(n * bpr)), dim3(256), smem_p, ctx->stream, a, bpr);
         hipLaunchKernelGGL(k_batch_asym, dim3((unsigned)n), dim3(256), 2 * smem_c, ctx->stream, a);
         hipLaunchKernelGGL(k_batch_branching, dim3((unsigned)n), dim3(256), smem_c, ctx->stream, a);
         switch (poly_order + 1) {
