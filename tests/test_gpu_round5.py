@@ -91,3 +91,25 @@ def test_batch_row_with_non_finite_paths_is_zeroed_like_the_driver(eng):
     assert np.array_equal(alone[0], four[0])              # a flagged neighbour changes nothing
     six = eng.batch_price_rows(rows, seed=5, features=np.array([[0.2, 0.01]] * 3))
     assert np.all(six[1] == 0.0) and six[0][4] == 0.2 and six[2][5] == 0.01
+
+
+def test_widened_pricers_match_oracle_on_the_c3_matrix(eng, orc):
+    """The three other pricers of the driver on the matrix bench.py times them on -- C3's 1M GBM paths x 50 dates, full size --
+    against the oracle on the downloaded matrix: AsymptoticAnalysis (the oracle is pinned bit for bit to the compiled
+    reference) to 1e-13, MartingaleOptimization to 1e-8, BranchingProcesses (oracle in philox mode: the same resampling
+    draws; the 1M-path row is four 2 MB slices, one launch per exercise date) to 1e-12.  Rounds 1-4 compared these at
+    <= 524k paths."""
+    n, steps, dt = 1_000_000, 50, 0.02
+    P = eng.gbm(SEED, 100.0, 0.04, 0.2, dt, steps, n)
+    S = P.to_host_step_major()
+    got_a = eng.price_asymptotic(P, 0.04, 100.0, 1.0, dt, False, 0.2, 0.0)
+    want_a = orc.asymptotic_price(S, 0.04, 100.0, 1.0, dt, False, 0.2, 0.0)
+    assert abs(got_a - want_a) <= 1e-13 * abs(want_a), (got_a, want_a)
+    got_m = eng.price_martingale(P, 0.04, 100.0, 1.0, dt, False, 2, 5)
+    want_m = orc.martingale_price(S, 0.04, 100.0, 1.0, dt, False, 2, 5)
+    assert np.allclose(got_m, want_m, rtol=1e-8, atol=0.0), (got_m, want_m)
+    ex = np.arange(0, steps, 7, dtype=np.int32)     # eight exercise dates: the oracle's resampling loop is serial
+    got_b = eng.price_branching(P, 0.04, 100.0, 1.0, dt, False, 10, ex, seed=17)
+    want_b = orc.branching_price(S, 0.04, 100.0, 1.0, dt, False, 10, ex, 17, mode="philox")
+    assert np.allclose(got_b, want_b, rtol=1e-12, atol=1e-14), (got_b, want_b)
+    P.free()

@@ -405,3 +405,33 @@ def test_branching_upper_bound_statistics(orc):
         se = math.sqrt(a.var(ddof=1) / len(a) + x.var(ddof=1) / len(x))
         assert abs(a.mean() - x.mean()) <= 4 * se, (a.mean(), x.mean(), se)
     assert 0.5 < b.std(ddof=1) / c.std(ddof=1) < 2.0
+
+
+def test_cpu_baseline_harness_prices_what_the_single_calls_price(orc):
+    """bench.py's CPU baselines of the widened rows run the pricers over a resident sample in driver rows of 250 paths under
+    omp dynamic (oracle/ref_harness.cpp: ref_pricer_chunks_omp, oracle/mcg_oracle.cpp: orc_pricer_chunks_omp).  What they
+    time must be the pricers themselves: the sum of prices they return equals the sum over the same rows priced one call at
+    a time (exactly for the deterministic pricers; BranchingProcesses resamples with an unseeded generator in the reference)."""
+    from oracle.binding import Reference, have_ref
+    S = np.ascontiguousarray(orc.paths_gbm(11, 100.0, 0.04, 0.2, 0.02, 50, 0, 1000).T)   # [1000][51]
+    arg = (0.04, 100.0, 1.0, 0.02, False)
+    th, sec, chk = orc.pricer_chunks_omp("lsm", S, 250, *arg, 2)
+    one = sum(orc.lsm_price(S[k:k + 250], *arg, 2, step_major=False) for k in range(0, 1000, 250))
+    assert th >= 1 and sec > 0 and abs(chk - one) <= 1e-12 * one
+    th, sec, chk = orc.pricer_chunks_omp("martingale", S, 250, *arg, 2)
+    one = sum(orc.martingale_price(S[k:k + 250], *arg, 2, 5, step_major=False)[0] for k in range(0, 1000, 250))
+    assert abs(chk - one) <= 1e-12 * one
+    if not have_ref():
+        pytest.skip("compiled reference not built here")
+    ref = Reference()
+    th, sec, chk = ref.pricer_chunks_omp("asymptotic", S, 250, *arg, 0.2, 0.0)
+    one = sum(ref.asymptotic_price(S[k:k + 250], *arg, 0.2, 0.0) for k in range(0, 1000, 250))
+    assert abs(chk - one) <= 1e-12 * one
+    th, sec, chk = ref.pricer_chunks_omp("branching", S, 250, *arg, 0.2, 0.0, 10)
+    lo = sum(ref.branching_price(S[k:k + 250], *arg, 10, np.arange(50, dtype=np.int32))[1] for k in range(0, 1000, 250))
+    assert chk > 0.5 * lo and np.isfinite(chk)       # midpoint of the deterministic lower bound and a resampled upper bound
+    # whole driver rows: four sums, all positive, LSM and MartingaleOptimization through the restatement's entry points
+    from oracle.binding import synthetic_history
+    hist = synthetic_history(300, seed=3)
+    th, sec, sums = ref.driver_rows_omp(hist, [20, 40, 11], [float(hist[-1])] * 3, [0, 1, 0], 250, 0.2, 0.08, orc)
+    assert th >= 1 and sec > 0 and np.all(sums > 0) and np.all(np.isfinite(sums))
