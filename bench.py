@@ -520,28 +520,49 @@ def c5_rows_mode(args, world: int) -> str:
 
 
 def rccl_forms_in_time(make_scratch, rank: int, world: int, bcast, limit_s: float) -> bool:
-    """Form the built-in RCCL communicator on a scratch context in a thread; True iff it formed within limit_s."""
+    """Form the built-in RCCL communicator on a scratch context inside a time box; True iff it formed within limit_s.  Only
+    ncclCommInitRank itself runs in the worker thread: the id's broadcast stays in the MAIN thread (torch's current device is
+    thread-local -- a collective issued from a fresh thread would run on device 0 on every rank), which enters it ALWAYS,
+    whatever the worker did (an empty id from rank 0 makes every rank's init raise together)."""
     import threading
     box = {}
+    uid_ready, uid_back = threading.Event(), threading.Event()
+
+    def bcast_in_main(uid):   # called by init_rccl inside the worker: park the id, wait for the main thread's broadcast
+        box["uid_in"] = uid
+        uid_ready.set()
+        uid_back.wait()
+        return box.get("uid_out")
 
     def work():
         try:
             e = make_scratch()
-            e.init_rccl(rank, world, bcast)
-            box["eng"] = e
+            box["scratch"] = e
+            e.init_rccl(rank, world, bcast_in_main)
+            box["formed"] = True
         except Exception as ex:   # noqa: BLE001
             box["err"] = ex
+        finally:
+            uid_ready.set()       # (a worker that failed before it had an id must not keep the main thread from the broadcast)
     t = threading.Thread(target=work, daemon=True)
     t.start()
+    uid_ready.wait(limit_s)       # creating the id is local
+    box["uid_out"] = bcast(box.get("uid_in", b"") if rank == 0 else None)
+    uid_back.set()
     t.join(limit_s)
     if t.is_alive():
         print(f"bench: rank {rank}: the built-in RCCL communicator did not form within {limit_s:.0f} s; falling back to torch.distributed",
               file=sys.stderr, flush=True)
         return False
-    if "err" in box:
-        print(f"bench: built-in RCCL communicator unavailable ({box['err']}); using torch.distributed", file=sys.stderr)
+    if "err" in box or not box.get("formed"):
+        print(f"bench: built-in RCCL communicator unavailable ({box.get('err')}); using torch.distributed", file=sys.stderr)
+        if box.get("scratch") is not None:
+            try:
+                box["scratch"].close()
+            except Exception:   # noqa: BLE001
+                pass
         return False
-    box["eng"].close()
+    box["scratch"].close()
     return True
 
 
