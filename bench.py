@@ -1095,7 +1095,8 @@ def main() -> None:
             except Exception:
                 traffic = None
         if args.config == "c2":
-            workload = "C2: European call, GBM, 10M paths x 252 steps per GPU, fp64 matrix written"
+            workload = (f"C2: European call, GBM, {args.paths // 1_000_000}M paths x {n_steps} steps per GPU, fp64 matrix written" if args.paths % 1_000_000 == 0
+                        else f"C2: European call, GBM, {args.paths} paths x {n_steps} steps per GPU, fp64 matrix written")
             sharding = f"contiguous path ids over {world} rank(s); one 3-double all-reduce"
             ref = bs_call(S0, K, r, sigma, T)
             parity = {"price": price, "std_err": se, "black_scholes": ref,
