@@ -95,6 +95,14 @@ def cpu_baseline(n_steps: int, budget_s: float = 15.0) -> dict:
            "sample": f"{n} paths x {n_steps} steps via RoughVolatility::GenerateStockPricePaths "
                      f"(rBergomi, 1001-point synthetic history), omp dynamic, {chunk} paths/call, {dt:.1f} s"}
     if kind == "reference":
+        # the same entry point on ONE thread, ~2 s: what a host core delivers when the calls do not compete (every call of the
+        # reference constructs std::random_device + mt19937 three times per path and allocates per path: on many cores the
+        # parallel rate above is far below cores x this)
+        t0, done = time.perf_counter(), 0
+        while time.perf_counter() - t0 < 2.0:
+            ref.generate_paths(hist, n_steps, chunk)
+            done += chunk
+        out["single_thread_value"] = done / (time.perf_counter() - t0) / 1e6
         # the reference's own sample, priced: undiscounted mean call payoff +- std-err at K = S0
         m = sums[1] / sums[3]
         var = max(0.0, (sums[2] - sums[3] * m * m) / (sums[3] - 1))

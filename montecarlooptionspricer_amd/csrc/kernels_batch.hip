@@ -16,6 +16,7 @@
 // of rows: the call works through them in chunks under a memory budget (run_batch_rows); a row's Philox ids, and
 // therefore its prices, do not depend on which chunk it falls into.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <vector>
 
@@ -510,9 +511,17 @@ static int run_batch_chunk(mcg_ctx* ctx, std::vector<BatchRow>& h, BatchArgs a, 
     return MCG_OK;
 }
 
+#ifdef MCG_BATCH_TRACE   // (A/B builds: where the host time of a call goes, printed to stderr)
+#define BT_NOW() std::chrono::steady_clock::now()
+#define BT_US(a, b) (std::chrono::duration<double, std::micro>((b) - (a)).count())
+#endif
+
 int run_batch_rows(mcg_ctx* ctx, const mcg_row* rows, int64_t n_rows, int n_paths, double r, double dt, int num_branches,
                    int poly_order, int max_iterations, uint64_t seed, double* out, unsigned char* priced) {
     g_stats.batch_calls.fetch_add(1, std::memory_order_relaxed);
+#ifdef MCG_BATCH_TRACE
+    const auto bt0 = BT_NOW();
+#endif
     std::vector<int64_t> cls[N_LDS_CLASSES], long_rows;
     for (int64_t i = 0; i < n_rows; ++i) {
         const mcg_row& s = rows[i];
@@ -534,6 +543,9 @@ int run_batch_rows(mcg_ctx* ctx, const mcg_row* rows, int64_t n_rows, int n_path
         while (M < s.n_steps) M <<= 1;
         cls[lds_class(M)].push_back(i);
     }
+#ifdef MCG_BATCH_TRACE
+    const auto bt1 = BT_NOW();
+#endif
     // Memory budget of one chunk: a quarter of what is free now (mcg_debug_batch_budget overrides), never less than one row.
     size_t budget = ctx->batch_budget;
     if (budget == 0) {
@@ -575,6 +587,10 @@ int run_batch_rows(mcg_ctx* ctx, const mcg_row* rows, int64_t n_rows, int n_path
             k = ch.end;
         }
     }
+#ifdef MCG_BATCH_TRACE
+    const auto bt2 = BT_NOW();
+    double bt_build = 0.0, bt_chunk = 0.0;
+#endif
     int rc = MCG_OK;
     if (!plan.empty()) {
         void *S = nullptr, *small = nullptr;  // ONE pair of buffers for all chunks
@@ -601,6 +617,9 @@ int run_batch_rows(mcg_ctx* ctx, const mcg_row* rows, int64_t n_rows, int n_path
         a.max_iterations = max_iterations;
         std::vector<BatchRow> h;
         for (const Chunk& ch : plan) {
+#ifdef MCG_BATCH_TRACE
+            const auto bc0 = BT_NOW();
+#endif
             h.clear();
             h.reserve(ch.end - ch.begin);
             for (size_t k = ch.begin; k < ch.end; ++k) {
@@ -624,7 +643,14 @@ int run_batch_rows(mcg_ctx* ctx, const mcg_row* rows, int64_t n_rows, int n_path
                 while (d.M < d.n_steps) d.M <<= 1;
                 h.push_back(d);
             }
+#ifdef MCG_BATCH_TRACE
+            const auto bc1 = BT_NOW();
+#endif
             rc = run_batch_chunk(ctx, h, a, (double*)S, (double*)small, poly_order, out, priced);
+#ifdef MCG_BATCH_TRACE
+            bt_build += BT_US(bc0, bc1);
+            bt_chunk += BT_US(bc1, BT_NOW());
+#endif
             if (rc) break;
             g_stats.batch_chunks.fetch_add(1, std::memory_order_relaxed);
             g_stats.batch_rows.fetch_add((int64_t)h.size(), std::memory_order_relaxed);
@@ -633,6 +659,10 @@ int run_batch_rows(mcg_ctx* ctx, const mcg_row* rows, int64_t n_rows, int n_path
         pool_release(ctx, small, max_small * sizeof(double));
         if (rc) return rc;
     }
+#ifdef MCG_BATCH_TRACE
+    std::fprintf(stderr, "batch trace: classify %.0f us, budget+plan %.0f us, build images %.0f us, chunks (upload, launches, download, scatter) %.0f us, total %.0f us\n",
+                 BT_US(bt0, bt1), BT_US(bt1, bt2), bt_build, bt_chunk, BT_US(bt0, BT_NOW()));
+#endif
     g_stats.batch_rows_singly.fetch_add((int64_t)long_rows.size(), std::memory_order_relaxed);
     for (int64_t i : long_rows) {  // PredictionGen.cpp:718-816 for one row, through the single-contract entry points
         const mcg_row& s = rows[i];
