@@ -516,7 +516,7 @@ int run_branching(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double m
     size_t state_bytes = 0;
     // Rows of more than four slices (more than a million paths), up to 2^30 - 2 paths: per-date launches of the BINNED
     // kernel (k_branch_date_binned: every thread walks its indices sorted by slice), sixteen slices of >= 2 MB.
-    int bshift = BR_SLICE_SHIFT;
+    int bshift = study_switch("MCG_BRANCH_BIN_SHIFT", BR_SLICE_SHIFT);  // (A/B builds: 17 = 1 MB slices while sixteen of them cover the row)
     while ((((P->n_paths > 0 ? P->n_paths : 1) - 1) >> bshift) + 1 > 16) ++bshift;
     const int b_slices = (int)((((P->n_paths > 0 ? P->n_paths : 1) - 1) >> bshift) + 1);
     const bool binned = b_slices > BR_DATE_MAX_SLICES && quads >= 1 && quads <= 3 && !ex.empty() && P->n_paths < ((int64_t)1 << 30) - 1 &&
