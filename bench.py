@@ -234,7 +234,7 @@ def valu_profile(name: str):
 
 
 def extra_configs(eng, N, baselines=None) -> list:
-    """C3, C4 and the C5 shard on this GPU, once each (one untimed pass, then 3 timed for the wall time and 3 more with
+    """C3, C4 and the C5 shard on this GPU, once each (one untimed pass, then 5 timed for the wall time -- the median -- and 3 more with
     per-kernel HIP events), after the headline loop: ms per pass, Mpaths/s, the dominant kernel's average launch time and what it achieves against the HBM roofline
     (SURVEY 8d algorithmic bytes) and against the VALU issue rate (instruction count from the committed PMC profile)."""
     reps = 3
@@ -272,11 +272,13 @@ def extra_configs(eng, N, baselines=None) -> list:
         # wall time WITHOUT the library's event timing (a HIP-event pair per launch costs ~9 us: 7 % of a C3 pass), then
         # the same passes again with it, for the per-kernel breakdown
         eng.timing_enable(False)
-        t0 = time.perf_counter()
-        for _ in range(reps):
+        walls = []
+        for _ in range(2 * reps - 1):   # every pass ends in the price coming back: it can be timed by itself; the MEDIAN of five, so
+            t0 = time.perf_counter()    # that one host hiccup (3 ms once, on a 0.4-ms pass) does not become the row's number
             res = fn()
+            walls.append((time.perf_counter() - t0) * 1e3)
         eng.synchronize()
-        ms = (time.perf_counter() - t0) / reps * 1e3
+        ms = sorted(walls)[len(walls) // 2]
         eng.timing_enable(True)
         eng.timing_reset()
         for _ in range(reps):
