@@ -268,3 +268,32 @@ def test_bench_two_ranks_with_the_c5_rows_inline():
     assert rows[1]["comm"]["n_ranks"] == 2 and rows[1]["collective"] == "ipc"
     for r in rows[1:]:        # (two ranks on one card: the RCCL row runs its torch fall-back, a callback communicator)
         assert abs(r["price"] - want[0]) <= 1e-9 * want[0], r
+
+
+def test_bench_four_ranks_take_the_rows_inline_by_themselves():
+    """World size 4 on the one card (gloo): 2 x 4 processes would be over the pool's process guard, so `--c5-rows auto`
+    must decide for `inline` -- four GPU processes, the rows in the rank processes, the line through rank 0's guardian --
+    and every sharded row must carry the single-rank price of the same global path ids."""
+    root = os.path.dirname(HERE)
+    c2_paths, c5_paths = 400_000, 100_000
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "2", "--warmup", "1",
+           "--backend", "gloo", "--paths", str(c2_paths), "--c5-paths", str(c5_paths), "--c5-collectives", "none,shm,ipc"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-4000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 4 and out["config"]["c5_rows"] == "inline" and "aborted" not in out
+    assert out["config"]["global_paths"] == 4 * c2_paths and out["parity"]["abs_err_over_std_err"] < 4
+    rows = out["extra"]["configs"]
+    assert [r["collective_requested"] for r in rows] == ["none", "shm", "ipc"] and all("error" not in r for r in rows), rows
+    assert rows[1]["comm"]["n_ranks"] == 4 and rows[1]["comm"]["seen_ranks_min_over_ranks"] == 4 and rows[1]["lsm_one_launch"]
+    e = mc.PathEngine(0)
+    P = e.rbergomi(SEED, RB["S0"], RB["r"], RB["xi"], RB["H"], RB["eta"], RB["rho"], DT, 252, 4 * c5_paths)
+    want = e.price_lsm(P, RB["r"], 100.0, 252 * DT, DT, False, 2)
+    P.free()
+    e.close()
+    for r in rows[1:]:
+        assert abs(r["price"] - want[0]) <= 1e-9 * want[0], r
