@@ -49,6 +49,7 @@ struct BatchArgs {
     double* S;      // the rows' matrix blocks (BatchRow::off)
     const double2* log_tab;
     double* out;    // [n_rows][4]: asymptotic, branching, lsm, martingale (chunk-local row order)
+    const uint32_t* wg_map;  // k_batch_paths: workgroup -> (chunk-local row << 6) | share of the row's pairs
     double* bad;    // [n_rows]: != 0 when the row's path block holds a non-finite price (the driver zeroes such a row, PredictionGen.cpp:752-777)
     int num_branches, max_iterations;
 };
@@ -108,15 +109,17 @@ __global__ __launch_bounds__(256) void k_batch_weights(BatchArgs a) {
 // kernel only the transforms that class can need -- the register count of the Mz = 1024 variant is not what the many short
 // rows of the driver (Mz <= 128) should pay for.
 template <int CLS>
-__global__ __launch_bounds__(256, MCG_BATCH_PATHS_WAVES) void k_batch_paths(BatchArgs a, int blocks_per_row) {
+__global__ __launch_bounds__(256, MCG_BATCH_PATHS_WAVES) void k_batch_paths(BatchArgs a) {
     extern __shared__ double smem[];
     __shared__ fm::Tables tabs;
-    const int64_t r_idx = blockIdx.x / blocks_per_row;
-    const int sub = (int)(blockIdx.x % blocks_per_row);
+    // One workgroup per (row, share) that exists (run_batch_chunk's map).  Until round 5 the grid was rows x the widest row's
+    // shares and the others left at once -- but a workgroup that leaves at once has still been given its 71 KB of LDS and 185
+    // registers: 45 % of the 80 000 workgroups of a 20 000-row call queued for the two slots of a CU only to return.
+    const uint32_t m = a.wg_map[blockIdx.x];
+    const int64_t r_idx = m >> 6;
+    const int sub = (int)(m & 63u);
     const BatchRow row = a.rows[r_idx];
     if (!row.valid) return;
-    const int n_pairs = (a.n_paths + 1) / 2;
-    if ((int64_t)sub * rb_pairs_per_block(row.M) >= n_pairs) return;  // this row needs fewer workgroups than the widest
     RbArgs g;
     g.out = a.S + row.off;
     g.ld = BATCH_LD;
@@ -158,6 +161,9 @@ __global__ __launch_bounds__(256, MCG_BATCH_PATHS_WAVES) void k_batch_paths(Batc
     }
 }
 
+#ifndef MCG_ASYM_DEPTH
+#define MCG_ASYM_DEPTH 4   // loads of a thread's scan in flight (A/B builds: 8)
+#endif
 // ---- AsymptoticAnalysis (AsymptoticAnalysisPricer.cpp:38-113), one workgroup per row ------------
 __global__ __launch_bounds__(256) void k_batch_asym(BatchArgs a) {
     extern __shared__ double sm[];  // bnd[n_cols], disc[n_cols]
@@ -194,12 +200,12 @@ __global__ __launch_bounds__(256) void k_batch_asym(BatchArgs a) {
         int n_scan = 0;  // the reference scans until the first date beyond the maturity (:62-64)
         while (n_scan < n_cols && !(n_scan * a.dt > row.maturity)) ++n_scan;
         // a thread's scan is a chain of dependent-looking loads (one row of the block per date): four at a time are in flight
-        for (int j0 = 0; j0 < n_scan; j0 += 4) {
-            double S4[4];
+        for (int j0 = 0; j0 < n_scan; j0 += MCG_ASYM_DEPTH) {
+            double S4[MCG_ASYM_DEPTH];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) S4[u] = col[(int64_t)min(j0 + u, n_scan - 1) * BATCH_LD];
+            for (int u = 0; u < MCG_ASYM_DEPTH; ++u) S4[u] = col[(int64_t)min(j0 + u, n_scan - 1) * BATCH_LD];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < MCG_ASYM_DEPTH; ++u) {
                 const int j = j0 + u;
                 const double S = S4[u];
                 if (j >= n_scan || isnan(S) || isinf(S)) continue;
@@ -475,18 +481,31 @@ static int run_batch_chunk(mcg_ctx* ctx, std::vector<BatchRow>& h, BatchArgs a, 
     for (int m = 1; m <= m_max; m <<= 1) smem_p = std::max(smem_p, rb_smem_bytes(m, std::min(m, max_steps)));
     smem_p += (size_t)study_switch("MCG_BATCH_PATHS_EXTRA_LDS_KB", 0) << 10;  // (A/B builds: fewer workgroups per CU -- how much does the generator live off its occupancy?)
     const size_t smem_c = ((size_t)max_steps + 1) * sizeof(double);
-    // workgroups per row: enough for the row with the fewest pairs per workgroup (the largest Mz)
+    // k_batch_paths: one workgroup per share of rb_pairs_per_block(Mz) pairs of a row -- exactly those that exist
     const int n_pairs = (a.n_paths + 1) / 2;
-    int bpr = 1;
-    for (int m = 32; m <= m_max; m <<= 1) bpr = std::max(bpr, (n_pairs + rb_pairs_per_block(m) - 1) / rb_pairs_per_block(m));
+    std::vector<uint32_t> wg_map;
+    wg_map.reserve((size_t)n * 2);
+    for (int64_t k = 0; k < n; ++k) {
+        const int shares = (n_pairs + rb_pairs_per_block(h[(size_t)k].M) - 1) / rb_pairs_per_block(h[(size_t)k].M);  // <= 63 (n_paths <= 256)
+        for (int sub = 0; sub < shares; ++sub) wg_map.push_back((uint32_t)(k << 6) | (uint32_t)sub);
+    }
+    void* d_map = nullptr;
+    const size_t map_bytes = wg_map.size() * sizeof(uint32_t);
+    int rc_map = pool_alloc(ctx, map_bytes, &d_map);
+    if (rc_map) return rc_map;
+    if (hipMemcpyAsync(d_map, wg_map.data(), map_bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+        pool_release(ctx, d_map, map_bytes);
+        return fail(MCG_ERR_HIP, "batch upload failed (workgroup map)");
+    }
+    a.wg_map = (const uint32_t*)d_map;
     {
         TimedLaunch t(ctx, MCG_K_BATCH);
         hipLaunchKernelGGL(k_batch_weights, dim3((unsigned)n), dim3(256), smem_w, ctx->stream, a);
-        typedef void (*PathsKernel)(BatchArgs, int);
+        typedef void (*PathsKernel)(BatchArgs);
         static const PathsKernel paths_kernel[N_LDS_CLASSES] = {k_batch_paths<0>, k_batch_paths<1>, k_batch_paths<2>, k_batch_paths<3>};
         const PathsKernel pk = paths_kernel[lds_class(m_max)];  // (a chunk holds rows of one class, run_batch_rows)
         if (smem_p > 48 * 1024) (void)hipFuncSetAttribute((const void*)pk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_p);
-        hipLaunchKernelGGL(pk, dim3((unsigned)(n * bpr)), dim3(256), smem_p, ctx->stream, a, bpr);
+        hipLaunchKernelGGL(pk, dim3((unsigned)wg_map.size()), dim3(256), smem_p, ctx->stream, a);
         hipLaunchKernelGGL(k_batch_asym, dim3((unsigned)n), dim3(256), 2 * smem_c, ctx->stream, a);
         hipLaunchKernelGGL(k_batch_branching, dim3((unsigned)n), dim3(256), smem_c, ctx->stream, a);
         switch (poly_order + 1) {
@@ -500,7 +519,8 @@ static int run_batch_chunk(mcg_ctx* ctx, std::vector<BatchRow>& h, BatchArgs a, 
     e = hipGetLastError();
     std::vector<double> four((size_t)n * 5);
     if (e == hipSuccess) e = hipMemcpyAsync(four.data(), a.out, 5 * sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // (also: the host vector `h` has outlived its upload)
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // (also: the host vectors `h` and `wg_map` have outlived their uploads)
+    pool_release(ctx, d_map, map_bytes);
     if (e != hipSuccess) return fail(MCG_ERR_HIP, "batch run failed: %s", hipGetErrorString(e));
     for (int64_t k = 0; k < n; ++k) {
         const int64_t i = (int64_t)h[(size_t)k].id;
@@ -573,7 +593,7 @@ int run_batch_rows(mcg_ctx* ctx, const mcg_row* rows, int64_t n_rows, int n_path
                 int M = 1;
                 while (M < s.n_steps) M <<= 1;
                 const size_t need = row_workspace_bytes(s.n_steps, M);
-                if (ch.end > ch.begin && (used + need > budget || ch.end - ch.begin >= ((size_t)1 << 30))) break;
+                if (ch.end > ch.begin && (used + need > budget || ch.end - ch.begin >= ((size_t)1 << 24))) break;  // (k_batch_paths' workgroup map holds the chunk-local row in 26 bits)
                 used += need;
                 ch.bytes_S += (size_t)BATCH_LD * (size_t)(s.n_steps + 1) * sizeof(double);
                 w += (size_t)M + (size_t)s.n_steps;
