@@ -552,8 +552,13 @@ int run_branching(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double m
                 const int t_idx = ex[(size_t)e];
                 const bool branch = t_idx < ex_last && t_idx + 1 < n_cols;
                 const int ns = branch ? b_slices : 0;
-                for (int64_t l = 0; l < n_launches_b; ++l)
-                    hipLaunchKernelGGL(k, dim3(ggrid), dim3(256), lds_b, ctx->stream, a, l * per_launch_b, e, (double2*)state, e == 0, bshift, ns);
+                for (int64_t l = 0; l < n_launches_b; ++l) {
+                    // (the last generation's grid covers the paths that are left: a workgroup without a live path would still
+                    //  draw, sort and gather for the clamped ones)
+                    const int64_t left = P->n_paths - l * per_launch_b;
+                    const int g = (int)std::min<int64_t>(ggrid, (left + per_wg_b - 1) / per_wg_b);
+                    hipLaunchKernelGGL(k, dim3(g), dim3(256), lds_b, ctx->stream, a, l * per_launch_b, e, (double2*)state, e == 0, bshift, ns);
+                }
             }
             hipLaunchKernelGGL(k_branch_finish, dim3(grid), dim3(256), 0, ctx->stream, (const double2*)state, P->n_paths, ctx->partials);
         }
@@ -576,7 +581,8 @@ int run_branching(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double m
                 const int t_idx = ex[(size_t)e];
                 const bool branch = t_idx < ex_last && t_idx + 1 < n_cols;
                 for (int64_t l = 0; l < n_launches; ++l) {
-                    const dim3 g(bgrid), b(256);
+                    const int64_t left = P->n_paths - l * per_launch;
+                    const dim3 g((unsigned)std::min<int64_t>(bgrid, (left + per_wg - 1) / per_wg)), b(256);
                     const int ns = branch ? n_slices : 0;
                     if (quads == 1) hipLaunchKernelGGL(k_branch_date<1>, g, b, 0, ctx->stream, a, l * per_launch, e, (double2*)state, e == 0, slice_shift, ns);
                     else if (quads == 2) hipLaunchKernelGGL(k_branch_date<2>, g, b, 0, ctx->stream, a, l * per_launch, e, (double2*)state, e == 0, slice_shift, ns);
