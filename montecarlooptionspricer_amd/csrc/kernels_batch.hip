@@ -302,18 +302,19 @@ __global__ __launch_bounds__(256) void k_batch_branching(BatchArgs a) {
 }
 
 // ---- LSM (LSMPricer.cpp:19-102) ------------------------------------------------------------------
-// One wavefront per row, four rows per workgroup (lsm_wave_body).
+// One wavefront per row (lsm_wave_body) and -- round 5 -- one wavefront per WORKGROUP: with four rows to a workgroup the
+// workgroup lived as long as its longest row (the driver's rows run from 5 to 126 steps: the longest of four is ~100 on
+// average, the mean 66), its other three wave slots idle meanwhile; the scheduler packs single waves as they come.
 template <int NB>
-__global__ __launch_bounds__(256) void k_batch_lsm(BatchArgs a) {
-    __shared__ double ws[4][lsm_ws_doubles(NB) + LSM_COEF_DOUBLES];  // per wave: workspace of a refined date's solve
-    const int64_t r_idx = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r_idx >= a.n_rows) return;
+__global__ __launch_bounds__(64) void k_batch_lsm(BatchArgs a) {
+    __shared__ double ws[lsm_ws_doubles(NB) + LSM_COEF_DOUBLES];  // workspace of a refined date's solve
+    const int64_t r_idx = (int64_t)blockIdx.x;
     const BatchRow row = a.rows[r_idx];
     if (!row.valid) return;
     double sum_v, sum_v2;
-    lsm_wave_body<NB>(a.S + row.off, BATCH_LD, a.n_paths, row.n_steps + 1, row.strike, row.maturity, a.dt, a.disc, row.is_call,
-                      ws[threadIdx.x >> 6], sum_v, sum_v2);
-    if ((threadIdx.x & 63) == 0) a.out[4 * r_idx + 2] = sum_v / (double)a.n_paths;
+    lsm_wave_body<NB>(a.S + row.off, BATCH_LD, a.n_paths, row.n_steps + 1, row.strike, row.maturity, a.dt, a.disc, row.is_call, ws,
+                      sum_v, sum_v2);
+    if (threadIdx.x == 0) a.out[4 * r_idx + 2] = sum_v / (double)a.n_paths;
 }
 
 // ---- MartingaleOptimization (MartingaleOptimizationPricer.cpp:21-189) ----------------------------
@@ -432,7 +433,7 @@ __global__ __launch_bounds__(256) void k_batch_martingale(BatchArgs a) {
 
 template <int NB>
 static void launch_row_regressions(mcg_ctx* ctx, const BatchArgs& a, size_t smem_cols) {
-    hipLaunchKernelGGL(k_batch_lsm<NB>, dim3((unsigned)((a.n_rows + 3) / 4)), dim3(256), 0, ctx->stream, a);
+    hipLaunchKernelGGL(k_batch_lsm<NB>, dim3((unsigned)a.n_rows), dim3(64), 0, ctx->stream, a);
     hipLaunchKernelGGL(k_batch_martingale<NB>, dim3((unsigned)a.n_rows), dim3(256), smem_cols, ctx->stream, a);
 }
 
