@@ -519,7 +519,7 @@ int run_branching(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double m
     int bshift = study_switch("MCG_BRANCH_BIN_SHIFT", BR_SLICE_SHIFT);  // (A/B builds: 17 = 1 MB slices while sixteen of them cover the row)
     while ((((P->n_paths > 0 ? P->n_paths : 1) - 1) >> bshift) + 1 > 16) ++bshift;
     const int b_slices = (int)((((P->n_paths > 0 ? P->n_paths : 1) - 1) >> bshift) + 1);
-    const bool binned = b_slices > BR_DATE_MAX_SLICES && quads >= 1 && quads <= 3 && !ex.empty() && P->n_paths < ((int64_t)1 << 30) - 1 &&
+    const bool binned = b_slices > study_switch("MCG_BRANCH_BINNED_ABOVE", BR_DATE_MAX_SLICES) && quads >= 1 && quads <= 3 && !ex.empty() && P->n_paths < ((int64_t)1 << 30) - 1 &&
                         study_switch("MCG_BRANCH_BINNED", 1) != 0;
     if (binned) {
         // Paths per thread: a generation is three resident workgroups per CU of 256 x PPT paths, and a launch that is nearly
