@@ -458,11 +458,11 @@ __device__ __forceinline__ void lsm_small_body(const double* data, int64_t ld, i
     }
 }
 
-// The same sweep for one row of at most 256 paths on ONE wavefront (four paths per lane): the moments are reduced
-// with an xor butterfly, which leaves the totals in every lane, so every lane runs the identical solve and no hand-over
-// through LDS and no workgroup barrier is needed.  A 256-thread workgroup prices four rows at once; the per-date
-// critical path (reduce -> solve -> update) is latency-bound, so four independent rows per workgroup give close to
-// four times the throughput of lsm_small_body on the batched driver rows.  sum_v, sum_v2: sums of V and V^2 (all lanes).
+// The same sweep for one row of at most 256 paths on ONE wavefront (four paths per lane): the moments are reduced by the
+// folded butterfly (wave_sum_all: the totals come back wave-uniform), so every lane runs the identical solve and no
+// hand-over through LDS and no workgroup barrier is needed.  The per-date critical path (reduce -> solve -> update) is
+// latency-bound, so independent rows on the waves of a CU give close to four times the throughput of lsm_small_body on the
+// batched driver rows (k_batch_lsm: one wavefront per workgroup).  sum_v, sum_v2: sums of V and V^2 (all lanes).
 template <int NB>
 __device__ __forceinline__ void lsm_wave_body(const double* data, int64_t ld, int n, int n_cols, double K, double maturity,
                                               double dt, double disc, int is_call, double* ws /* LDS, this wave's own:
