@@ -505,16 +505,29 @@ class LastWill:
                 os._exit(code)
         os.close(r)
         self._w = os.fdopen(w, "w")
+        self._out, self._lost = json_out, False
+
+    def _send(self, tag: str, out: dict) -> None:
+        try:
+            self._w.write(tag + " " + json.dumps(out) + "\n")
+            self._w.flush()
+        except OSError:   # the guardian is gone (it should never be): this process prints the line itself at the end
+            self._lost = True
 
     def update(self, out: dict):
-        self._w.write("WILL " + json.dumps(out) + "\n")
-        self._w.flush()
+        if not self._lost:
+            self._send("WILL", out)
 
     def final(self, out: dict):
-        self._w.write("FINAL " + json.dumps(out) + "\n")
-        self._w.flush()
-        self._w.close()
-        os.waitpid(self.pid, 0)
+        if not self._lost:
+            self._send("FINAL", out)
+        try:
+            self._w.close()
+        except OSError:
+            pass
+        _, status = os.waitpid(self.pid, 0)
+        if self._lost or status != 0:
+            print(json.dumps(out), file=self._out, flush=True)
 
 
 GPU_PROCESS_GUARD = 6   # what the pool's process guard allowed on the builder's one-GPU box; a node's is not stated
