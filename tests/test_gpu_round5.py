@@ -113,3 +113,41 @@ def test_widened_pricers_match_oracle_on_the_c3_matrix(eng, orc):
     want_b = orc.branching_price(S, 0.04, 100.0, 1.0, dt, False, 10, ex, 17, mode="philox")
     assert np.allclose(got_b, want_b, rtol=1e-12, atol=1e-14), (got_b, want_b)
     P.free()
+
+
+def test_c5_full_job_on_eight_rank_threads_equals_the_unsharded_job(tmp_path):
+    """BASELINE.json configs[4] at FULL size as far as one GPU can take it: 64M rBergomi paths x 252 steps, American put, LSM
+    order 2, sharded over EIGHT ranks -- eight threads of one child process on GPU 0 (tests/thread_ranks_worker.py c5full),
+    eight 16.2 GB matrices resident together (130 GB of the 288), contiguous even-aligned path ids of one Philox stream, the
+    per-date route with one all-reduce of the 8 regression moments per exercise date over the rank threads -- against the
+    UNSHARDED 64M-path job on one context (a 129.5 GB matrix).  Every rank must hold the unsharded price (1e-9) and the same
+    bits as rank 0.  What a node adds to this is the transport (RCCL / xGMI), not the arithmetic."""
+    import json
+    import os
+    import subprocess
+    import sys
+    import torch
+    free_b, _total = torch.cuda.mem_get_info(0)
+    if free_b < (150 << 30):
+        pytest.skip(f"needs 150 GB of free device memory, {free_b >> 30} GB are free")
+    here = os.path.dirname(os.path.abspath(__file__))
+    out_file = str(tmp_path / "c5full.json")
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="16", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(here, "thread_ranks_worker.py"), "8", "callback", out_file, "c5full"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1000)
+    assert p.returncode == 0, p.stdout[-4000:]
+    ranks = json.load(open(out_file))["ranks"]
+    n, steps = 64_000_000, 252
+    assert sum(r["shard"][1] for r in ranks) == n and all(r["shard"][0] % 2 == 0 for r in ranks)
+    assert all(r["rb_lsm_sweep_launches"] == steps + 1 + 1 for r in ranks)       # the per-date kernels + the final sums
+    assert all(r["rb_lsm"] == ranks[0]["rb_lsm"] and r["rb_euro_put"] == ranks[0]["rb_euro_put"] for r in ranks)
+    e = mc.PathEngine(0)
+    P = e.rbergomi(SEED, RB["S0"], RB["r"], RB["xi"], RB["H"], RB["eta"], RB["rho"], DT, steps, n)
+    want = e.price_lsm(P, RB["r"], 100.0, steps * DT, DT, False, 2)
+    want_eu = e.price_european(P, 100.0, RB["r"], steps * DT, False)
+    P.free()
+    e.close()
+    got, got_eu = ranks[0]["rb_lsm"], ranks[0]["rb_euro_put"]
+    assert abs(got[0] - want[0]) <= 1e-9 * want[0] and abs(got[1] - want[1]) <= 1e-8 * want[1], (got, want)
+    assert abs(got_eu[0] - want_eu[0]) <= 1e-12 * want_eu[0], (got_eu, want_eu)
+    assert 2.7 < got[0] < 2.8 and got[0] > want_eu[0]                             # the C5 shard's price region; American above European

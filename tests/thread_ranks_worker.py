@@ -4,7 +4,10 @@ GPU_MAX_HW_QUEUES = 4 hardware queues by default, and two one-launch sweeps that
 each waiting for the other's moments until the hand-shake times out.  On a node every rank thread drives its own GPU and
 has that GPU's queues to itself.)
 
-    GPU_MAX_HW_QUEUES=16 python tests/thread_ranks_worker.py <world> <shm|ipc|callback> <out.json>
+    GPU_MAX_HW_QUEUES=16 python tests/thread_ranks_worker.py <world> <shm|ipc|callback> <out.json> [c5full]
+
+c5full: ONLY the rBergomi American put, at BASELINE.json configs[4]'s full size -- 64M paths x 252 steps over the ranks (8 x
+16.2 GB of matrices resident on the one GPU together), per-date route with the all-reduce over the rank threads.
 """
 import json
 import os
@@ -19,7 +22,10 @@ RB = dict(S0=100.0, r=0.04, xi=0.04, H=0.1, eta=1.9, rho=-0.9)
 JOBS = dict(euro_paths=300_001, lsm_paths=200_001, lsm_steps=50, rb_paths=100_003, rb_steps=64)
 
 
-def run_rank_threads(world, mode, tag):
+C5_FULL = dict(rb_paths=64_000_000, rb_steps=252)
+
+
+def run_rank_threads(world, mode, tag, c5_full=False):
     """Every rank a thread with a ctx of its own; returns (per-rank result dicts, per-rank all-reduce counts) or raises
     the first rank's error."""
     import numpy as np
@@ -63,6 +69,23 @@ def run_rank_threads(world, mode, tag):
                 peer = e.init_shm(f"/mcg_threads_{tag}_{os.getpid()}", rank, world, peer_mailbox=(mode == "ipc"))
             e.timing_enable(True)
             out = {}
+            jobs = dict(JOBS, **C5_FULL) if c5_full else JOBS
+            if c5_full:
+                b, c = shard_range(jobs["rb_paths"], rank, world, align=2)
+                out["shard"] = (b, c)
+                T = jobs["rb_steps"] * DT
+                P = e.rbergomi(SEED, RB["S0"], RB["r"], RB["xi"], RB["H"], RB["eta"], RB["rho"], DT, jobs["rb_steps"], c, path_begin=b)
+                e.timing_reset()
+                out["rb_lsm"] = e.price_lsm(P, RB["r"], 100.0, T, DT, False, 2)
+                out["rb_lsm_sweep_launches"] = e.timing_get(N.K_LSM_SWEEP)[1]
+                out["rb_euro_put"] = e.price_european(P, 100.0, RB["r"], T, False)
+                P.free()
+                out["comm"] = e.comm_info()
+                res[rank] = out
+                e.synchronize()
+                bar.wait()
+                e.close()
+                return
             b, c = shard_range(JOBS["euro_paths"], rank, world)
             P = e.gbm(SEED, 100.0, 0.04, 0.2, DT, 252, c, path_begin=b, payoff=(100.0, True))
             out["euro"] = e.price_european(P, 100.0, 0.04, 1.0, True)
@@ -97,7 +120,7 @@ def run_rank_threads(world, mode, tag):
     for t in th:
         t.start()
     for t in th:
-        t.join(300)
+        t.join(900 if c5_full else 300)
     if any(t.is_alive() for t in th):
         raise RuntimeError("a rank thread hangs")
     if errs:
@@ -108,7 +131,7 @@ def run_rank_threads(world, mode, tag):
 def main():
     world, mode, out_path = int(sys.argv[1]), sys.argv[2], sys.argv[3]
     import montecarlooptionspricer_amd as mc
-    ranks, calls = run_rank_threads(world, mode, f"{mode}{world}")
+    ranks, calls = run_rank_threads(world, mode, f"{mode}{world}", c5_full=len(sys.argv) > 4 and sys.argv[4] == "c5full")
     with open(out_path, "w") as f:
         json.dump({"ranks": ranks, "calls": [{"1": c.count(1), "3": c.count(3), "8": c.count(8)} for c in calls], "stats": mc.stats(),
                    "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES")}, f)
