@@ -71,6 +71,12 @@ def run_rank_threads(world, mode, tag, c5_full=False):
             out = {}
             jobs = dict(JOBS, **C5_FULL) if c5_full else JOBS
             if c5_full:
+                # C2 at the driver's N = 8 size first: 8 x 10M paths of one stream, one 3-double all-reduce
+                b, c = shard_range(80_000_000, rank, world)
+                P = e.gbm(SEED, 100.0, 0.04, 0.2, DT, 252, c, path_begin=b, payoff=(100.0, True))
+                out["euro"] = e.price_european(P, 100.0, 0.04, 1.0, True)
+                P.free()
+                e.trim()                                  # (the pool would keep the 20 GB beside the next job's 16)
                 b, c = shard_range(jobs["rb_paths"], rank, world, align=2)
                 out["shard"] = (b, c)
                 T = jobs["rb_steps"] * DT
