@@ -278,7 +278,9 @@ def test_bench_four_ranks_take_the_rows_inline_by_themselves():
     c2_paths, c5_paths = 400_000, 100_000
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "2", "--warmup", "1",
-           "--backend", "gloo", "--paths", str(c2_paths), "--c5-paths", str(c5_paths), "--c5-collectives", "none,shm,ipc"]
+           "--backend", "gloo", "--paths", str(c2_paths), "--c5-paths", str(c5_paths), "--c5-collectives", "none,shm"]
+    # (four persistent sweeps spinning on ONE card take seconds per pass: one mailbox row is enough here; the peer-memory
+    #  mailbox at four ranks is test_two_rank_processes_equal_single_rank[ipc4])
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     p = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-4000:]
@@ -288,7 +290,7 @@ def test_bench_four_ranks_take_the_rows_inline_by_themselves():
     assert out["n_gpus"] == 4 and out["config"]["c5_rows"] == "inline" and "aborted" not in out
     assert out["config"]["global_paths"] == 4 * c2_paths and out["parity"]["abs_err_over_std_err"] < 4
     rows = out["extra"]["configs"]
-    assert [r["collective_requested"] for r in rows] == ["none", "shm", "ipc"] and all("error" not in r for r in rows), rows
+    assert [r["collective_requested"] for r in rows] == ["none", "shm"] and all("error" not in r for r in rows), rows
     assert rows[1]["comm"]["n_ranks"] == 4 and rows[1]["comm"]["seen_ranks_min_over_ranks"] == 4 and rows[1]["lsm_one_launch"]
     e = mc.PathEngine(0)
     P = e.rbergomi(SEED, RB["S0"], RB["r"], RB["xi"], RB["H"], RB["eta"], RB["rho"], DT, 252, 4 * c5_paths)
