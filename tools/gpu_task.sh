@@ -55,7 +55,8 @@ two-rank)
   done ;;
 tool)      # a dev tool under tools/ plainly, its output kept: gpu_task.sh tool <tag> bench_branching.py [args]
   timeout -k 10 600 python3 tools/"$@" 2>&1 | tee $O/${T}_tool.log; guard ;;
-toolstats) # ... and under rocprofv3 --kernel-trace --stats (the per-kernel table is printed)
+toolstats) # ... and under rocprofv3 --kernel-trace --stats (the per-kernel table is printed; mind that it averages over ALL calls of
+           #     a kernel -- bench_rows.py's first call prices 64 rows: read full-call times from the kernel trace)
   timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${T}_toolstats -- python3 tools/"$@" > $O/${T}_toolstats.log 2>&1; guard || exit $?
   python3 - <<PY
 import csv, glob
