@@ -395,7 +395,6 @@ def widening_configs(eng, N, mc, baselines=None) -> list:
         rows.append(dict(S0=S0, xi=float(rs.uniform(0.01, 0.3)), H=float(rs.uniform(0.3, 0.6)), eta=float(rs.uniform(0.01, 0.06)),
                          rho=-0.3, strike=S0 * float(rs.uniform(0.9, 1.1)), maturity=st / 252.0, sigma=float(rs.uniform(0.1, 0.6)),
                          dividend=0.08, n_steps=st, is_call=int(rs.randint(0, 2))))
-    eng.batch_price_rows(rows[:64])
     arr = mc.make_rows(rows)   # the C array of mcg_row, built ONCE: what is timed below is the entry point, not its marshalling
     eng.batch_price_rows(arr, seed=1)
     eng.timing_reset()

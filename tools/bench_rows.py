@@ -25,7 +25,6 @@ for i in range(args.rows):
                      rho=-0.3, strike=S0 * float(rs.uniform(0.9, 1.1)), maturity=steps / 252.0 * 252.0 / 365.0 * 365.0 / 252.0,
                      sigma=float(rs.uniform(0.1, 0.6)), dividend=0.08, n_steps=steps, is_call=int(rs.randint(0, 2))))
 eng = mc.PathEngine(0)
-eng.batch_price_rows(rows[:64])
 arr = mc.make_rows(rows) if hasattr(mc, "make_rows") else rows   # the C array, built once (an older build through MCG_LIB: the dicts)
 eng.batch_price_rows(arr, seed=1)
 eng.timing_enable(True)
