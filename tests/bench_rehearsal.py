@@ -12,6 +12,7 @@ Failure injection (MCG_REHEARSAL_FAIL = comma-separated):
   shm_init:<rank>     that rank's init_shm raises            -> all ranks fall to rccl together
   rccl_id             rank 0 cannot create the RCCL id       -> all ranks raise together, fall to torch
   rccl_probe:<rank>   that rank cannot load librccl          -> nobody enters ncclCommInitRank, all fall to torch
+  rccl_hang:<rank>    that rank's ncclCommInitRank never returns -> the time box (MCG_BENCH_RCCL_INIT_LIMIT) closes, all fall to torch
   pass:<rank>:<want>  that rank raises in the passes of the C5 row <want> -> over the node mailbox (shm, ipc): the row fails on
                       ALL ranks, the next row runs; over the RCCL / torch route (unbounded: the peers cannot leave their
                       all-reduce) the rank ends the job with exit code 17 and the line survives with rank 0's guardian
@@ -97,6 +98,8 @@ class RehearsalEngine:
         uid = broadcast_bytes(uid)           # rank 0 ALWAYS enters the broadcast (PathEngine.init_rccl's contract)
         if not uid:
             raise mc.McgError("rank 0 could not create the RCCL id: injected", 7)
+        if _fail(f"rccl_hang:{rank}"):       # a communicator that never forms: what bench.py's time box is for
+            time.sleep(3600)
         raise mc.McgError("no HIP device: the built-in RCCL communicator cannot form on CPU ranks", 7)
 
     def init_shm(self, name, rank, world, peer_mailbox=False):

@@ -139,3 +139,16 @@ def test_the_row_budget_is_kept_by_all_ranks_together():
     out, _ = _run(4, extra=("--c5-rows", "inline", "--c5-budget", "0", "--c5-collectives", "none,shm"))
     rows = out["extra"]["configs"]
     assert len(rows) == 1 and "budget" in rows[0]["error"] and "aborted" not in out
+
+
+def test_a_communicator_that_never_forms_costs_the_collective_not_the_run():
+    """ncclCommInitRank with N > 1 has never run in this repo's history.  bench.py forms the built-in RCCL communicator on a
+    scratch context inside a time box first: a rank whose formation never returns (injected) reports so when the box closes,
+    every rank takes torch.distributed together, and the job finishes -- the hung scratch thread is a daemon."""
+    import time
+    world, t0 = 4, time.time()
+    out, err = _run(world, fail="rccl_hang:2", extra=("--c5-rows", "off"), env_extra={"MCG_BENCH_RCCL_INIT_LIMIT": "3"}, timeout=120)
+    assert time.time() - t0 < 60
+    assert out["config"]["collective"].startswith("torch (built-in RCCL init failed")
+    assert [out["ids_counted"], out["ids_summed"]] == _ids(world * 250_000)
+    assert "did not form within 3 s" in err
