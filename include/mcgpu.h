@@ -314,6 +314,7 @@ typedef struct mcg_stats_t {
     int64_t batch_rows;                /* rows priced by the row kernels                                                   */
     int64_t batch_rows_singly;         /* rows priced one by one through the single-contract entry points                 */
     int64_t batch_peak_workspace_bytes;/* largest device workspace a chunk has used                                        */
+    int64_t peer_mailbox_kept;         /* peer-memory mailboxes NOT freed at release: a same-process rank thread still held them */
 } mcg_stats_t;
 int mcg_stats(mcg_stats_t* out, int reset);
 

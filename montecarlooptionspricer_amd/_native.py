@@ -28,7 +28,8 @@ class Stats(C.Structure):
     _fields_ = [(k, C.c_int64) for k in (
         "lsm_one_launch_sweeps", "lsm_one_launch_timeouts", "lsm_per_date_sweeps", "lsm_per_date_launches",
         "lsm_per_date_refits", "lsm_per_date_faults", "shm_barrier_failures", "peer_mailbox_enabled", "peer_mailbox_refused",
-        "batch_calls", "batch_chunks", "batch_rows", "batch_rows_singly", "batch_peak_workspace_bytes")]
+        "batch_calls", "batch_chunks", "batch_rows", "batch_rows_singly", "batch_peak_workspace_bytes",
+        "peer_mailbox_kept")]
 
 
 class McgError(RuntimeError):

@@ -21,6 +21,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_SO = os.path.join(HERE, "libmcgoracle.so")
 REF_SO = os.path.join(HERE, "_ref", "libmcref.so")
 REF_DRIVER_SO = os.path.join(HERE, "_ref", "libmcref_driver.so")
+REF_EIGEN_SO = os.path.join(HERE, "_ref", "libmcref_eigen.so")   # only where an Eigen3 exists (oracle/Makefile: EIGEN_INC)
 
 _dp = C.POINTER(C.c_double)
 _u32p = C.POINTER(C.c_uint32)
@@ -530,6 +531,51 @@ class Reference:
 
 STAT_NAMES = ("S_T", "call_payoff", "put_payoff", "realised_var", "sq_ret_lag1", "sq_ret_lag8", "sq_ret_lag64",
               "integrated_var", "mean_X2", "mean_X_lag1")
+
+
+def have_ref_eigen() -> bool:
+    return os.path.exists(REF_EIGEN_SO)
+
+
+class ReferenceEigen:
+    """The reference's LSMPricer.cpp and MartingaleOptimizationPricer.cpp compiled in place against an Eigen3
+    (oracle/_ref/libmcref_eigen.so, oracle/ref_eigen_harness.cpp).  Exists only where the image has Eigen; this one does not."""
+
+    def __init__(self):
+        if not have_ref_eigen():
+            raise FileNotFoundError(REF_EIGEN_SO + " missing (built only where $(EIGEN_INC)/Eigen/Dense exists)")
+        L = C.CDLL(REF_EIGEN_SO)
+        self.L = L
+        L.ref_eigen_version.argtypes = [C.POINTER(C.c_int)]
+        L.ref_lsm_price.argtypes = [_dp, C.c_long, C.c_int] + [C.c_double] * 4 + [C.c_int, C.c_int, _dp, C.c_char_p, C.c_size_t]
+        L.ref_lsm_price.restype = C.c_int
+        L.ref_martingale_price.argtypes = [_dp, C.c_long, C.c_int] + [C.c_double] * 4 + [C.c_int, C.c_int, C.c_int, _dp, C.c_char_p,
+                                                                                      C.c_size_t]
+        L.ref_martingale_price.restype = C.c_int
+
+    def eigen_version(self):
+        v = (C.c_int * 3)()
+        self.L.ref_eigen_version(v)
+        return tuple(v)
+
+    def lsm_price(self, row_major, r, K, maturity, dt, is_call, poly_order):
+        """LSM::PredictOptionPrice (LSMPricer.cpp:19-102) on [n_paths][n_steps + 1]."""
+        a = np.ascontiguousarray(row_major, dtype=np.float64)
+        n, m = (a.shape if a.ndim == 2 else (0, 0))
+        out, err = C.c_double(), C.create_string_buffer(256)
+        if self.L.ref_lsm_price(_p(a), n, m, r, K, maturity, dt, int(bool(is_call)), int(poly_order), C.byref(out), err, 256):
+            raise RuntimeError(err.value.decode())
+        return out.value
+
+    def martingale_price(self, row_major, r, K, maturity, dt, is_call, poly_order, max_iterations=5):
+        """MartingaleOptimization::PredictOptionPrice (MartingaleOptimizationPricer.cpp:21-189)."""
+        a = np.ascontiguousarray(row_major, dtype=np.float64)
+        n, m = (a.shape if a.ndim == 2 else (0, 0))
+        out, err = C.c_double(), C.create_string_buffer(256)
+        if self.L.ref_martingale_price(_p(a), n, m, r, K, maturity, dt, int(bool(is_call)), int(poly_order), int(max_iterations),
+                                       C.byref(out), err, 256):
+            raise RuntimeError(err.value.decode())
+        return out.value
 
 
 def path_stats(step_major: np.ndarray, strike: float):

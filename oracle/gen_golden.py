@@ -4,6 +4,7 @@
 TEST INFRASTRUCTURE ONLY.  Run in the dev container (where /root/reference exists):
 
     make -C oracle && python oracle/gen_golden.py
+    make -C oracle && python oracle/gen_golden.py --eigen     # only where an Eigen3 exists: the LSM / MartingaleOptimization pin
 
 The reference has no tests and no golden vectors of its own, so every
 deterministic function on the hot path is pinned by calling the reference's own compiled code on
@@ -24,7 +25,40 @@ from oracle.binding import Reference, synthetic_history  # noqa: E402
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 
 
+def capture_eigen() -> None:
+    """--eigen: tests/golden/{lsm,martingale}.npz from the reference's LSMPricer.cpp / MartingaleOptimizationPricer.cpp compiled in
+    place against an Eigen3 (oracle/_ref/libmcref_eigen.so; `make -C oracle` builds it where $(EIGEN_INC)/Eigen/Dense exists --
+    not in the image this repo was developed in).  Every case of oracle/eigen_fixtures.py is stored as inputs + the reference's
+    price + the tolerance it will be held to; `eigen_version` records what the prices were captured with (the reference does not
+    pin one: CMakeLists.txt:17)."""
+    from oracle.binding import ReferenceEigen, have_ref_eigen
+    from oracle.eigen_fixtures import lsm_cases, martingale_cases
+    if not have_ref_eigen():
+        raise SystemExit("oracle/_ref/libmcref_eigen.so is missing: no Eigen3 was found when `make -C oracle` ran "
+                         "(set EIGEN_INC=<directory holding Eigen/Dense>); nothing captured, LSM / MartingaleOptimization stay unpinned")
+    os.makedirs(OUT, exist_ok=True)
+    ref = ReferenceEigen()
+    ver = np.array(ref.eigen_version())
+    out = {"eigen_version": ver, "names": np.array(sorted(lsm_cases()))}
+    for name, c in lsm_cases().items():
+        out[f"{name}_paths"] = c["paths"]
+        out[f"{name}_args"] = np.array([c["r"], c["K"], c["maturity"], c["dt"], c["is_call"], c["poly"], c["tol"]])
+        out[f"{name}_price"] = np.array(ref.lsm_price(c["paths"], c["r"], c["K"], c["maturity"], c["dt"], bool(c["is_call"]), c["poly"]))
+    np.savez(os.path.join(OUT, "lsm.npz"), **out)
+    out = {"eigen_version": ver, "names": np.array(sorted(martingale_cases()))}
+    for name, c in martingale_cases().items():
+        out[f"{name}_paths"] = c["paths"]
+        out[f"{name}_args"] = np.array([c["r"], c["K"], c["maturity"], c["dt"], c["is_call"], c["poly"], c["iters"], c["tol"]])
+        out[f"{name}_price"] = np.array(ref.martingale_price(c["paths"], c["r"], c["K"], c["maturity"], c["dt"], bool(c["is_call"]),
+                                                             c["poly"], c["iters"]))
+    np.savez(os.path.join(OUT, "martingale.npz"), **out)
+    print("Eigen", ".".join(map(str, ver)), "-> tests/golden/lsm.npz, tests/golden/martingale.npz")
+
+
 def main() -> None:
+    if "--eigen" in sys.argv[1:]:
+        capture_eigen()
+        return
     os.makedirs(OUT, exist_ok=True)
     ref = Reference()
 

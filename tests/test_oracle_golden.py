@@ -143,3 +143,65 @@ def test_row_features_bit_exact(orc):
         for n in (21, 22, 100, 1826):
             h = 30.0 * np.exp(np.cumsum(0.03 * rs.standard_normal(n)))
             assert orc.row_features(h) == ref.row_features(h)
+
+
+# ---- the Eigen-backed pin of LSM and MartingaleOptimization (LSMPricer.cpp:76, MartingaleOptimizationPricer.cpp:166) -------------
+# The fixtures exist only where `make -C oracle && python oracle/gen_golden.py --eigen` has run on an image with an Eigen3.  The
+# image this repo was developed in has none: the two comparisons below are skipped there, and DESIGN.md section 2 says "parity
+# unpinned" for that half of the oracle.  The recipe itself is exercised by test_eigen_recipe_is_dormant_without_eigen_and_fires_with_it.
+_NO_EIGEN = ("tests/golden/{}.npz absent: captured only where an Eigen3 exists (oracle/Makefile EIGEN_INC, oracle/gen_golden.py --eigen); "
+             "this image has none -- LSM / MartingaleOptimization parity is unpinned at the bdcSvd().solve boundary")
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(G, "lsm.npz")), reason=_NO_EIGEN.format("lsm"))
+def test_lsm_restatement_pinned_to_eigen(orc):
+    """orc_lsm_price (LSMPricer.cpp:19-102 restated with a one-sided Jacobi SVD) against the reference compiled with Eigen, case by
+    case at the tolerance stored with the case: 1e-9 where every regression has full numerical rank, 1e-6 .. 2e-5 where Eigen's
+    rank threshold decides the fit (single in-the-money path, S0 in the money at j = 0, near-coincident prices), 5e-6 at order 5."""
+    d = np.load(os.path.join(G, "lsm.npz"))
+    assert len(d["names"]) >= 15
+    for name in d["names"]:
+        r, K, maturity, dt, is_call, poly, tol = d[f"{name}_args"]
+        got = orc.lsm_price(d[f"{name}_paths"], r, K, maturity, dt, bool(is_call), int(poly), step_major=False)
+        want = float(d[f"{name}_price"])
+        assert abs(got - want) <= tol * abs(want), (str(name), got, want, tuple(d["eigen_version"]))
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(G, "martingale.npz")), reason=_NO_EIGEN.format("martingale"))
+def test_martingale_restatement_pinned_to_eigen(orc):
+    """orc_martingale_price (MartingaleOptimizationPricer.cpp:21-189) against the reference compiled with Eigen."""
+    d = np.load(os.path.join(G, "martingale.npz"))
+    assert len(d["names"]) >= 8
+    for name in d["names"]:
+        r, K, maturity, dt, is_call, poly, iters, tol = d[f"{name}_args"]
+        got = orc.martingale_price(d[f"{name}_paths"], r, K, maturity, dt, bool(is_call), int(poly), int(iters), step_major=False)[0]
+        want = float(d[f"{name}_price"])
+        assert abs(got - want) <= tol * abs(want), (str(name), got, want, tuple(d["eigen_version"]))
+
+
+def test_eigen_recipe_is_dormant_without_eigen_and_fires_with_it(tmp_path):
+    """oracle/Makefile's conditional rule, by dry run (`make -n`: nothing is compiled, no stand-in header is ever read): with no
+    Eigen/Dense under EIGEN_INC the build is what it always was; with one, the reference's LSMPricer.cpp and
+    MartingaleOptimizationPricer.cpp are compiled IN PLACE together with oracle/ref_eigen_harness.cpp into oracle/_ref/.  And the
+    fixture list the capture would run is well formed and goes through the restatement."""
+    import subprocess
+    from oracle.eigen_fixtures import lsm_cases, martingale_cases
+    here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")
+    if not os.path.exists("/root/reference/src/models/LSMPricer.cpp"):
+        pytest.skip("the reference tree is not on this machine (GPU box): the rule has nothing to compile")
+    off = subprocess.run(["make", "-n", "-B", "-C", here, "EIGEN_INC=/nonexistent"], capture_output=True, text=True, check=True).stdout
+    assert "LSMPricer.cpp" not in off and "libmcref.so" in off
+    (tmp_path / "Eigen").mkdir()
+    (tmp_path / "Eigen" / "Dense").write_text("")          # an empty marker for the wildcard; -n never opens it
+    on = subprocess.run(["make", "-n", "-B", "-C", here, f"EIGEN_INC={tmp_path}"], capture_output=True, text=True, check=True).stdout
+    line = [ln for ln in on.replace("\\\n", " ").splitlines() if "libmcref_eigen.so" in ln]
+    assert line and "/root/reference/src/models/LSMPricer.cpp" in on and "/root/reference/src/models/MartingaleOptimizationPricer.cpp" in on
+    assert f"-I{tmp_path}" in on and "ref_eigen_harness.cpp" in on
+    # the harness is valid C++ against the reference's headers (it needs Eigen only for the version macros)
+    subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-I/root/reference/include", os.path.join(here, "ref_eigen_harness.cpp")], check=True)
+    o = Oracle()
+    for c in lsm_cases().values():
+        assert np.isfinite(o.lsm_price(c["paths"], c["r"], c["K"], c["maturity"], c["dt"], bool(c["is_call"]), c["poly"], step_major=False))
+    for c in martingale_cases().values():
+        assert np.isfinite(o.martingale_price(c["paths"], c["r"], c["K"], c["maturity"], c["dt"], bool(c["is_call"]), c["poly"], c["iters"],
+                                              step_major=False)[0])

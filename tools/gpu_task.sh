@@ -8,6 +8,7 @@
 #   limiter    PMC passes that attribute the headline kernel's non-issue cycles (tools/pmc_passes.py, C2 command).  No TA_*
 #              counters: a pass with TA_TA_BUSY_sum / TA_*_STALLED_BY_TC_CYCLES_sum never returned on this pool (r5a: killed
 #              by the pass time-out after 240 s; the SQ passes before it take 2 s each)
+#   rblimiter  the same for the rBergomi generator (tools/bench_configs.py c5,c4); also lists the device's counters
 #   stats      rocprofv3 --kernel-trace --stats of the default bench -> <tag>_stats/
 #   ab A B [configs] [reps]   tools/ab_libs.sh between two built libraries
 #   tool / toolstats   a dev tool under tools/ (bench_branching.py, bench_rows.py, ...) plainly / under rocprofv3 --stats
@@ -42,6 +43,18 @@ limiter)
     --group "TCC_EA0_WRREQ_DRAM_CREDIT_STALL_sum TCC_EA0_WRREQ_LEVEL_sum TCC_TAG_STALL_sum TCC_SRC_FIFO_FULL_sum GRBM_GUI_ACTIVE" \
     --group "TCC_EA0_WRREQ_GMI_CREDIT_STALL_sum TCC_EA0_WRREQ_IO_CREDIT_STALL_sum TCC_NORMAL_WRITEBACK_sum TCC_STREAMING_REQ_sum GRBM_GUI_ACTIVE" \
     -- $C2 2>&1 | tee $O/${T}_c2lim.log; guard ;;
+rblimiter) # round 6: the same attribution for the rBergomi generator (C5 shard's <4,2,false> at 8M x 252, C4's <5,2,true> at 4M x 512)
+  rocprofv3 -L > $O/${T}_counters_avail.txt 2>&1
+  timeout -k 10 1100 python3 tools/pmc_passes.py --tag ${T}_rblim --kernels "k_rbergomi_fft<4,k_rbergomi_fft<5" \
+    --group "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" \
+    --group "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_FLAT GRBM_GUI_ACTIVE" \
+    --group "SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_LDS SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE" \
+    --group "SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM SQ_LEVEL_WAVES SQ_IFETCH SQ_IFETCH_LEVEL SQ_INSTS_BRANCH SQ_INSTS_SENDMSG GRBM_GUI_ACTIVE" \
+    --group "SQ_INST_CYCLES_VMEM_WR SQ_INST_CYCLES_SALU SQ_INST_CYCLES_SMEM SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_MISC GRBM_GUI_ACTIVE" \
+    --group "SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_LDS_MEM_VIOLATIONS SQ_LDS_ATOMIC_RETURN SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE" \
+    --group "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 GRBM_GUI_ACTIVE" \
+    --group "SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_TRANS_F32 GRBM_GUI_ACTIVE" \
+    -- python3 tools/bench_configs.py --configs c5,c4 --reps 4 2>&1 | tee $O/${T}_rblim.log; guard ;;
 stats)
   timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${T}_stats -- python3 bench.py "$@" > $O/${T}_stats.log 2>&1; rc=$?; echo "stats rc=$rc"; tail -2 $O/${T}_stats.log; exit $rc ;;
 ab)
