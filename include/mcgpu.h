@@ -315,6 +315,10 @@ typedef struct mcg_stats_t {
     int64_t batch_rows_singly;         /* rows priced one by one through the single-contract entry points                 */
     int64_t batch_peak_workspace_bytes;/* largest device workspace a chunk has used                                        */
     int64_t peer_mailbox_kept;         /* peer-memory mailboxes NOT freed at release: a same-process rank thread still held them */
+    int64_t coalesced_rounds;          /* class-API calls of several host threads answered together: rounds (one set of launches each) */
+    int64_t coalesced_calls;           /* ... and the calls they answered                                                  */
+    int64_t coalesced_peak_calls_per_round; /* most calls one round has answered                                           */
+    int64_t coalesced_fallbacks;       /* class-API calls that took the calling thread's own context instead (shape beyond the row kernels, coalescing off) */
 } mcg_stats_t;
 int mcg_stats(mcg_stats_t* out, int reset);
 

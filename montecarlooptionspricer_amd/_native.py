@@ -29,7 +29,7 @@ class Stats(C.Structure):
         "lsm_one_launch_sweeps", "lsm_one_launch_timeouts", "lsm_per_date_sweeps", "lsm_per_date_launches",
         "lsm_per_date_refits", "lsm_per_date_faults", "shm_barrier_failures", "peer_mailbox_enabled", "peer_mailbox_refused",
         "batch_calls", "batch_chunks", "batch_rows", "batch_rows_singly", "batch_peak_workspace_bytes",
-        "peer_mailbox_kept")]
+        "peer_mailbox_kept", "coalesced_rounds", "coalesced_calls", "coalesced_peak_calls_per_round", "coalesced_fallbacks")]
 
 
 class McgError(RuntimeError):

@@ -20,6 +20,9 @@
 #include <cmath>
 #include <vector>
 
+#include <cstring>
+
+#include "coalesce.hpp"
 #include "lsm_device.hpp"
 #include "mcg_internal.hpp"
 #include "rbergomi_device.hpp"
@@ -35,6 +38,7 @@ struct BatchRow {  // device image of one option row
     int64_t off;   // its block of the path matrix: S[off + 256 j + p]
     int64_t woff;  // its amplitudes w[woff .. woff + M), compensator w[woff + M .. woff + M + n_steps)
     uint64_t id;   // its index in the caller's array: Philox path ids (id << 32) + p
+    uint32_t k0, k1;  // its Philox key: the call's seed (mcg_batch_price_rows) or the row's own (coalesced class-API calls, coalesce.hpp)
     int n_steps, M, is_call, valid;
 };
 constexpr int64_t BATCH_LD = 256;  // columns of a row's block (n_paths <= 256)
@@ -127,8 +131,8 @@ __global__ __launch_bounds__(256, MCG_BATCH_PATHS_WAVES) void k_batch_paths(Batc
     g.n_steps = row.n_steps;
     g.M = row.M;
     g.path_begin = row.id << 32;
-    g.k0 = a.k0;
-    g.k1 = a.k1;
+    g.k0 = row.k0;
+    g.k1 = row.k1;
     g.S0 = row.S0;
     g.logS0 = row.logS0;
     g.r = a.r;
@@ -251,7 +255,7 @@ __global__ __launch_bounds__(256) void k_batch_branching(BatchArgs a) {
     const bool live = p < a.n_paths;
     const double* col = a.S + row.off + (live ? p : 0);
     const uint64_t id = (row.id << 32) + (uint64_t)p;
-    const PhiloxLane lane_rng = philox_lane_setup(id, 2u, a.k1);
+    const PhiloxLane lane_rng = philox_lane_setup(id, 2u, row.k1);
     const int quads = (a.num_branches + 3) >> 2;
     const double inv_b = a.num_branches > 0 ? 1.0 / (double)a.num_branches : 0.0;
     const int ex_last = row.n_steps - 1;
@@ -282,7 +286,7 @@ __global__ __launch_bounds__(256) void k_batch_branching(BatchArgs a) {
             if (e < ex_last && a.num_branches > 0) {
                 double sum = 0.0;
                 for (int q = 0; q < quads; ++q) {
-                    const Philox4 w = philox4x32_10_lane(lane_rng, (uint32_t)(e * quads + q), a.k0, a.k1);
+                    const Philox4 w = philox4x32_10_lane(lane_rng, (uint32_t)(e * quads + q), row.k0, row.k1);
                     const uint32_t ws[4] = {w.w0, w.w1, w.w2, w.w3};
 #pragma unroll
                     for (int s = 0; s < 4; ++s)
@@ -657,6 +661,8 @@ int run_batch_rows(mcg_ctx* ctx, const mcg_row* rows, int64_t n_rows, int n_path
                 d.sigma = s.sigma;
                 d.dividend = s.dividend;
                 d.id = (uint64_t)i;
+                d.k0 = a.k0;
+                d.k1 = a.k1;
                 d.n_steps = s.n_steps;
                 d.is_call = s.is_call;
                 d.valid = 1;
@@ -706,5 +712,312 @@ int run_batch_rows(mcg_ctx* ctx, const mcg_row* rows, int64_t n_rows, int n_path
     }
     return MCG_OK;
 }
+
+
+// =================================================================================================================
+// Coalesced class-API calls (coalesce.hpp): one ROUND = the calls of many host threads, grouped by kind, through the
+// row kernels above.  The requests' matrices live in per-thread slots of one arena (a slot = one row block of this
+// file's layout: step-major, 256 columns); generated paths and prices return through device-visible pinned host memory,
+// written by the kernels themselves -- a round costs ONE upload (its descriptors), its launches and ONE synchronisation.
+// =================================================================================================================
+namespace co {
+
+struct Xfer {  // one matrix between a slot and its owner's pinned buffer
+    int64_t slot_off;
+    double* host;  // [n_paths][n_cols] path-major, device-visible
+    int n_paths, n_cols;
+};
+constexpr int CO_TILE = 16;  // columns (dates) of one transposed tile: a path's piece of it is 128 contiguous bytes on the host side
+
+// slot (step-major, 256 columns) -> the owner's host buffer (path-major: the reference's vector<vector<double>> order)
+__global__ __launch_bounds__(256) void k_co_gather(const Xfer* x, const double* S, int tiles_max) {
+    __shared__ double tile[CO_TILE][BATCH_LD + 1];
+    const Xfer d = x[blockIdx.x / tiles_max];
+    const int j0 = (int)(blockIdx.x % tiles_max) * CO_TILE;
+    if (j0 >= d.n_cols) return;
+    const int nj = min(CO_TILE, d.n_cols - j0);
+    const double* blk = S + d.slot_off;
+    const int p = threadIdx.x;
+    for (int jj = 0; jj < nj; ++jj) tile[jj][p] = blk[(int64_t)(j0 + jj) * BATCH_LD + p];
+    __syncthreads();
+    const int jj = p & (CO_TILE - 1);
+    if (jj < nj)
+        for (int q = p / CO_TILE; q < d.n_paths; q += 256 / CO_TILE) d.host[(int64_t)q * d.n_cols + j0 + jj] = tile[jj][q];
+}
+
+// the owner's host buffer -> its slot (a pricer called with a matrix the slot does not hold)
+__global__ __launch_bounds__(256) void k_co_scatter(const Xfer* x, double* S, int tiles_max) {
+    __shared__ double tile[CO_TILE][BATCH_LD + 1];
+    const Xfer d = x[blockIdx.x / tiles_max];
+    const int j0 = (int)(blockIdx.x % tiles_max) * CO_TILE;
+    if (j0 >= d.n_cols) return;
+    const int nj = min(CO_TILE, d.n_cols - j0);
+    double* blk = S + d.slot_off;
+    const int p = threadIdx.x;
+    const int jj = p & (CO_TILE - 1);
+    if (jj < nj)
+        for (int q = p / CO_TILE; q < d.n_paths; q += 256 / CO_TILE) tile[jj][q] = d.host[(int64_t)q * d.n_cols + j0 + jj];
+    __syncthreads();
+    for (int k = 0; k < nj; ++k) blk[(int64_t)(j0 + k) * BATCH_LD + p] = p < d.n_paths ? tile[k][p] : 0.0;
+}
+
+namespace {
+
+struct Key {  // what the requests of one launch must share
+    int kind, n_paths, cls, a, b;
+    double r, dt;
+    bool operator==(const Key& o) const {
+        return kind == o.kind && n_paths == o.n_paths && cls == o.cls && a == o.a && b == o.b && r == o.r && dt == o.dt;
+    }
+    bool operator<(const Key& o) const {
+        if (kind != o.kind) return kind < o.kind;
+        if (n_paths != o.n_paths) return n_paths < o.n_paths;
+        if (cls != o.cls) return cls < o.cls;
+        if (a != o.a) return a < o.a;
+        if (b != o.b) return b < o.b;
+        if (r != o.r) return r < o.r;
+        return dt < o.dt;
+    }
+};
+
+Key key_of(const Request& q) {
+    Key k{q.kind, q.n_paths, 0, 0, 0, q.r, q.dt};
+    switch (q.kind) {
+        case GEN: k.cls = lds_class(q.M); k.r = 0.04; k.dt = 1.0 / 252.0; break;  // RoughVolatility.cpp:321-326
+        case BRANCH: k.a = q.num_branches; break;
+        case LSM: k.a = q.poly_order; break;
+        case MART: k.a = q.poly_order; k.b = q.max_iterations >= 2 ? 2 : 1; break;  // (k_batch_martingale: iteration 1 has M = 0, every later one the fitted M)
+        default: break;
+    }
+    return k;
+}
+
+int grow(RoundBuffers& rb, size_t bytes, size_t n_req) {
+    if (bytes > rb.cap) {
+        const size_t cap = std::max<size_t>(bytes * 2, (size_t)1 << 20);
+        if (rb.h) (void)hipHostFree(rb.h);
+        if (rb.d) (void)hipFree(rb.d);
+        rb.h = rb.d = nullptr;
+        rb.cap = 0;
+        MCG_HIP(hipHostMalloc((void**)&rb.h, cap, hipHostMallocDefault));
+        MCG_HIP(hipMalloc((void**)&rb.d, cap));
+        rb.cap = cap;
+    }
+    if (n_req > rb.out_cap) {
+        const size_t cap = std::max<size_t>(n_req * 2, 1024);
+        if (rb.h_out) (void)hipHostFree(rb.h_out);
+        if (rb.d_scratch) (void)hipFree(rb.d_scratch);
+        rb.h_out = rb.d_scratch = nullptr;
+        rb.out_cap = 0;
+        MCG_HIP(hipHostMalloc((void**)&rb.h_out, cap * 4 * sizeof(double), hipHostMallocDefault));
+        MCG_HIP(hipMalloc((void**)&rb.d_scratch, cap * sizeof(double)));
+        rb.out_cap = cap;
+    }
+    return MCG_OK;
+}
+
+template <int NB>
+void launch_lsm_rows(mcg_ctx* ctx, const BatchArgs& a) {
+    hipLaunchKernelGGL(k_batch_lsm<NB>, dim3((unsigned)a.n_rows), dim3(64), 0, ctx->stream, a);
+}
+template <int NB>
+void launch_martingale_rows(mcg_ctx* ctx, const BatchArgs& a, size_t smem_c) {
+    hipLaunchKernelGGL(k_batch_martingale<NB>, dim3((unsigned)a.n_rows), dim3(256), smem_c, ctx->stream, a);
+}
+
+int run_round(mcg_ctx* ctx, RoundBuffers& rb, double* arena_base, Request** reqs, int n) {
+    MCG_HIP(hipSetDevice(ctx->device));
+    // ---- order the requests by launch group -------------------------------------------------------------------
+    std::vector<int> order((size_t)n);
+    std::vector<Key> keys((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        order[(size_t)i] = i;
+        keys[(size_t)i] = key_of(*reqs[i]);
+    }
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return keys[(size_t)x] < keys[(size_t)y]; });
+    // ---- layout of the round's descriptors: [BatchRow x n][w][wg_map][Xfer x (generated + uploaded)] ------------
+    size_t w_doubles = 0, n_map = 0, n_gen = 0, n_up = 0;
+    for (int i = 0; i < n; ++i) {
+        const Request& q = *reqs[i];
+        if (q.kind == GEN) {
+            w_doubles += (size_t)q.M + (size_t)q.n_steps;
+            const int ppb = rb_pairs_per_block(q.M);
+            n_map += (size_t)(((q.n_paths + 1) / 2 + ppb - 1) / ppb);
+            ++n_gen;
+        } else if (q.upload) {
+            ++n_up;
+        }
+    }
+    const size_t off_rows = 0;
+    const size_t off_w = off_rows + sizeof(BatchRow) * (size_t)n;
+    const size_t off_map = off_w + sizeof(double) * (w_doubles + (w_doubles & 1));
+    const size_t off_x = (off_map + sizeof(uint32_t) * n_map + 15) & ~(size_t)15;
+    const size_t total = off_x + sizeof(Xfer) * (n_gen + n_up);
+    int rc = grow(rb, total, (size_t)n);
+    if (rc) return rc;
+    BatchRow* h_rows = reinterpret_cast<BatchRow*>(rb.h + off_rows);
+    double* h_w = reinterpret_cast<double*>(rb.h + off_w);
+    uint32_t* h_map = reinterpret_cast<uint32_t*>(rb.h + off_map);
+    Xfer* h_x = reinterpret_cast<Xfer*>(rb.h + off_x);
+    const BatchRow* d_rows = reinterpret_cast<const BatchRow*>(rb.d + off_rows);
+    double* d_w = reinterpret_cast<double*>(rb.d + off_w);
+    const uint32_t* d_map = reinterpret_cast<const uint32_t*>(rb.d + off_map);
+    const Xfer* d_x = reinterpret_cast<const Xfer*>(rb.d + off_x);
+    double* out_dev = nullptr;
+    MCG_HIP(hipHostGetDevicePointer((void**)&out_dev, rb.h_out, 0));
+
+    struct Group {
+        Key key;
+        int begin, end;        // positions in `order`
+        size_t map_begin, map_n;
+        int max_steps, m_max;
+    };
+    std::vector<Group> groups;
+    size_t woff = 0, mpos = 0, xg = 0, xu = n_gen;  // generated matrices' transfers first, then the uploads
+    int up_tiles = 1, gen_tiles = 1;
+    for (int pos = 0; pos < n; ++pos) {
+        const int i = order[(size_t)pos];
+        const Request& q = *reqs[i];
+        const Key& k = keys[(size_t)i];
+        if (groups.empty() || !(groups.back().key == k)) groups.push_back(Group{k, pos, pos, mpos, 0, 1, 1});
+        Group& g = groups.back();
+        g.end = pos + 1;
+        BatchRow d{};
+        d.S0 = q.S0;
+        d.logS0 = q.kind == GEN ? std::log(q.S0) : 0.0;
+        d.xi = q.xi;
+        d.H = q.H;
+        d.eta = q.eta;
+        d.strike = q.strike;
+        d.maturity = q.maturity;
+        d.sigma = q.sigma;
+        d.dividend = q.dividend;
+        d.off = q.slot_off;
+        d.id = 0;  // Philox path ids 0 .. n_paths - 1: what mcg_paths_rbergomi / mcg_price_branching use for a matrix that begins at path 0
+        d.k0 = (uint32_t)q.seed;
+        d.k1 = (uint32_t)(q.seed >> 32);
+        d.n_steps = q.n_steps;
+        d.is_call = q.is_call;
+        d.valid = 1;
+        d.M = 1;
+        while (d.M < d.n_steps) d.M <<= 1;
+        g.max_steps = std::max(g.max_steps, d.n_steps);
+        g.m_max = std::max(g.m_max, d.M);
+        const int n_cols = q.n_steps + 1;
+        if (q.kind == GEN) {
+            d.woff = (int64_t)woff;
+            std::memcpy(h_w + woff, q.amp, sizeof(double) * (size_t)q.M);
+            std::memcpy(h_w + woff + q.M, q.comp, sizeof(double) * (size_t)q.n_steps);
+            woff += (size_t)q.M + (size_t)q.n_steps;
+            const int ppb = rb_pairs_per_block(q.M);
+            const int shares = ((q.n_paths + 1) / 2 + ppb - 1) / ppb;
+            for (int sub = 0; sub < shares; ++sub) h_map[mpos++] = ((uint32_t)(pos - g.begin) << 6) | (uint32_t)sub;
+            g.map_n += (size_t)shares;
+            double* hp = nullptr;
+            MCG_HIP(hipHostGetDevicePointer((void**)&hp, q.host, 0));
+            h_x[xg++] = Xfer{q.slot_off, hp, q.n_paths, n_cols};
+            gen_tiles = std::max(gen_tiles, (n_cols + CO_TILE - 1) / CO_TILE);
+        } else if (q.upload) {
+            double* hp = nullptr;
+            MCG_HIP(hipHostGetDevicePointer((void**)&hp, q.host, 0));
+            h_x[xu++] = Xfer{q.slot_off, hp, q.n_paths, n_cols};
+            up_tiles = std::max(up_tiles, (n_cols + CO_TILE - 1) / CO_TILE);
+        }
+        h_rows[pos] = d;
+    }
+    MCG_HIP(hipMemcpyAsync(rb.d, rb.h, total, hipMemcpyHostToDevice, ctx->stream));
+    // ---- launches ---------------------------------------------------------------------------------------------
+    if (n_up) hipLaunchKernelGGL(k_co_scatter, dim3((unsigned)(n_up * (size_t)up_tiles)), dim3(256), 0, ctx->stream, d_x + n_gen, arena_base, up_tiles);
+    for (const Group& g : groups) {
+        BatchArgs a{};
+        a.rows = d_rows + g.begin;
+        a.n_rows = g.end - g.begin;
+        a.n_paths = g.key.n_paths;
+        a.max_steps = g.max_steps;
+        a.m_max = g.m_max;
+        a.r = g.key.r;
+        a.dt = g.key.dt;
+        a.sqdt = std::sqrt(a.dt);
+        a.disc = std::exp(-a.r * a.dt);
+        a.w = d_w;
+        a.S = arena_base;
+        a.log_tab = (const double2*)ctx->log_tab;
+        a.out = out_dev + 4 * (size_t)g.begin;
+        a.bad = rb.d_scratch + g.begin;
+        a.wg_map = d_map + g.map_begin;
+        a.num_branches = g.key.a;
+        a.max_iterations = g.key.b == 1 ? 1 : 5;
+        const size_t smem_c = ((size_t)g.max_steps + 1) * sizeof(double);
+        switch (g.key.kind) {
+            case GEN: {
+                size_t smem_p = 0;
+                for (int m = 1; m <= g.m_max; m <<= 1) smem_p = std::max(smem_p, rb_smem_bytes(m, std::min(m, g.max_steps)));
+                typedef void (*PathsKernel)(BatchArgs);
+                static const PathsKernel paths_kernel[N_LDS_CLASSES] = {k_batch_paths<0>, k_batch_paths<1>, k_batch_paths<2>, k_batch_paths<3>};
+                const PathsKernel pk = paths_kernel[g.key.cls];
+                if (smem_p > 48 * 1024) (void)hipFuncSetAttribute((const void*)pk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_p);
+                hipLaunchKernelGGL(pk, dim3((unsigned)g.map_n), dim3(256), smem_p, ctx->stream, a);
+                break;
+            }
+            case ASYM: hipLaunchKernelGGL(k_batch_asym, dim3((unsigned)a.n_rows), dim3(256), 2 * smem_c, ctx->stream, a); break;
+            case BRANCH: hipLaunchKernelGGL(k_batch_branching, dim3((unsigned)a.n_rows), dim3(256), smem_c, ctx->stream, a); break;
+            case LSM:
+                switch (g.key.a + 1) {
+                    case 1: launch_lsm_rows<1>(ctx, a); break;
+                    case 2: launch_lsm_rows<2>(ctx, a); break;
+                    case 3: launch_lsm_rows<3>(ctx, a); break;
+                    case 4: launch_lsm_rows<4>(ctx, a); break;
+                    default: launch_lsm_rows<5>(ctx, a); break;
+                }
+                break;
+            default:
+                switch (g.key.a + 1) {
+                    case 1: launch_martingale_rows<1>(ctx, a, smem_c); break;
+                    case 2: launch_martingale_rows<2>(ctx, a, smem_c); break;
+                    case 3: launch_martingale_rows<3>(ctx, a, smem_c); break;
+                    case 4: launch_martingale_rows<4>(ctx, a, smem_c); break;
+                    default: launch_martingale_rows<5>(ctx, a, smem_c); break;
+                }
+                break;
+        }
+    }
+    if (n_gen) hipLaunchKernelGGL(k_co_gather, dim3((unsigned)(n_gen * (size_t)gen_tiles)), dim3(256), 0, ctx->stream, d_x, (const double*)arena_base, gen_tiles);
+    MCG_HIP(hipGetLastError());
+    MCG_HIP(hipStreamSynchronize(ctx->stream));
+    static const int column[N_KINDS] = {0, 0, 1, 2, 3};
+    for (int pos = 0; pos < n; ++pos) {
+        Request& q = *reqs[order[(size_t)pos]];
+        q.status = MCG_OK;
+        if (q.kind != GEN) q.price = rb.h_out[4 * (size_t)pos + column[q.kind]];
+    }
+    g_stats.coalesced_rounds.fetch_add(1, std::memory_order_relaxed);
+    g_stats.coalesced_calls.fetch_add(n, std::memory_order_relaxed);
+    int64_t seen = g_stats.coalesced_peak_calls_per_round.load(std::memory_order_relaxed);
+    while (n > seen && !g_stats.coalesced_peak_calls_per_round.compare_exchange_weak(seen, n, std::memory_order_relaxed)) {
+    }
+    return MCG_OK;
+}
+
+}  // namespace
+
+int execute_round(mcg_ctx* ctx, RoundBuffers& rb, double* arena_base, Request** reqs, int n) {
+    int rc;
+    try {
+        rc = run_round(ctx, rb, arena_base, reqs, n);
+    } catch (const std::exception& e) {
+        rc = fail(MCG_ERR_OOM, "coalesced round: %s", e.what());
+    }
+    if (rc != MCG_OK) {
+        (void)hipStreamSynchronize(ctx->stream);  // nothing of this round may still be writing into the requesters' buffers
+        const char* msg = mcg_last_error();
+        for (int i = 0; i < n; ++i) {
+            reqs[i]->status = rc;
+            std::snprintf(reqs[i]->err, sizeof reqs[i]->err, "%s", msg ? msg : "coalesced round failed");
+        }
+    }
+    return rc;
+}
+
+}  // namespace co
 
 }  // namespace mcg

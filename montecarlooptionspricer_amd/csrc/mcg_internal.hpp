@@ -35,7 +35,8 @@ inline int study_switch(const char* name, int fallback) {
 struct Stats {
     std::atomic<int64_t> lsm_one_launch_sweeps{0}, lsm_one_launch_timeouts{0}, lsm_per_date_sweeps{0}, lsm_per_date_launches{0},
         lsm_per_date_refits{0}, lsm_per_date_faults{0}, shm_barrier_failures{0}, peer_mailbox_enabled{0}, peer_mailbox_refused{0},
-        batch_calls{0}, batch_chunks{0}, batch_rows{0}, batch_rows_singly{0}, batch_peak_workspace_bytes{0}, peer_mailbox_kept{0};
+        batch_calls{0}, batch_chunks{0}, batch_rows{0}, batch_rows_singly{0}, batch_peak_workspace_bytes{0}, peer_mailbox_kept{0},
+        coalesced_rounds{0}, coalesced_calls{0}, coalesced_peak_calls_per_round{0}, coalesced_fallbacks{0};
 };
 extern Stats g_stats;
 

@@ -443,6 +443,12 @@ __device__ __forceinline__ void rb_fft_block(const RbArgs& a, const RbLds& L, in
                 pb[v] = fma(pb[v - 1], ib[v], pb[v - 1]);
             }
             // exclusive product scan of the lane totals over g = 0..G-1 (lanes c, c+P, c+2P, ...)
+            // (Round 6, profiles/r06_rb_limiter.json: by ablation these 1 + LG dependent lane exchanges are 6-7 % of the kernel.
+            // Hoisting the scans of all NT tiles of a share into one phase -- 2 NT chains in flight together -- was tried and
+            // LOST 1.5-3.3 %, bit-identical output: profiles/r06_rb_batched_scan_attempt.diff.)
+#ifdef RB_ABL_NO_SCAN   // (timing study only: tools/build_variant.sh abl_scan kernels_rbergomi.hip -DRB_ABL_NO_SCAN)
+            double la = 1.0, lb = 1.0;
+#else
             double la = __shfl_up(pa[3], P, 64), lb = __shfl_up(pb[3], P, 64);
             if (g == 0) {
                 la = 1.0;
@@ -455,6 +461,7 @@ __device__ __forceinline__ void rb_fft_block(const RbArgs& a, const RbLds& L, in
                 la *= __shfl(la, src, 64);
                 lb *= __shfl(lb, src, 64);
             }
+#endif
             const double base_a = S_a * la, base_b = S_b * lb;
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
@@ -475,9 +482,16 @@ __device__ __forceinline__ void rb_fft_block(const RbArgs& a, const RbLds& L, in
                     default: break;
                 }
             }
+#ifdef RB_ABL_NO_SCAN
+            S_a = last_a + (double)src_g * 1e-300;
+            S_b = last_b;
+#else
             S_a = __shfl(last_a, src_g * P + c, 64);
             S_b = __shfl(last_b, src_g * P + c, 64);
+#endif
+#ifndef RB_ABL_NO_BARRIER   // (timing study only: the tile barrier's share of the waiting -- none, r06_rb_limiter.json)
             __syncthreads();
+#endif
             // write-out: the tile is 4G rows x PW pairs = 1024 16-byte units, four per thread (rows wr_row + i G); a
             // wavefront store covers 64 / PW complete rows of PW * 16 contiguous bytes.  Columns are never masked: rows
             // are padded to 256 columns and a workgroup's 2 PW columns divide that, so the columns behind n_paths
