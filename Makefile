@@ -64,7 +64,13 @@ build/thread_ranks_driver: tests/cpp/thread_ranks_driver.cpp $(LIB) $(HDRS)
 	g++ -O2 -std=c++17 -fopenmp -Iinclude tests/cpp/thread_ranks_driver.cpp -o $@ \
 	    -L$(PKG)/lib -lmcgpu -Wl,-rpath,'$$ORIGIN/../$(PKG)/lib' -Wl,-rpath-link,/opt/rocm/lib
 
-cpp: build/dropin_driver build/batch_driver build/thread_ranks_driver
+# the reference driver's row loop, unchanged in shape, as a measured workload (bench.py's "unchanged driver" row; tests/test_gpu_round6.py)
+build/unchanged_driver: tests/cpp/unchanged_driver.cpp $(LIB) $(HDRS)
+	@mkdir -p build
+	g++ -O2 -std=c++17 -fopenmp -Iinclude tests/cpp/unchanged_driver.cpp -o $@ \
+	    -L$(PKG)/lib -lmcgpu -Wl,-rpath,'$$ORIGIN/../$(PKG)/lib' -Wl,-rpath-link,/opt/rocm/lib
+
+cpp: build/dropin_driver build/batch_driver build/thread_ranks_driver build/unchanged_driver
 .PHONY: cpp
 
 # Static check of the device assembly for the gfx940+ hazards hipcc does not cover inside inline-asm statements

@@ -256,6 +256,14 @@ int mcg_rbergomi_spectrum(double H, double eta, double dt, int n_steps, double* 
  * LSM::PredictOptionPrice(pricePaths, r, strike, maturity, dt, isCall, polyOrder).
  * Both use a lazily created per-thread ctx on device 0 (MCG_DEVICE overrides). */
 int mcg_compat_set_seed(uint64_t seed, int enabled); /* default: std::random_device per call */
+/* Calls of the class API that arrive from DIFFERENT host threads while a round of them is on the device are answered
+ * together: one launch per kind of call over all of them (the row kernels of mcg_batch_price_rows, one workgroup per
+ * matrix), the reference's driver unchanged (src/core/PredictionGen.cpp:542-570, :736-737, :788-791: one row per OpenMP
+ * thread, five calls per row).  Shapes the row kernels serve -- at most 256 paths, 1 .. 1020 steps, polynomial order <= 4,
+ * BranchingProcesses with the driver's exercise dates 0 .. steps - 1; anything else, or everything after
+ * mcg_compat_set_coalescing(0), runs on the calling thread's own context as before.  On by default; a lone caller is a round
+ * of one.  mcg_stats counts rounds, calls and fall-backs. */
+int mcg_compat_set_coalescing(int enabled);
 int mcg_compat_generate_paths(const double* hist, size_t n, int forward_steps, int path_num,
                               double* row_major_out);
 int mcg_compat_lsm_price(const double* row_major, int64_t n_paths, int n_cols, double r,
@@ -319,6 +327,9 @@ typedef struct mcg_stats_t {
     int64_t coalesced_calls;           /* ... and the calls they answered                                                  */
     int64_t coalesced_peak_calls_per_round; /* most calls one round has answered                                           */
     int64_t coalesced_fallbacks;       /* class-API calls that took the calling thread's own context instead (shape beyond the row kernels, coalescing off) */
+    int64_t coalesced_round_us;        /* wall time of the rounds, summed (packing + upload + launches + synchronisation), microseconds */
+    int64_t coalesced_device_wait_us;  /* ... of which inside hipStreamSynchronize                                          */
+    int64_t coalesced_wake_us;         /* time the leaders spent waking the callers they had answered (overlaps the next round) */
 } mcg_stats_t;
 int mcg_stats(mcg_stats_t* out, int reset);
 

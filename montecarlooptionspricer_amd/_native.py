@@ -29,7 +29,8 @@ class Stats(C.Structure):
         "lsm_one_launch_sweeps", "lsm_one_launch_timeouts", "lsm_per_date_sweeps", "lsm_per_date_launches",
         "lsm_per_date_refits", "lsm_per_date_faults", "shm_barrier_failures", "peer_mailbox_enabled", "peer_mailbox_refused",
         "batch_calls", "batch_chunks", "batch_rows", "batch_rows_singly", "batch_peak_workspace_bytes",
-        "peer_mailbox_kept", "coalesced_rounds", "coalesced_calls", "coalesced_peak_calls_per_round", "coalesced_fallbacks")]
+        "peer_mailbox_kept", "coalesced_rounds", "coalesced_calls", "coalesced_peak_calls_per_round", "coalesced_fallbacks",
+        "coalesced_round_us", "coalesced_device_wait_us", "coalesced_wake_us")]
 
 
 class McgError(RuntimeError):
@@ -138,6 +139,7 @@ def load_library():
     L.mcg_estimate_params.argtypes = [dp, C.c_size_t, dp]
     L.mcg_rbergomi_spectrum.argtypes = [C.c_double, C.c_double, C.c_double, C.c_int, dp, dp, C.POINTER(C.c_int)]
     L.mcg_compat_set_seed.argtypes = [C.c_uint64, C.c_int]
+    L.mcg_compat_set_coalescing.argtypes = [C.c_int]
     L.mcg_compat_generate_paths.argtypes = [dp, C.c_size_t, C.c_int, C.c_int, dp]
     L.mcg_compat_lsm_price.argtypes = [dp, C.c_int64, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double,
                                        C.c_int, C.c_int, dp]

@@ -33,6 +33,12 @@ def set_compat_seed(seed: int | None) -> None:
     check(L.mcg_compat_set_seed(0 if seed is None else int(seed), 0 if seed is None else 1))
 
 
+def set_compat_coalescing(enabled: bool) -> None:
+    """Answer class-API calls of different host threads together (mcg_compat_set_coalescing; on by default)."""
+    L = N.load_library()
+    check(L.mcg_compat_set_coalescing(1 if enabled else 0))
+
+
 class RoughVolatility:
     def GenerateStockPricePaths(self, historical_prices, forward_steps: int, path_num: int):
         L = N.load_library()

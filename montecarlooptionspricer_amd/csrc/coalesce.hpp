@@ -38,6 +38,7 @@ struct Request {
     int n_paths = 0, n_steps = 0;
     int64_t slot_off = 0;
     double* host = nullptr;
+    double* host_dev = nullptr;  // the same buffer as the device addresses it (hipHostGetDevicePointer)
     bool upload = false;  // pricers: the slot does not hold this matrix yet -- fill it from `host` first
     // GEN (RoughVolatility.cpp:312-368 with the estimates made on the requester's thread)
     double S0 = 0, xi = 0, H = 0, eta = 0;
@@ -60,6 +61,7 @@ struct RoundBuffers {
     unsigned char* d = nullptr;   // device copy
     size_t cap = 0;
     double* h_out = nullptr;      // pinned, device-visible: [max_requests][4] prices as the kernels write them
+    double* d_out = nullptr;      // ... as the device addresses it
     double* d_scratch = nullptr;  // device: per-request flags nobody reads back
     size_t out_cap = 0;           // requests
 };

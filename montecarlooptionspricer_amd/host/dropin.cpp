@@ -19,6 +19,7 @@
 
 #include "../../include/mcgpu/dropin.hpp"
 #include "../csrc/mcg_internal.hpp"
+#include "coalesce_host.hpp"
 
 namespace {
 
@@ -72,6 +73,9 @@ struct ThreadCtx {
 };
 thread_local ThreadCtx t_ctx;
 
+// Calls of different host threads are answered together (csrc/coalesce.hpp) unless mcg_compat_set_coalescing(0) said otherwise.
+std::atomic<bool> g_coalesce{true};
+
 std::atomic<bool> g_seed_fixed{false};
 std::atomic<uint64_t> g_seed{0};
 
@@ -117,6 +121,33 @@ mcg_paths* device_matrix(const std::vector<std::vector<double>>& pricePaths, con
     return own.p;
 }
 
+// ---- the coalesced route (csrc/coalesce.hpp): shapes the row kernels serve -- at most 256 paths, 1..1020 steps ----------
+bool co_shape(size_t n_paths, size_t n_cols) {
+    return g_coalesce.load(std::memory_order_relaxed) && n_paths >= 1 && n_paths <= (size_t)mcg::co::MAX_PATHS && n_cols >= 2 &&
+           n_cols <= (size_t)mcg::co::MAX_STEPS + 1;
+}
+
+void took_own_context() { mcg::g_stats.coalesced_fallbacks.fetch_add(1, std::memory_order_relaxed); }
+
+// A pricer call through the combiner: the thread's slot when it holds exactly this matrix (compared element by element),
+// otherwise the matrix goes up with the request.  q carries the pricer's own arguments.
+double co_price(const std::vector<std::vector<double>>& pricePaths, const char* ragged_msg, mcg::co::Request& q) {
+    const size_t N = pricePaths.size(), M = pricePaths[0].size();
+    for (const auto& row : pricePaths)
+        if (row.size() < M) throw std::runtime_error(ragged_msg);
+    mcg::co::ThreadState& t = mcg::co::thread_state();
+    q.n_paths = (int)N;
+    q.n_steps = (int)M - 1;
+    q.upload = false;
+    if (!t.holds(pricePaths, M)) {
+        if (t.prepare((int)N, (int)M) != MCG_OK) raise_last();
+        for (size_t i = 0; i < N; ++i) std::memcpy(t.pinned + i * M, pricePaths[i].data(), M * sizeof(double));
+        q.upload = true;
+    }
+    if (t.submit(q) != MCG_OK) raise_last();
+    return q.price;
+}
+
 }  // namespace
 
 RoughVolatility::RoughVolatility() {}
@@ -145,13 +176,38 @@ std::vector<std::vector<double>> RoughVolatility::GenerateStockPricePaths(
         return paths;
     }
 
+    const size_t cols = (size_t)forward_steps + 1;
+    if (co_shape((size_t)path_num, cols) && S0 > 0.0) {
+        // Coalesced: the estimates and the spectrum are this thread's work; the generator launch, shared with whatever other
+        // threads are asking at the moment, is the round leader's.  Same kernel code, same Philox ids (seed, paths 0 ..
+        // path_num - 1) and the same host-made amplitudes as mcg_paths_rbergomi: the same matrix bit for bit.
+        std::vector<double> amp, comp;
+        if (mcg::host_rbergomi_spectrum(H, eta, dt, forward_steps, amp, comp) != MCG_OK) raise_last();
+        mcg::co::ThreadState& t = mcg::co::thread_state();
+        if (t.prepare(path_num, (int)cols) != MCG_OK) raise_last();
+        mcg::co::Request q;
+        q.kind = mcg::co::GEN;
+        q.n_paths = path_num;
+        q.n_steps = forward_steps;
+        q.S0 = S0;
+        q.xi = xi;
+        q.H = H;
+        q.eta = eta;
+        q.seed = next_seed();
+        q.amp = amp.data();
+        q.comp = comp.data();
+        q.M = (int)amp.size();
+        if (t.submit(q) != MCG_OK) raise_last();
+        for (size_t i = 0; i < (size_t)path_num; ++i) paths[i].assign(t.pinned + i * cols, t.pinned + (i + 1) * cols);
+        return paths;  // (the slot keeps the matrix for the pricers that come next, PredictionGen.cpp:788-791)
+    }
+    took_own_context();
     mcg_ctx* ctx = t_ctx.get();
     PathsGuard g;
     if (mcg_paths_rbergomi(ctx, next_seed(), S0, r, xi, H, eta, rho, dt, forward_steps, 0, path_num, &g.p) != MCG_OK)
         raise_last();
     std::vector<double> flat((size_t)path_num * ((size_t)forward_steps + 1));
     if (mcg_paths_to_host(g.p, flat.data()) != MCG_OK) raise_last();
-    const size_t cols = (size_t)forward_steps + 1;
     for (size_t i = 0; i < (size_t)path_num; ++i) paths[i].assign(flat.begin() + i * cols, flat.begin() + (i + 1) * cols);
     if (flat.size() * sizeof(double) <= ThreadCtx::CACHE_MAX_BYTES)
         t_ctx.remember(g.release(), (size_t)path_num, cols, std::move(flat));  // the pricers come next
@@ -165,6 +221,18 @@ double LSM::PredictOptionPrice(const std::vector<std::vector<double>>& pricePath
     // (raw monomials beyond S^15 at S ~ 100 span more than thirty orders of magnitude: the reference's own solve keeps a
     // handful of singular directions of them; orders up to 15 are served and checked against the restated reference)
     if (polyOrder < 0 || polyOrder > 15) throw std::invalid_argument("LSM: polyOrder must be in [0, 15]");
+    if (polyOrder <= 4 && dt > 0.0 && co_shape(pricePaths.size(), pricePaths[0].size())) {
+        mcg::co::Request q;
+        q.kind = mcg::co::LSM;
+        q.r = r;
+        q.strike = strike;
+        q.maturity = maturity;
+        q.dt = dt;
+        q.is_call = isCall ? 1 : 0;
+        q.poly_order = polyOrder;
+        return co_price(pricePaths, "LSM: Invalid path index in regression", q);
+    }
+    took_own_context();
     PathsGuard own;
     mcg_paths* P = device_matrix(pricePaths, "LSM: Invalid path index in regression", own);
     double price = 0.0;
@@ -182,6 +250,19 @@ double AsymptoticAnalysis::PredictOptionPrice(const std::vector<std::vector<doub
     for (const auto& row : pricePaths)
         if (row.size() != M) return 0.0;                                               // :57-61
     try {
+        if (co_shape(pricePaths.size(), M)) {
+            mcg::co::Request q;
+            q.kind = mcg::co::ASYM;
+            q.r = r;
+            q.strike = strike;
+            q.maturity = maturity;
+            q.dt = dt;
+            q.is_call = isCall ? 1 : 0;
+            q.sigma = sigma;
+            q.dividend = dividend;
+            return co_price(pricePaths, "AsymptoticAnalysis: ragged pricePaths.", q);
+        }
+        took_own_context();
         PathsGuard own;
         mcg_paths* P = device_matrix(pricePaths, "AsymptoticAnalysis: ragged pricePaths.", own);
         double price = 0.0;
@@ -200,6 +281,19 @@ double MartingaleOptimization::PredictOptionPrice(const std::vector<std::vector<
         throw std::runtime_error("MartingaleOptimization: Empty pricePaths.");                      // :31-33
     if (maxIterations <= 0) throw std::runtime_error("MartingaleOptimization: maxIterations must be positive.");  // :34-36
     if (polyOrder < 0 || polyOrder > 15) throw std::invalid_argument("MartingaleOptimization: polyOrder must be in [0, 15]");
+    if (polyOrder <= 4 && strike != 0.0 && co_shape(pricePaths.size(), pricePaths[0].size())) {
+        mcg::co::Request q;
+        q.kind = mcg::co::MART;
+        q.r = r;
+        q.strike = strike;
+        q.maturity = maturity;
+        q.dt = dt;
+        q.is_call = isCall ? 1 : 0;
+        q.poly_order = polyOrder;
+        q.max_iterations = maxIterations;
+        return co_price(pricePaths, "MartingaleOptimization: ragged pricePaths.", q);
+    }
+    took_own_context();
     PathsGuard own;
     mcg_paths* P = device_matrix(pricePaths, "MartingaleOptimization: ragged pricePaths.", own);
     double price = 0.0;
@@ -215,6 +309,23 @@ double BranchingProcesses::PredictOptionPrice(const std::vector<std::vector<doub
     if (pricePaths.empty() || pricePaths[0].empty()) throw std::runtime_error("BranchingProcesses: Empty pricePaths.");
     if (exerciseTimes.empty()) throw std::runtime_error("BranchingProcesses: No exercise times.");
     if (strike <= 0.0) throw std::runtime_error("BranchingProcesses: Strike must be positive.");
+    // the row kernel walks the driver's exercise dates 0 .. steps - 1 (PredictionGen.cpp:780-783); any other list takes the
+    // single-contract kernels on this thread's own context
+    bool driver_dates = exerciseTimes.size() + 1 == pricePaths[0].size() && numBranches >= 0 && numBranches <= 1024;
+    for (size_t i = 0; driver_dates && i < exerciseTimes.size(); ++i) driver_dates = exerciseTimes[i] == (int)i;
+    if (driver_dates && co_shape(pricePaths.size(), pricePaths[0].size())) {
+        mcg::co::Request q;
+        q.kind = mcg::co::BRANCH;
+        q.r = r;
+        q.strike = strike;
+        q.maturity = maturity;
+        q.dt = dt;
+        q.is_call = isCall ? 1 : 0;
+        q.num_branches = numBranches;
+        q.seed = next_seed();
+        return co_price(pricePaths, "BranchingProcesses: ragged pricePaths.", q);
+    }
+    took_own_context();
     PathsGuard own;
     mcg_paths* P = device_matrix(pricePaths, "BranchingProcesses: ragged pricePaths.", own);
     double price = 0.0;
@@ -284,6 +395,11 @@ int mcg_compat_asymptotic_price(const double* row_major, int64_t n_paths, int n_
     } catch (const std::exception& e) {
         return mcg::fail(MCG_ERR_INVALID, "%s", e.what());
     }
+}
+
+int mcg_compat_set_coalescing(int enabled) {
+    g_coalesce.store(enabled != 0);
+    return MCG_OK;
 }
 
 int mcg_compat_set_seed(uint64_t seed, int enabled) {

@@ -183,3 +183,97 @@ def test_device_lsm_and_martingale_match_the_eigen_fixtures(eng):
         P.free()
         want = float(d[f"{name}_price"])
         assert abs(got - want) <= max(tol, 1e-8) * abs(want), (str(name), got, want)
+
+
+# ---- the reference's driver unchanged: calls of many host threads answered together (csrc/coalesce.hpp) -----------------------
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run_unchanged_driver(n_rows, threads, coalesce, out_file, timeout=600):
+    import json
+    import subprocess
+    subprocess.run(["make", "build/unchanged_driver"], cwd=ROOT, check=True, stdout=subprocess.DEVNULL)
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), OMP_DYNAMIC="false")
+    res = subprocess.run([os.path.join(ROOT, "build", "unchanged_driver"), str(n_rows), str(coalesce), out_file], capture_output=True,
+                         text=True, env=env, timeout=timeout)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    line = json.loads(res.stdout.strip().splitlines()[-1])
+    rows = np.loadtxt(out_file)
+    assert rows.shape == (n_rows, 6)
+    return line, rows
+
+
+def test_unchanged_driver_128_threads_equals_the_single_thread_run(tmp_path):
+    """tests/cpp/unchanged_driver.cpp = the row loop of src/core/PredictionGen.cpp:542-570 / :736-737 / :788-791 against the
+    reference's own headers: 128 OpenMP threads, each constructing the five classes per row and calling them in turn, 1 500 rows
+    of 250 paths x 5..126 steps under mcg_compat_set_seed.  Calls of different threads are answered in shared launches
+    (coalesced rounds); the prices of every row must equal -- to the last bit -- those of the same program run on ONE thread
+    (rounds of one call), rows that throw in the reference's classes (a one-price history, sigma = 0) must come out as
+    exceptions per row, not as a failed run, and nothing may dead-lock (the run is timed out)."""
+    n = 1500
+    one, a = _run_unchanged_driver(n, 1, 1, str(tmp_path / "one.txt"))
+    many, b = _run_unchanged_driver(n, 128, 1, str(tmp_path / "many.txt"))
+    assert many["threads"] == 128 and one["threads"] == 1
+    assert np.array_equal(a, b), np.argwhere(a != b)[:5]
+    threw = a[:, 1] == 1
+    expect = np.array([(i % 211 == 17) or (i % 257 == 29) for i in range(n)])
+    assert np.array_equal(threw, expect)
+    assert np.all(a[threw, 2:] == 0.0) and np.all(a[~threw, 2:] >= 0.0) and np.all(np.isfinite(a))
+    assert one["priced"] == many["priced"] == n - int(expect.sum())
+    # ... and against the per-thread route (every call a launch and a synchronisation on the calling thread's own context:
+    # the single-contract kernels instead of the row kernels): the same prices to 1e-9
+    _legacy, c = _run_unchanged_driver(300, 8, 0, str(tmp_path / "legacy.txt"))
+    assert np.array_equal(c[:, :2], a[:300, :2])
+    assert np.allclose(c[:, 2:], a[:300, 2:], rtol=1e-9, atol=1e-12), np.max(np.abs(c[:, 2:] - a[:300, 2:]))
+
+
+def test_coalesced_calls_of_python_threads_match_sequential_calls(orc):
+    """Sixteen host threads (ctypes releases the GIL around every call) hammer the class API with DIFFERENT matrices and kinds
+    at once -- generated paths, uploaded matrices the slot has never seen, all four pricers, orders 0..4, calls the row
+    kernels do not serve (300 paths; order 7; a custom exercise-date list) in between -- and every answer must equal the one
+    the same call gives alone.  mcg_stats must show rounds that answered several calls."""
+    import threading
+    from oracle.binding import synthetic_history
+    mc.set_compat_seed(77)
+    mc.stats(reset=True)
+    hists = [synthetic_history(300 + 40 * k, seed=k + 1) for k in range(16)]
+
+    def work(k, out):
+        rv, lsm, aa, mo, bp = mc.RoughVolatility(), mc.LSM(), mc.AsymptoticAnalysis(), mc.MartingaleOptimization(), mc.BranchingProcesses()
+        res = []
+        for it in range(6):
+            steps = 5 + 17 * ((k + it) % 7)
+            n_paths = 300 if (k + it) % 11 == 0 else 250 - (k % 5)
+            p = rv.GenerateStockPricePaths(hists[k], steps, n_paths)
+            K = float(hists[k][-1]) * (1.0 + 0.02 * ((k % 5) - 2))
+            T = steps / 252.0
+            res.append(float(p.sum()))
+            res.append(aa.PredictOptionPrice(p, 0.04, K, T, DT, k % 2 == 0, 0.2 + 0.01 * k, 0.08))
+            res.append(lsm.PredictOptionPrice(p, 0.04, K, T, DT, k % 2 == 1, (k + it) % 5))
+            res.append(mo.PredictOptionPrice(p, 0.04, K, T, DT, False, 2, 1 + (it % 3)))
+            res.append(bp.PredictOptionPrice(p, 0.04, K, T, DT, False, 10, list(range(steps))))
+            q = p[::-1].copy() * 1.01                        # a matrix the thread's slot has never seen
+            res.append(lsm.PredictOptionPrice(q, 0.04, K, T, DT, False, 2))
+            res.append(lsm.PredictOptionPrice(q, 0.04, K, T, DT, False, 7))                      # order 7: the thread's own context
+            res.append(bp.PredictOptionPrice(q, 0.04, K, T, DT, False, 10, list(range(0, steps, 2))))   # custom dates: likewise
+            res.append(aa.PredictOptionPrice(p, 0.04, K, T, DT, False, 0.3, 0.0))                # back to the first matrix
+        out[k] = res
+
+    alone = {}
+    for k in range(16):
+        work(k, alone)
+    s0 = mc.stats(reset=True)
+    assert s0["coalesced_calls"] > 0 and s0["coalesced_peak_calls_per_round"] == 1 and s0["coalesced_fallbacks"] > 0
+    together = {}
+    threads = [threading.Thread(target=work, args=(k, together)) for k in range(16)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not any(t.is_alive() for t in threads)
+    s1 = mc.stats()
+    mc.set_compat_seed(None)
+    for k in range(16):
+        assert together[k] == alone[k], (k, [i for i, (x, y) in enumerate(zip(together[k], alone[k])) if x != y][:5])
+    assert s1["coalesced_calls"] == s0["coalesced_calls"] and s1["coalesced_rounds"] < s1["coalesced_calls"]
+    assert s1["coalesced_peak_calls_per_round"] >= 2
