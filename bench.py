@@ -45,11 +45,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
-N_SIMDS = 1024         # 256 CUs x 4 SIMDs
-SEED = 20251031
-DT = 1.0 / 252.0
-RB = dict(S0=100.0, r=0.04, xi=0.04, H=0.1, eta=1.9, rho=-0.9)
+from tools.bench_common import DT, HBM_PEAK_GBS, RB, SEED  # noqa: E402
+from tools.bench_extra import (extra_configs, reference_parity, rough_regime_parity, unchanged_driver_row,  # noqa: E402
+                               widening_configs)
+from tools.bench_multirank import (GPU_PROCESS_GUARD, Gpu, LastWill, c5_rows_in_child_job, c5_rows_inline,  # noqa: E402
+                                   c5_rows_mode, c5_sharded_rows, install_collective)
 
 
 def bs_call(S0, K, r, sigma, T):
@@ -164,707 +164,6 @@ def cpu_baselines_widened(budget_s: float = 3.0) -> dict:
                                         "steps, then AsymptoticAnalysis and BranchingProcesses of the compiled reference and the restated LSM and "
                                         f"MartingaleOptimization), omp parallel for schedule(dynamic) over rows as PredictionGen.cpp:542-823, {sec:.1f} s"}
     return out
-
-
-def reference_parity(eng, mc, ref_price: dict, n_steps: int, seed: int) -> dict:
-    """|price - ref| / MC-std-err against the compiled reference itself: the engine prices the same contract
-    (rBergomi with the parameters the reference estimates from the same history, same step count, K = S0) and is
-    set beside the mean payoff of the reference's own sample from the cpu_baseline leg."""
-    p = mc.estimate_params(ref_price["history"])
-    n, parts = 4_000_000, 4   # 16M paths of the seed's stream, four launches (the matrix of one is 8 GB)
-    K = ref_price["strike"]
-    means, ses = [], []
-    for k in range(parts):
-        P = eng.rbergomi(seed, p["S0"], 0.04, p["xi"], p["H"], p["eta"], p["rho"], 1.0 / 252.0, n_steps, n, path_begin=k * n,
-                         payoff=(K, True))
-        m, s = eng.price_european(P, K, 0.0, 0.0, True)  # r = 0: undiscounted mean payoff
-        P.free()
-        means.append(m)
-        ses.append(s)
-    price = sum(means) / parts
-    se = math.sqrt(sum(x * x for x in ses)) / parts
-    n = n * parts
-    comb = math.hypot(se, ref_price["std_err"])
-    return {"contract": f"rBergomi European call, K = S0 = {K:.4f}, {n_steps} steps, parameters estimated from the "
-                        "1001-point synthetic history (xi=%.5f H=%.4f eta=%.4f)" % (p["xi"], p["H"], p["eta"]),
-            "gpu_mean_payoff": price, "gpu_std_err": se, "gpu_paths": n,
-            "reference_mean_payoff": ref_price["mean_payoff"], "reference_std_err": ref_price["std_err"],
-            "reference_paths": ref_price["paths"],
-            "abs_diff_over_combined_std_err": abs(price - ref_price["mean_payoff"]) / comb if comb > 0 else None}
-
-
-def rough_regime_parity(eng) -> dict:
-    """C4 / C5 parameters against the committed sample of the compiled reference (tests/golden/
-    rough_regime_reference.json, oracle/gen_rough_fixture.py): undiscounted call and put at 252 and 512 steps."""
-    path = os.path.join(ROOT, "tests", "golden", "rough_regime_reference.json")
-    if not os.path.exists(path):
-        return {}
-    fx = json.load(open(path))
-    p, out = fx["params"], {}
-    for steps in ("252", "512"):
-        fix = fx["samples"][steps]
-        for is_call, idx, name in ((True, 1, "call"), (False, 2, "put")):
-            P = eng.rbergomi(SEED, p["S0"], p["r"], p["xi"], p["H"], p["eta"], p["rho"], DT, int(steps), 4_000_000,
-                             payoff=(p["strike"], is_call))
-            m, se = eng.price_european(P, p["strike"], 0.0, 0.0, is_call)
-            P.free()
-            out[f"{name}_{steps}_steps"] = {"gpu": m, "gpu_std_err": se, "reference": fix["mean"][idx],
-                                            "reference_std_err": fix["std_err"][idx], "reference_paths": fix["paths"],
-                                            "abs_diff_over_combined_std_err":
-                                                abs(m - fix["mean"][idx]) / math.hypot(se, fix["std_err"][idx])}
-    return out
-
-
-def valu_profile(name: str):
-    """Committed PMC summary of a kernel (profiles/*_valu_counters.json): VALU instructions per launch at the profiled
-    path count and the shader clock measured in the same passes.  None when no profile is committed."""
-    best = None
-    pdir = os.path.join(ROOT, "profiles")
-    for f in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
-        if f.endswith("_valu_counters.json") and name in f:
-            best = os.path.join(pdir, f)  # sorted: the latest round wins
-    if not best:
-        return None
-    try:
-        j = json.load(open(best))
-        return {"insts": j["counters_mean_per_launch"]["SQ_INSTS_VALU"], "clock_GHz": j["derived"]["shader_clock_GHz"],
-                "paths": j.get("paths_per_launch"), "source": os.path.relpath(best, ROOT)}
-    except Exception:
-        return None
-
-
-def extra_configs(eng, N, baselines=None) -> list:
-    """C3, C4 and the C5 shard on this GPU, once each (one untimed pass, then 5 timed for the wall time -- the median -- and 3 more with
-    per-kernel HIP events), after the headline loop: ms per pass, Mpaths/s, the dominant kernel's average launch time and what it achieves against the HBM roofline
-    (SURVEY 8d algorithmic bytes) and against the VALU issue rate (instruction count from the committed PMC profile)."""
-    reps = 3
-    out = []
-
-    def c3():
-        P = eng.gbm(SEED, 100.0, 0.04, 0.2, 0.02, 50, 1_000_000)
-        r = eng.price_lsm(P, 0.04, 100.0, 1.0, 0.02, False, 2)
-        P.free()
-        return r
-
-    def c4():
-        P = eng.rbergomi(SEED, RB["S0"], RB["r"], RB["xi"], RB["H"], RB["eta"], RB["rho"], DT, 512, 4_000_000, payoff=(100.0, True))
-        r = eng.price_european(P, 100.0, RB["r"], 512 * DT, True)
-        P.free()
-        return r
-
-    def c5():
-        P = eng.rbergomi(SEED, RB["S0"], RB["r"], RB["xi"], RB["H"], RB["eta"], RB["rho"], DT, 252, 8_000_000)
-        r = eng.price_lsm(P, RB["r"], 100.0, 1.0, DT, False, 2)
-        P.free()
-        return r
-
-    # (name, pass, paths, time steps / exercise dates, {kernel: SURVEY 8(d) algorithmic bytes of all its launches in one pass})
-    specs = [
-        ("C3: American put, LSM order 2, GBM, 1M paths x 50 exercise dates", c3, 1_000_000, 50,
-         {"gbm": 8.0 * 51 * 1_000_000, "lsm_sweep": 40.0 * 50 * 1_000_000}),
-        ("C4: rBergomi European call (H=0.1), 4M paths x 512 steps", c4, 4_000_000, 512, {"rbergomi": 8.0 * 513 * 4_000_000}),
-        ("C5 shard: rBergomi American put LSM order 2, 8M paths x 252 steps (1/8 of the 64M job)", c5, 8_000_000, 252,
-         {"rbergomi": 8.0 * 253 * 8_000_000, "lsm_sweep": 40.0 * 252 * 8_000_000}),
-    ]
-    for name, fn, paths, steps, alg in specs:
-        fn()
-        eng.synchronize()
-        # wall time WITHOUT the library's event timing (a HIP-event pair per launch costs ~9 us: 7 % of a C3 pass), then
-        # the same passes again with it, for the per-kernel breakdown
-        eng.timing_enable(False)
-        walls = []
-        for _ in range(2 * reps - 1):   # every pass ends in the price coming back: it can be timed by itself; the MEDIAN of five, so
-            t0 = time.perf_counter()    # that one host hiccup (3 ms once, on a 0.4-ms pass) does not become the row's number
-            res = fn()
-            walls.append((time.perf_counter() - t0) * 1e3)
-        eng.synchronize()
-        ms = sorted(walls)[len(walls) // 2]
-        eng.timing_enable(True)
-        eng.timing_reset()
-        for _ in range(reps):
-            fn()
-        eng.synchronize()
-        kernels = {}
-        for k, kname in N.KERNEL_NAMES.items():
-            tot, cnt = eng.timing_get(k)
-            if cnt:
-                kernels[kname] = {"ms_per_pass": tot / reps, "launches_per_pass": cnt // reps}
-        # Against the HBM roofline by the bytes each kernel MOVES.  Generators: SURVEY 8(d)'s 8 (steps + 1) B per path, all
-        # written (counters: 1.00x, profiles/*_pmc_traffic.json).  LSM sweep: what the one-launch kernels stream by construction
-        # -- every row once with the values in registers (8 B per path and date, k_lsm_coop, <= 2.09M paths = 512 workgroups x
-        # 4096) or twice through the LDS ring (16 B, k_lsm_big: counters 32.47 GB against 32.26, profiles/r04_c5_pmc_traffic.json);
-        # V never touches memory.  SURVEY 8(d)'s 40 B per path and date is the two-pass formulation's traffic, which these
-        # kernels do not generate: it is kept for context only and no fraction is formed with it.
-        for kname, b in alg.items():
-            if kname in kernels:
-                moved = b
-                if kname == "lsm_sweep":
-                    kernels[kname]["survey_two_pass_bytes_per_pass"] = b
-                    moved = (8.0 if paths <= 2_097_152 else 16.0) * steps * paths
-                kernels[kname]["bytes_moved_per_pass"] = moved
-                kernels[kname]["hbm_frac"] = moved / (kernels[kname]["ms_per_pass"] * 1e-3) / 1e9 / HBM_PEAK_GBS
-        dom = max(alg, key=lambda k: kernels.get(k, {}).get("ms_per_pass", 0.0))
-        row = {"config": name, "paths": paths, "ms_per_pass": ms, "Mpaths_per_s": paths / ms / 1e3,
-               "price": res[0], "std_err": res[1], "kernels": kernels, "dominant_kernel": dom,
-               "dominant_kernel_ms_per_pass": kernels[dom]["ms_per_pass"], "hbm_frac": kernels[dom].get("hbm_frac"),
-               "bound": "valu-issue (fp64; generation_valu_issue_frac)" if dom == "rbergomi" else "hbm"}
-        if dom == "lsm_sweep" and paths <= 2_097_152:
-            # one launch, one grid-wide exchange of the regression moments per exercise date: at 1M paths a date's 8 MB stream in
-            # ~1 us and the exchange costs several -- the sweep is bound by that latency, not by HBM
-            row["bound"] = "latency (one grid-wide moment exchange per exercise date inside the launch)"
-            row["us_per_exercise_date"] = kernels[dom]["ms_per_pass"] * 1e3 / steps
-        if baselines and "lsm_sweep" in kernels and "lsm" in baselines:
-            row["cpu_baseline"] = dict(baselines["lsm"], gpu_comparable="paths / kernels.lsm_sweep.ms_per_pass",
-                                       gpu_value=paths / kernels["lsm_sweep"]["ms_per_pass"] / 1e3)
-        if "rbergomi" in kernels:  # the generator is issue-bound: VALU instructions x 4 cycles against SIMD-cycles available
-            vp = valu_profile("c4" if steps == 512 else "c5gen")
-            if vp and vp.get("paths"):
-                g = kernels["rbergomi"]["ms_per_pass"]
-                insts = vp["insts"] * paths / vp["paths"]
-                row["generation_valu_issue_frac"] = insts * 4.0 / (N_SIMDS * vp["clock_GHz"] * 1e9 * g * 1e-3)
-                row["valu_source"] = (f"{vp['source']}: SQ_INSTS_VALU per launch scaled to {paths} paths x 4 cycles / "
-                                      f"({N_SIMDS} SIMDs x {vp['clock_GHz']:.2f} GHz measured there x kernel time measured here)")
-        out.append(row)
-    return out
-
-
-def widening_configs(eng, N, mc, baselines=None) -> list:
-    """SURVEY 8(f) rows in this round's terms: the three other pricers of the reference's driver on the C3 matrix
-    (GBM, 1M paths x 50 dates, device-resident) and the batched driver rows (20 000 option rows x 250 rBergomi paths, four
-    prices each), once each after one untimed pass: device ms of the pricer's kernels (HIP events), the bytes its
-    streams move by construction and the HBM fraction that makes."""
-    import numpy as np
-    out, reps = [], 3
-    n, steps, dt = 1_000_000, 50, 0.02
-    mat = 8.0 * (steps + 1) * n   # one read of the matrix
-    P = eng.gbm(SEED, 100.0, 0.04, 0.2, dt, steps, n)
-    ex = list(range(steps))       # the driver passes 0..steps-1 (PredictionGen.cpp:780-783)
-    specs = [
-        ("asymptotic", "AsymptoticAnalysis::PredictOptionPrice (put, sigma 0.2, dividend 0) on the C3 matrix", N.K_ASYM,
-         lambda: eng.price_asymptotic(P, 0.04, 100.0, 1.0, dt, False, 0.2, 0.0), mat,
-         "one read of the matrix (k_asym_scan)"),
-        ("martingale", "MartingaleOptimization::PredictOptionPrice (put, order 2, 5 iterations) on the C3 matrix", N.K_MARTINGALE,
-         lambda: eng.price_martingale(P, 0.04, 100.0, 1.0, dt, False, 2, 5)[0], 2.0 * mat + 8.0 * n,
-         "two reads of the matrix (primal + moments, dual) and one of row 0"),
-        ("branching", "BranchingProcesses::PredictOptionPrice (put, 10 branches, 50 exercise dates) on the C3 matrix", N.K_BRANCHING,
-         lambda: eng.price_branching(P, 0.04, 100.0, 1.0, dt, False, 10, ex, SEED)[0], 3.0 * mat + 8.0 * 10 * steps * n,
-         "suffix maxima: read S, write F; bounds: read S + 10 random 8-byte gathers in F per path and date (rows of F are 8 MB: L2 / MALL hits, counted as moved)"),
-    ]
-    for key, name, kid, fn, moved, what in specs:
-        fn()
-        eng.synchronize()
-        eng.timing_reset()
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            price = fn()
-        eng.synchronize()
-        wall = (time.perf_counter() - t0) / reps * 1e3
-        ms, cnt = eng.timing_get(kid)
-        out.append({"config": name, "paths": n, "ms_per_call": wall, "price": price,
-                    "kernel_ms_per_call": ms / reps, "launches_per_call": cnt // reps, "bytes_moved_per_call": moved,
-                    "bytes_moved": what, "hbm_frac": moved / (ms / reps * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                    "Mpaths_per_s_of_device_time": n / (ms / reps) / 1e3})
-        if baselines and key in baselines:
-            out[-1]["cpu_baseline"] = dict(baselines[key], gpu_comparable="Mpaths_per_s_of_device_time")
-    P.free()
-    # BranchingProcesses on rows of F beyond one L2 (VERDICT r4, next #5): 4M paths x 50 dates, rows of 32 MB, the binned
-    # per-date kernel (k_branch_date_binned).  What bounds it is stated with the row: every generation of resident paths
-    # pulls the whole row through the L2 of every XCD.
-    n4 = 4_000_000
-    P4 = eng.gbm(SEED, 100.0, 0.04, 0.2, dt, steps, n4)
-    eng.price_branching(P4, 0.04, 100.0, 1.0, dt, False, 10, ex, SEED)
-    eng.synchronize()
-    eng.timing_reset()
-    for _ in range(reps):
-        price4 = eng.price_branching(P4, 0.04, 100.0, 1.0, dt, False, 10, ex, SEED)[0]
-    eng.synchronize()
-    ms4, cnt4 = eng.timing_get(N.K_BRANCHING)
-    P4.free()
-    moved4 = 3.0 * 8.0 * (steps + 1) * n4 + 8.0 * 10 * steps * n4
-    out.append({"config": "BranchingProcesses::PredictOptionPrice (put, 10 branches, 50 exercise dates) on a 4M x 50 GBM matrix (rows of F: 32 MB, 16 slices)",
-                "paths": n4, "price": price4, "kernel_ms_per_call": ms4 / reps, "launches_per_call": cnt4 // reps,
-                "bytes_moved_per_call": moved4, "bytes_moved": "as the C3-matrix row above: S read twice, F written, 10 gathers of 8 B per path and date",
-                "hbm_frac": moved4 / (ms4 / reps * 1e-3) / 1e9 / HBM_PEAK_GBS, "Mpaths_per_s_of_device_time": n4 / (ms4 / reps) / 1e3,
-                "bound": "L2 fill: the gathers of a generation of resident paths (590k-786k) touch every line of the 32 MB row in every XCD's L2 "
-                         "(counters: profiles/r05_branching_binned_counters.json)"})
-    rs = np.random.RandomState(0)   # the row mix of tools/bench_rows.py: 5..126 steps, calls and puts around the money
-    rows = []
-    for _ in range(20_000):
-        st = int(rs.randint(5, 127))
-        S0 = float(rs.uniform(20, 400))
-        rows.append(dict(S0=S0, xi=float(rs.uniform(0.01, 0.3)), H=float(rs.uniform(0.3, 0.6)), eta=float(rs.uniform(0.01, 0.06)),
-                         rho=-0.3, strike=S0 * float(rs.uniform(0.9, 1.1)), maturity=st / 252.0, sigma=float(rs.uniform(0.1, 0.6)),
-                         dividend=0.08, n_steps=st, is_call=int(rs.randint(0, 2))))
-    arr = mc.make_rows(rows)   # the C array of mcg_row, built ONCE: what is timed below is the entry point, not its marshalling
-    eng.batch_price_rows(arr, seed=1)
-    eng.timing_reset()
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        pr = eng.batch_price_rows(arr, seed=1)
-    wall = (time.perf_counter() - t0) / reps * 1e3
-    ms, cnt = eng.timing_get(N.K_BATCH)
-    cols = sum(r["n_steps"] + 1 for r in rows)
-    # row blocks written once by the generator; read once each by AsymptoticAnalysis, BranchingProcesses (its suffix maxima stay in
-    # registers / LDS since round 3) and LSM, twice by MartingaleOptimization (primal and dual scan)
-    moved = 8.0 * 250 * cols * (1 + 5)
-    out.append({"config": "mcg_batch_price_rows: 20 000 driver rows x 250 rBergomi paths (5-126 steps), four prices per row",
-                "rows": len(rows), "ms_per_call": wall, "rows_per_s": len(rows) / wall * 1e3, "kernel_ms_per_call": ms / reps,
-                "rows_per_s_of_device_time": len(rows) / (ms / reps) * 1e3, "launches_per_call": 6 * cnt // reps, "chunks_per_call": cnt // reps,
-                "timed": "mcg_batch_price_rows on a prebuilt array of mcg_row (upload, kernels, download, scatter); device time = the chunks' kernel spans",
-                "bytes_moved_per_call": moved,
-                "bytes_moved": "row blocks written once by the generator, read once each by AsymptoticAnalysis, BranchingProcesses and LSM, twice by "
-                               "MartingaleOptimization (primal and dual scan)",
-                "hbm_frac": moved / (ms / reps * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "note": "latency- and issue-bound small-row work: the HBM fraction is reported, not the bound",
-                "mean_prices": [float(x) for x in pr.mean(axis=0)]})
-    if baselines and "driver_rows" in baselines:
-        out[-1]["cpu_baseline"] = dict(baselines["driver_rows"], gpu_comparable="rows_per_s")
-    return out
-
-
-class Gpu:
-    """What this script asks of torch.cuda (tests/bench_rehearsal.py has the CPU stand-in of --rehearsal)."""
-    name = "cuda"
-
-    @staticmethod
-    def set_device(d):
-        import torch
-        torch.cuda.set_device(d)
-
-    @staticmethod
-    def synchronize():
-        import torch
-        torch.cuda.synchronize()
-
-    @staticmethod
-    def current_stream_handle():
-        import torch
-        return torch.cuda.current_stream().cuda_stream
-
-    @staticmethod
-    def device_count():
-        import torch
-        return torch.cuda.device_count()
-
-
-def agree(flags, dist, torch, dev) -> list:
-    """Element-wise AND of `flags` over the ranks (one all-reduce).  Every rank enters it -- from its except branch too."""
-    t = torch.tensor([1 if f else 0 for f in flags], device=dev)
-    dist.all_reduce(t, op=dist.ReduceOp.MIN)
-    return [int(x) == 1 for x in t.tolist()]
-
-
-def everyone(ok: bool, dist, torch, dev) -> bool:
-    """True iff `ok` on EVERY rank.  Every rank enters it -- from its except branch too -- so it doubles as the point where
-    the ranks of a step that may fail locally meet again.  That is sound only where the step itself cannot leave a peer
-    inside ANOTHER collective for good: set-up steps (nothing collective inside), and passes over the node mailbox (shm /
-    ipc: the segment barrier times out, the peers raise and arrive here too).  A pass over the built-in RCCL communicator or
-    over torch.distributed is not bounded like that -- see c5_sharded_rows.phase for what a failing rank does there."""
-    return agree([ok], dist, torch, dev)[0]
-
-
-class LastWill:
-    """Rank 0 of an N > 1 run: a guardian process, forked before anything touches the GPU, that owns the job's ONE JSON
-    line.  The rank sends it the line as soon as the headline is complete ("WILL", re-sent after every C5 row) and the
-    finished line at the end ("FINAL"); when the pipe closes -- the rank returned, raised, was killed by the launcher after
-    a peer died, or took a device fault in a C5 row -- the guardian prints FINAL, or else the last WILL with an "aborted"
-    note.  Nothing after the headline can cost the line any more, whatever the C5 rows do."""
-
-    def __init__(self, json_out):
-        import signal
-        r, w = os.pipe()
-        self.pid = os.fork()
-        if self.pid == 0:
-            code = 0
-            try:
-                os.close(w)
-                for sg in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
-                    signal.signal(sg, signal.SIG_IGN)
-                will = final = None
-                with os.fdopen(r, "r") as f:
-                    for ln in f:
-                        if not ln.endswith("\n"):
-                            break                      # (the rank died inside a write)
-                        if ln.startswith("WILL "):
-                            will = ln[5:]
-                        elif ln.startswith("FINAL "):
-                            final = ln[6:]
-                line = final
-                if line is None and will is not None:
-                    j = json.loads(will)
-                    j["aborted"] = ("rank 0 ended before the line was finished (a peer rank failed and the launcher ended the job, or "
-                                    "a C5 row took the process down); the headline was complete, extra.configs holds the rows that were")
-                    line = json.dumps(j)
-                if line:
-                    json_out.write(line.rstrip("\n") + "\n")
-                    json_out.flush()
-            except BaseException:   # noqa: BLE001
-                code = 1
-            finally:
-                os._exit(code)
-        os.close(r)
-        self._w = os.fdopen(w, "w")
-        self._out, self._lost = json_out, False
-
-    def _send(self, tag: str, out: dict) -> None:
-        try:
-            self._w.write(tag + " " + json.dumps(out) + "\n")
-            self._w.flush()
-        except OSError:   # the guardian is gone (it should never be): this process prints the line itself at the end
-            self._lost = True
-
-    def update(self, out: dict):
-        if not self._lost:
-            self._send("WILL", out)
-
-    def final(self, out: dict):
-        if not self._lost:
-            self._send("FINAL", out)
-        try:
-            self._w.close()
-        except OSError:
-            pass
-        _, status = os.waitpid(self.pid, 0)
-        if self._lost or status != 0:
-            print(json.dumps(out), file=self._out, flush=True)
-
-
-GPU_PROCESS_GUARD = 6   # what the pool's process guard allowed on the builder's one-GPU box (DESIGN 6); a node's is not stated
-
-
-def c5_rows_mode(args, world: int) -> str:
-    """child: every rank starts a child process for the C5 rows while it still holds the device (2 x world GPU processes; a
-    fault in a row cannot touch the parent).  inline: the rows run in the rank processes, after the headline is safe with
-    the guardian (world GPU processes).  auto: child where 2 x world fits under the process guard measured, else inline."""
-    if args.c5_rows != "auto":
-        return args.c5_rows
-    return "child" if 2 * world <= GPU_PROCESS_GUARD else "inline"
-
-
-def rccl_forms_in_time(make_scratch, rank: int, world: int, bcast, limit_s: float) -> bool:
-    """Form the built-in RCCL communicator on a scratch context inside a time box; True iff it formed within limit_s.  Only
-    ncclCommInitRank itself runs in the worker thread: the id's broadcast stays in the MAIN thread (torch's current device is
-    thread-local -- a collective issued from a fresh thread would run on device 0 on every rank), which enters it ALWAYS,
-    whatever the worker did (an empty id from rank 0 makes every rank's init raise together)."""
-    import threading
-    box = {}
-    uid_ready, uid_back = threading.Event(), threading.Event()
-
-    def bcast_in_main(uid):   # called by init_rccl inside the worker: park the id, wait for the main thread's broadcast
-        box["uid_in"] = uid
-        uid_ready.set()
-        uid_back.wait()
-        return box.get("uid_out")
-
-    def work():
-        try:
-            e = make_scratch()
-            box["scratch"] = e
-            e.init_rccl(rank, world, bcast_in_main)
-            box["formed"] = True
-        except Exception as ex:   # noqa: BLE001
-            box["err"] = ex
-        finally:
-            uid_ready.set()       # (a worker that failed before it had an id must not keep the main thread from the broadcast)
-    t = threading.Thread(target=work, daemon=True)
-    t.start()
-    uid_ready.wait(limit_s)       # creating the id is local
-    box["uid_out"] = bcast(box.get("uid_in", b"") if rank == 0 else None)
-    uid_back.set()
-    t.join(limit_s)
-    if t.is_alive():
-        print(f"bench: rank {rank}: the built-in RCCL communicator did not form within {limit_s:.0f} s; falling back to torch.distributed",
-              file=sys.stderr, flush=True)
-        return False
-    if "err" in box or not box.get("formed"):
-        print(f"bench: built-in RCCL communicator unavailable ({box.get('err')}); using torch.distributed", file=sys.stderr)
-        if box.get("scratch") is not None:
-            try:
-                box["scratch"].close()
-            except Exception:   # noqa: BLE001
-                pass
-        return False
-    box["scratch"].close()
-    return True
-
-
-def install_collective(eng, mc, want: str, dist, torch, rank: int, world: int, dev="cuda", scratch=None) -> str:
-    """Give `eng` the collective `want` ("ipc", "shm", "rccl", "torch") -- every rank ends up on the SAME one: a set-up
-    that fails on any rank sends all of them one step down (ipc -> shm -> rccl -> torch).  Returns what is installed.
-    No rank can be left alone in a collective: whatever a rank does before a broadcast cannot fail (the segment's name is
-    a string; the RCCL id is created inside a try and an empty one is broadcast on failure, PathEngine.init_rccl), and
-    every local step that can fail is followed by everyone()."""
-    got = want
-    if want in ("shm", "ipc"):
-        box = [f"/mcg_bench_{os.getpid()}_{time.time_ns()}" if rank == 0 else None]
-        dist.broadcast_object_list(box, src=0)
-        ok = True
-        try:
-            eng.init_shm(box[0], rank, world)
-        except mc.McgError as e:
-            print(f"bench: shared-memory communicator unavailable ({e}); using RCCL", file=sys.stderr)
-            ok = False
-        if not everyone(ok, dist, torch, dev):
-            eng.set_allreduce(None)
-            got = f"rccl ({want} init failed" + ("" if not ok else " on a peer") + ")"
-        elif want == "ipc":
-            try:     # (collective over the segment: the ranks agree inside; an error poisons the segment for all of them)
-                peer = eng.shm_peer_mailbox(True)
-            except mc.McgError as e:
-                print(f"bench: peer-memory mailbox failed ({e})", file=sys.stderr)
-                peer, ok = False, False
-            if not everyone(ok, dist, torch, dev):
-                eng.set_allreduce(None)
-                got = "rccl (ipc set-up failed" + ("" if not ok else " on a peer") + ")"
-            elif not peer:
-                got = "shm (peer-memory mailbox unavailable: export, open or in-kernel ping failed on some rank)"
-    if got.startswith("rccl"):
-        def bcast(uid):
-            box = [uid]
-            dist.broadcast_object_list(box, src=0)
-            return box[0]
-        ok = True
-        try:                               # can EVERY rank load librccl?  (agreed before anybody enters ncclCommInitRank, where a
-            eng.rccl_probe()               #  rank whose peer never arrives would wait)
-        except mc.McgError as e:
-            print(f"bench: librccl unavailable on rank {rank} ({e})", file=sys.stderr)
-            ok = False
-        if everyone(ok, dist, torch, dev):
-            # ncclCommInitRank with more than one rank has never run in this repo's history (every GPU box had one GPU): a
-            # communicator that does not FORM must cost the run its collective, not its line.  So it is formed once on a
-            # scratch context inside a time box; only if every rank's formed in time does the real context get its own.  A
-            # scratch context that is still inside ncclCommInitRank when the box closes is abandoned (daemon thread).
-            ok = rccl_forms_in_time(scratch or (lambda: mc.PathEngine(eng.device)), rank, world, bcast,
-                                    float(os.environ.get("MCG_BENCH_RCCL_INIT_LIMIT", "90")))
-            if everyone(ok, dist, torch, dev):
-                try:
-                    eng.init_rccl(rank, world, bcast)
-                except mc.McgError as e:       # communicator set-up failed on this node: use torch's, and say so
-                    print(f"bench: built-in RCCL communicator unavailable ({e}); using torch.distributed", file=sys.stderr)
-                    ok = False
-            else:
-                ok = False
-        else:
-            ok = False
-        if not everyone(ok, dist, torch, dev):               # all ranks take the same route
-            got = "torch (built-in RCCL init failed" + ("" if not ok else " on a peer") + ")"
-            eng.use_torch_distributed()
-    elif got == "torch":
-        eng.use_torch_distributed()
-    return got
-
-
-def c5_sharded_rows(args, mc, N, dist, torch, device, stream, rank, world, hw=Gpu, make_engine=None, on_row=None,
-                    deadline=None) -> list:
-    """BASELINE.json configs[4] on this run's N ranks, after the headline loop: rBergomi (H = 0.1, eta = 1.9) American put,
-    LSM order 2, 252 steps, --c5-paths (8M) paths per GPU of ONE Philox stream, timed through each collective of
-    --c5-collectives in turn on a fresh context.  One untimed pass, then 3 timed between barriers; per row: the slowest
-    and the fastest rank's ms per pass, the collective that ran, what its communicator has seen (mcg_comm_info), the
-    launches of the LSM sweep per pass (1 = the one-launch sweep exchanged inside the kernel) and the global price.
-    A row is a sequence of local phases; after each the ranks meet in agree(): a rank that raised is there too, so the
-    row is recorded as failed on ALL ranks at once -- WHERE the peers can get there: set-up phases and passes over the node
-    mailbox (its barrier times out).  A rank that raises inside a pass over the built-in RCCL communicator or over
-    torch.distributed leaves its peers inside an all-reduce that never completes (or, worse, would pair its own agreement
-    all-reduce with their data all-reduce): there it ends the job instead -- exit code 17, the launcher (or the parents of
-    the child job) take the peers down, the rows finished so far and the headline are already with rank 0's guardian.
-    `deadline` (time.time() value): once any rank is past it the remaining rows are abandoned by all ranks together."""
-    from montecarlooptionspricer_amd.sharding import shard_range
-    rows, reps, steps = [], 3, 252
-    total = args.c5_paths * world
-    begin, count = shard_range(total, rank, world, align=2)
-    dev = torch.device("cuda", device) if hw is Gpu else torch.device("cpu")
-    make_engine = make_engine or (lambda: mc.PathEngine(device, stream=stream))
-    out_of_time = False
-    for want in [c for c in args.c5_collectives.split(",") if c]:
-        if out_of_time:
-            break
-        e5, err, row = None, None, None
-        if args.rehearsal:
-            os.environ["MCG_REHEARSAL_ROW"] = want   # (read by the rehearsal's failure injection only)
-        st = {"unbounded": False}
-
-        def phase(fn):
-            """Run a local step; every rank then learns whether it worked everywhere (and whether there is time left)."""
-            nonlocal err, out_of_time
-            ok = True
-            if err is None:
-                try:
-                    fn()
-                except Exception as ex:   # noqa: BLE001
-                    err, ok = f"{type(ex).__name__}: {ex}", False
-                    if st["unbounded"]:
-                        print(f"bench: rank {rank} failed inside a pass over '{st.get('got')}' ({err}); its peers cannot leave that "
-                              "collective, so this rank ends the job (exit code 17)", file=sys.stderr, flush=True)
-                        os._exit(17)
-            else:
-                ok = False
-            in_time = deadline is None or time.time() < deadline
-            ok, in_time = agree([ok, in_time], dist, torch, dev)
-            if not in_time:
-                out_of_time = True
-            return ok and in_time
-
-        def setup():
-            nonlocal e5
-            e5 = make_engine()
-
-        def one_pass():
-            P = e5.rbergomi(SEED, RB["S0"], RB["r"], RB["xi"], RB["H"], RB["eta"], RB["rho"], DT, steps, count, path_begin=begin)
-            r = e5.price_lsm(P, RB["r"], 100.0, steps * DT, DT, False, 2)
-            P.free()
-            return r
-
-        def warm():
-            one_pass()
-            e5.synchronize()
-            hw.synchronize()
-
-        def timed():
-            e5.timing_enable(True)
-            e5.timing_reset()
-            t0 = time.perf_counter()
-            for _ in range(reps):
-                st["price"], st["se"] = one_pass()
-            e5.synchronize()
-            hw.synchronize()
-            st["mine"] = (time.perf_counter() - t0) / reps * 1e3
-
-        try:
-            good = phase(setup)
-            if good:
-                # (install_collective agrees among the ranks inside; an exception there is the same on every rank)
-                st["got"] = "none (every rank prices its own shard alone: a local price, the baseline the routes below add their exchange to)" \
-                    if want == "none" else install_collective(e5, mc, want, dist, torch, rank, world, dev, scratch=make_engine)
-                st["info"] = e5.comm_info()
-                st["unbounded"] = st["got"].startswith(("rccl", "torch"))
-            good = good and phase(warm) and phase(timed)
-            st["unbounded"] = False
-            if good:
-                t = torch.tensor([st["mine"], -st["mine"]], dtype=torch.float64, device=dev)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                ms_max, ms_min = float(t[0].item()), -float(t[1].item())
-                gen_ms, _ = e5.timing_get(N.K_RBERGOMI)
-                sw_ms, sw_n = e5.timing_get(N.K_LSM_SWEEP)
-                seen = torch.tensor([st["info"]["seen_ranks"]], device=dev)
-                dist.all_reduce(seen, op=dist.ReduceOp.MIN)
-                row = {
-                    "config": f"C5: rBergomi American put LSM order 2, {args.c5_paths} paths x {steps} steps per GPU, {world} rank(s) "
-                              f"= {total} paths of one Philox stream",
-                    "collective_requested": want, "collective": st["got"],
-                    "comm": dict(st["info"], seen_ranks_min_over_ranks=int(seen.item())),
-                    "paths_per_gpu": args.c5_paths, "global_paths": total,
-                    "ms_per_pass_slowest_rank": ms_max, "ms_per_pass_fastest_rank": ms_min,
-                    "Mpaths_per_s": total / ms_max / 1e3, "price": st["price"], "std_err": st["se"],
-                    "rank0_generator_ms_per_pass": gen_ms / reps, "rank0_lsm_sweep_ms_per_pass": sw_ms / reps,
-                    "rank0_lsm_sweep_launches_per_pass": sw_n // reps,
-                    "lsm_one_launch": e5.lsm_one_launch_enabled() and sw_n // reps <= 2, "rank0_stats": mc.stats()}
-            elif out_of_time:
-                row = {"config": "C5", "collective_requested": want,
-                       "error": "the wall-clock budget of the C5 rows was used up: this row and the remaining ones were abandoned by all ranks together"}
-            else:
-                row = {"config": "C5", "collective_requested": want,
-                       "error": err or "a peer rank failed in this row (its own stderr says why); all ranks abandoned it together"}
-        except Exception as ex:   # (outside the phases: the collectives of this function itself)
-            row = {"config": "C5", "collective_requested": want, "error": f"{type(ex).__name__}: {ex}"}
-        finally:
-            if e5 is not None:
-                e5.close()
-        rows.append(row)
-        if on_row is not None:
-            on_row(rows)
-    return rows
-
-
-def c5_rows_in_child_job(args, dist, torch, rank: int, world: int, budget_s: float):
-    """Every rank of this job starts `bench.py --c5-child` as a child process (same RANK / LOCAL_RANK / WORLD_SIZE, a
-    rendezvous port of its own) and the parents WATCH the children together: four times a second they exchange (over a gloo
-    group of their own: no device work beside the children's timing) who is still running and who has failed -- a child
-    that could not be started (spawn refused), one that exited non-zero, or the budget running out.  On the first failure
-    every parent kills its child: no parent waits for a child whose peer is gone.  Rank 0's child prints each finished row
-    as a line of its own, so the rows before a failure are kept.  Returns (on rank 0) the rows plus, after a failure, one
-    row that says what went wrong."""
-    import socket
-    import subprocess
-    import tempfile
-    from datetime import timedelta
-    mon = dist.new_group(backend="gloo", timeout=timedelta(seconds=120))
-    box = [None]
-    if rank == 0:
-        with socket.socket() as sk:
-            sk.bind(("127.0.0.1", 0))
-            box[0] = sk.getsockname()[1]
-    dist.broadcast_object_list(box, src=0)
-    env = dict(os.environ, MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"), MASTER_PORT=str(box[0]),
-               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-    for k in list(env):   # the child is not an elastic worker of the parent's agent
-        if k.startswith("TORCHELASTIC_") or k in ("TORCH_NCCL_ASYNC_ERROR_HANDLING",):
-            env.pop(k)
-    cmd = [sys.executable, os.path.abspath(__file__), "--c5-child", "--gpus", str(world), "--backend", args.backend,
-           "--c5-paths", str(args.c5_paths), "--c5-collectives", args.c5_collectives, "--c5-budget", str(budget_s)] + (["--rehearsal"] if args.rehearsal else [])
-    fo, fe = tempfile.TemporaryFile("w+"), tempfile.TemporaryFile("w+")
-    proc, why = None, None
-    try:
-        if os.environ.get("MCG_BENCH_SPAWN_FAIL") in (str(rank), "all"):   # test hook: the pool refuses the process
-            raise OSError(11, "Resource temporarily unavailable (injected)")
-        proc = subprocess.Popen(cmd, env=env, stdout=fo, stderr=fe, text=True)
-    except OSError as e:
-        why = f"rank {rank}: the child process could not be started ({e})"
-        print("bench: " + why, file=sys.stderr, flush=True)
-    t_end = time.time() + budget_s + 60.0   # (the child abandons its rows at budget_s by itself; this is for one that hangs)
-    failed_any = False
-    while True:
-        rc = proc.poll() if proc is not None else 1
-        failed = proc is None or (rc is not None and rc != 0) or time.time() > t_end
-        t = torch.tensor([1 if failed else 0, 1 if (proc is not None and rc is None) else 0])
-        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=mon)
-        if int(t[0]):
-            failed_any = True
-            if proc is not None and proc.poll() is None:
-                proc.kill()
-            break
-        if not int(t[1]):
-            break
-        time.sleep(0.25)
-    if proc is not None:
-        try:
-            proc.wait(timeout=30)
-        except subprocess.TimeoutExpired:
-            pass
-    rows = None
-    if rank == 0:
-        fo.seek(0)
-        rows = [json.loads(ln[4:]) for ln in fo.read().splitlines() if ln.startswith("ROW ")]
-        if failed_any:
-            fe.seek(0)
-            rc = proc.returncode if proc is not None else None
-            rows.append({"config": "C5", "error": why or (f"child job failed (exit code {rc})" if rc not in (None, 0, -9) else
-                                                          "child job ended by its parents: a peer rank's child failed, could not be started, or "
-                                                          f"the job ran past {budget_s + 60:.0f} s (every rank's own stderr says which)"),
-                         "stderr_tail": fe.read()[-1500:]})
-    dist.barrier()
-    return rows
-
-
-def c5_rows_inline(args, mc, N, dist, torch, device, stream, rank, world, hw, make_engine, will, out, budget_s: float):
-    """The C5 rows in the rank processes themselves (world GPU processes, not 2 x world).  The headline is with the guardian
-    already; every finished row is sent after it.  A wall-clock budget: past it the ranks abandon the remaining rows
-    together (checked in every agreement); a rank still inside a row a minute after that -- a collective that never
-    returns -- ends the job (exit code 18), which the guardian's line survives."""
-    import threading
-    dog = threading.Timer(budget_s + 60.0, lambda: (print(f"bench: rank {rank}: the inline C5 rows hang past their budget; ending the job",
-                                                          file=sys.stderr, flush=True), os._exit(18)))
-    dog.daemon = True
-    dog.start()
-
-    def on_row(rows):
-        if will is not None:
-            out.setdefault("extra", {})["configs"] = list(rows)
-            will.update(out)
-    try:
-        return c5_sharded_rows(args, mc, N, dist, torch, device, stream, rank, world, hw, make_engine, on_row=on_row,
-                               deadline=time.time() + budget_s)
-    finally:
-        dog.cancel()
 
 
 def main() -> None:
@@ -1205,6 +504,8 @@ def main() -> None:
                     except Exception as e:   # noqa: BLE001 -- reported baselines, never required
                         print(f"bench: CPU baselines of the widened rows failed ({e})", file=sys.stderr)
                 out["extra"] = {"configs": extra_configs(eng, N, base) + widening_configs(eng, N, mc, base)}
+                eng.trim()   # (the child processes of the next row bring their own contexts)
+                out["extra"]["configs"].append(unchanged_driver_row(base))
                 out["extra"]["c2_cold_first_launch_ms"] = cold_ms
             except Exception as e:
                 out["extra"] = {"configs": [], "error": str(e)}
