@@ -48,7 +48,7 @@ if ROOT not in sys.path:
 from tools.bench_common import DT, HBM_PEAK_GBS, RB, SEED  # noqa: E402
 from tools.bench_extra import (extra_configs, reference_parity, rough_regime_parity, unchanged_driver_row,  # noqa: E402
                                widening_configs)
-from tools.bench_multirank import (GPU_PROCESS_GUARD, Gpu, LastWill, c5_rows_in_child_job, c5_rows_inline,  # noqa: E402
+from tools.bench_multirank import (ABANDONED, GPU_PROCESS_GUARD, Gpu, LastWill, c5_rows_in_child_job, c5_rows_inline,  # noqa: E402
                                    c5_rows_mode, c5_sharded_rows, install_collective)
 
 
@@ -164,6 +164,27 @@ def cpu_baselines_widened(budget_s: float = 3.0) -> dict:
                                         "steps, then AsymptoticAnalysis and BranchingProcesses of the compiled reference and the restated LSM and "
                                         f"MartingaleOptimization), omp parallel for schedule(dynamic) over rows as PredictionGen.cpp:542-823, {sec:.1f} s"}
     return out
+
+
+def leave(eng, dist, json_out) -> None:
+    """The end of a rank.  Normally: close the context, meet the peers, leave the process group.  With a scratch context
+    abandoned inside ncclCommInitRank (tools/bench_multirank.py: rccl_forms_in_time) a thread of this process still holds a
+    GPU context and a half-formed communicator: closing contexts, destroying the process group or running library
+    destructors at interpreter exit could block on it.  The line is out by now (rank 0: printed, or with the guardian, which
+    has been waited for) -- so such a rank still meets its peers in the barrier (torch's own group is not affected) and then
+    leaves through os._exit(0)."""
+    abandoned = ABANDONED["rccl_init"]
+    if not abandoned:
+        eng.timing_enable(False)
+        eng.close()
+    if dist is not None:
+        dist.barrier()
+    if abandoned:
+        json_out.flush()
+        sys.stderr.flush()
+        os._exit(0)
+    if dist is not None:
+        dist.destroy_process_group()
 
 
 def main() -> None:
@@ -374,10 +395,10 @@ def main() -> None:
         c5_rows = c5_rows_after(out)
         if rank == 0:
             out["extra"] = {"configs": c5_rows}
+            if ABANDONED["rccl_init"]:
+                out["config"]["rccl_init_abandoned"] = True
             will.final(out)
-        eng.close()
-        dist.barrier()
-        dist.destroy_process_group()
+        leave(eng, dist, json_out)
         return
     k_ms, k_n = eng.timing_get(k_main)
     sweep_ms, sweep_n = eng.timing_get(N.K_LSM_SWEEP)
@@ -519,15 +540,13 @@ def main() -> None:
         if c5_rows is not None:
             out.setdefault("extra", {})["configs"] = c5_rows
         out["config"]["comm"] = eng.comm_info()
+        if ABANDONED["rccl_init"]:
+            out["config"]["rccl_init_abandoned"] = True   # a scratch context is still inside ncclCommInitRank on this rank
         if will is not None:
             will.final(out)
         else:
             print(json.dumps(out), file=json_out, flush=True)
-    eng.timing_enable(False)
-    eng.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    leave(eng, dist, json_out)
 
 
 if __name__ == "__main__":

@@ -103,9 +103,9 @@ int mcg_comm_init_shm(mcg_ctx* ctx, const char* name, int n_ranks, int rank);
  * ranks stay on the host mailbox together (status MCG_OK, *active = 0).  enable = 0 goes back to the host mailbox.
  * The host segment keeps serving the barrier, the flags and the host all-reduce.
  * Lifetime: a rank's mailbox outlives every peer that maps it.  Between processes the IPC mapping sees to that by itself;
- * rank THREADS of one process use the owner's pointer as it stands, so the library counts them in the segment and a rank
- * that finalises (or switches back) waits up to 5 s for its borrowers to let go before it frees the mailbox -- and keeps it
- * allocated if one never does.  Finalise the ranks of a job together, as one would leave any collective. */
+ * rank THREADS of one process use the owner's pointer as it stands, so the library counts them in the segment: a rank that
+ * finalises (or switches back) while a rank thread still holds its mailbox leaves the mailbox to the LAST of them to let go,
+ * which frees it -- nobody waits, nothing leaks, in whatever order the rank threads' contexts are closed. */
 int mcg_comm_shm_peer_mailbox(mcg_ctx* ctx, int enable, int* active);
 
 /* What collective this ctx holds and how many ranks it has SEEN: kind 0 none, 1 callback (mcg_set_allreduce),
@@ -209,7 +209,7 @@ typedef struct mcg_row {
  * MartingaleOptimization(poly_order, max_iterations) on them.  out[4*i + {0,1,2,3}] = the four prices of row i
  * in the driver's column order (asymPrice, branchPrice, lsmPriceVal, martinPrice, :809-814).  Rows the driver
  * would answer with zeros (no steps, degenerate estimates, sigma <= 0, strike <= 0, an inf / nan among the row's generated
- * paths: :739-777 -- the row kernels scan every row's block for it) get zeros; every other row gets what its pricers
+ * paths: :739-777 -- the row kernels scan every row's block for it, rows priced singly are scanned by a pass of their own) get zeros; every other row gets what its pricers
  * returned, finite or not (:809-816).
  * Row i uses Philox path ids (i << 32) + p of `seed`: its prices equal the single-contract entry points
  * called with path_begin = i << 32 -- and a row of more than 1020 steps (four years of trading days) IS priced through
@@ -322,7 +322,7 @@ typedef struct mcg_stats_t {
     int64_t batch_rows;                /* rows priced by the row kernels                                                   */
     int64_t batch_rows_singly;         /* rows priced one by one through the single-contract entry points                 */
     int64_t batch_peak_workspace_bytes;/* largest device workspace a chunk has used                                        */
-    int64_t peer_mailbox_kept;         /* peer-memory mailboxes NOT freed at release: a same-process rank thread still held them */
+    int64_t peer_mailbox_kept;         /* peer-memory mailboxes left at release to the last same-process rank thread that held them (it frees them) */
     int64_t coalesced_rounds;          /* class-API calls of several host threads answered together: rounds (one set of launches each) */
     int64_t coalesced_calls;           /* ... and the calls they answered                                                  */
     int64_t coalesced_peak_calls_per_round; /* most calls one round has answered                                           */

@@ -63,9 +63,11 @@ struct ShmHeader {
     // "the same process" = the same pid AND the same per-process random token (two containers sharing /dev/shm can hold
     // equal pids; a foreign pointer must never be dereferenced)
     uint64_t owner_token[SHM_MAX_RANKS];
-    // ranks that currently hold rank r's OWN pointer (same-process borrowers).  An IPC mapping keeps the owner's memory
-    // alive until every opener has closed it; a borrowed pointer does not -- so the owner frees its mailbox only once
-    // this count is back at zero (peer_release), and leaks it rather than free it under a borrower that never lets go.
+    // ranks that currently hold rank r's OWN pointer (same-process borrowers), plus BORROW_ORPHANED once the owner has let
+    // go of it.  An IPC mapping keeps the owner's memory alive until every opener has closed it; a borrowed pointer does
+    // not -- so whoever brings this word to "orphaned, nobody left" frees the mailbox: the owner when no borrower is left,
+    // else the LAST borrower to let go (one address space: any thread may hipFree it).  Nobody waits for anybody, nothing
+    // leaks, whatever order the rank threads' contexts are closed in (round 5 waited up to 5 s and then kept the megabyte).
     std::atomic<uint32_t> borrowers[SHM_MAX_RANKS];
 };
 static_assert(sizeof(ShmHeader) % 64 == 0, "mailbox starts cache-line aligned");
@@ -94,6 +96,7 @@ struct ShmComm {
 
 namespace {
 
+constexpr uint32_t BORROW_ORPHANED = 0x80000000u;  // ShmHeader::borrowers: the owner has gone, the last borrower frees
 constexpr uint32_t SHM_MAGIC = 0x4D434756u;  // "MCGV" (layout of round 5: owner_token, borrowers)
 
 uint64_t process_token() {  // one random word per process, never written anywhere but into the segment's owner_token
@@ -354,20 +357,27 @@ bool peer_map_allowed(bool same_process, bool bus_id_resolves, bool same_device,
 static void peer_release(ShmComm* c) {
     for (int r = 0; r < SHM_MAX_RANKS; ++r) {
         if (c->peer_map[r] && r != c->rank) {
-            if (c->peer_borrowed[r]) c->hdr->borrowers[r].fetch_sub(1, std::memory_order_acq_rel);  // (our kernels are done: callers synchronise the stream first)
-            else (void)hipIpcCloseMemHandle(c->peer_map[r]);
+            if (c->peer_borrowed[r]) {  // (our kernels are done: callers synchronise the stream first)
+                if (c->hdr->borrowers[r].fetch_sub(1, std::memory_order_acq_rel) == (BORROW_ORPHANED | 1u)) {
+                    (void)hipFree(c->peer_map[r]);  // the owner left before us and we were the last to hold its mailbox
+                    c->hdr->borrowers[r].store(0, std::memory_order_release);
+                }
+            } else {
+                (void)hipIpcCloseMemHandle(c->peer_map[r]);
+            }
         }
         c->peer_map[r] = nullptr;
         c->peer_borrowed[r] = false;
     }
     if (c->peer_own) {
         // Same-process rank threads hold this pointer as it stands.  Lifetime rule (mcgpu.h, mcg_comm_init_shm): a rank's
-        // mailbox outlives every peer that maps it -- enforced here: wait (bounded) for the borrowers to let go, and if one
-        // never does, keep the megabyte allocated rather than free memory a peer's sweep or ping may still store into.
-        const auto t0 = std::chrono::steady_clock::now();
-        while (c->hdr->borrowers[c->rank].load(std::memory_order_acquire) != 0 && since(t0) < 5.0) sched_yield();
-        if (c->hdr->borrowers[c->rank].load(std::memory_order_acquire) == 0) (void)hipFree(c->peer_own);
-        else g_stats.peer_mailbox_kept.fetch_add(1, std::memory_order_relaxed);  // still borrowed after the wait: not freed (mcg_stats)
+        // mailbox outlives every peer that maps it -- so if a borrower is left, the mailbox is ITS to free when it lets go.
+        if (c->hdr->borrowers[c->rank].fetch_or(BORROW_ORPHANED, std::memory_order_acq_rel) == 0) {
+            (void)hipFree(c->peer_own);
+            c->hdr->borrowers[c->rank].store(0, std::memory_order_release);
+        } else {
+            g_stats.peer_mailbox_kept.fetch_add(1, std::memory_order_relaxed);  // handed to the last borrower (mcg_stats)
+        }
     }
     c->peer_own = nullptr;
     c->peer_active = false;
@@ -380,7 +390,7 @@ void shm_release(mcg_ctx* ctx) {
         ctx->allreduce = nullptr;
         ctx->allreduce_user = nullptr;
     }
-    if (c->registered) (void)hipStreamSynchronize(ctx->stream);  // (this rank's own pushes into borrowed mailboxes are over)
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);  // (this rank's own pushes into borrowed or mapped mailboxes are over)
     peer_release(c);
     if (c->registered) (void)hipHostUnregister(c->base);
     if (c->pinned) (void)hipHostFree(c->pinned);
@@ -454,13 +464,15 @@ extern "C" int mcg_comm_shm_peer_mailbox(mcg_ctx* ctx, int enable, int* active) 
         return MCG_OK;
     }
     if (c->peer_own) peer_release(c);  // (left behind by an earlier attempt that failed half-way)
+    // (a mailbox of an earlier enable that a rank thread still holds: its count must not be mixed with the new one's)
+    const bool earlier_still_borrowed = c->hdr->borrowers[c->rank].load(std::memory_order_acquire) != 0;
     // 1. allocate + export.  Uncached device memory first (every access goes to HBM: what a peer stores over xGMI is what
     // a local poll reads), fine-grained next, an ordinary allocation last; the in-kernel ping below is the judge.
     int ok = 0;
     {
         const unsigned kinds[3] = {hipDeviceMallocUncached, hipDeviceMallocFinegrained, hipDeviceMallocDefault};
         const char* names[3] = {"uncached device memory", "fine-grained device memory", "device memory"};
-        for (int k = 0; k < 3 && !ok; ++k) {
+        for (int k = 0; k < 3 && !ok && !earlier_still_borrowed; ++k) {
             void* p = nullptr;
             if (hipExtMallocWithFlags(&p, mailbox_bytes(), kinds[k]) != hipSuccess) {
                 (void)hipGetLastError();

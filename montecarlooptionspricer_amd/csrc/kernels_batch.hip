@@ -445,7 +445,8 @@ namespace {
 
 // Device workspace one row needs in a chunk: its matrix block, its amplitudes + compensator, its image and its four prices.
 size_t row_workspace_bytes(int n_steps, int M) {
-    return ((size_t)BATCH_LD * (size_t)(n_steps + 1) + (size_t)M + (size_t)n_steps + 5) * sizeof(double) + sizeof(BatchRow);
+    // (+ the generator's workgroup map: at most 32 shares of 4 bytes per row at 256 paths)
+    return ((size_t)BATCH_LD * (size_t)(n_steps + 1) + (size_t)M + (size_t)n_steps + 5) * sizeof(double) + sizeof(BatchRow) + 32 * sizeof(uint32_t);
 }
 
 // LDS class of a row: the row kernels' dynamic LDS is sized by the longest row of a LAUNCH, so the rare long rows (Mz >= 256:
@@ -494,14 +495,19 @@ static int run_batch_chunk(mcg_ctx* ctx, std::vector<BatchRow>& h, BatchArgs a, 
         const int shares = (n_pairs + rb_pairs_per_block(h[(size_t)k].M) - 1) / rb_pairs_per_block(h[(size_t)k].M);  // <= 63 (n_paths <= 256)
         for (int sub = 0; sub < shares; ++sub) wg_map.push_back((uint32_t)(k << 6) | (uint32_t)sub);
     }
+    std::vector<double> four((size_t)n * 5);   // (host memory first: a bad_alloc below this line would leave a pool buffer out)
     void* d_map = nullptr;
     const size_t map_bytes = wg_map.size() * sizeof(uint32_t);
     int rc_map = pool_alloc(ctx, map_bytes, &d_map);
     if (rc_map) return rc_map;
-    if (hipMemcpyAsync(d_map, wg_map.data(), map_bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
-        pool_release(ctx, d_map, map_bytes);
+    struct PoolGuard {   // the map goes back to the pool on every way out
+        mcg_ctx* c;
+        void* p;
+        size_t b;
+        ~PoolGuard() { pool_release(c, p, b); }
+    } map_guard{ctx, d_map, map_bytes};
+    if (hipMemcpyAsync(d_map, wg_map.data(), map_bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
         return fail(MCG_ERR_HIP, "batch upload failed (workgroup map)");
-    }
     a.wg_map = (const uint32_t*)d_map;
     {
         TimedLaunch t(ctx, MCG_K_BATCH);
@@ -522,10 +528,9 @@ static int run_batch_chunk(mcg_ctx* ctx, std::vector<BatchRow>& h, BatchArgs a, 
         }
     }
     e = hipGetLastError();
-    std::vector<double> four((size_t)n * 5);
     if (e == hipSuccess) e = hipMemcpyAsync(four.data(), a.out, 5 * sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // (also: the host vectors `h` and `wg_map` have outlived their uploads)
-    pool_release(ctx, d_map, map_bytes);
+    else (void)hipStreamSynchronize(ctx->stream);                // (nothing of this chunk may still read the map when it goes back to the pool)
     if (e != hipSuccess) return fail(MCG_ERR_HIP, "batch run failed: %s", hipGetErrorString(e));
     for (int64_t k = 0; k < n; ++k) {
         const int64_t i = (int64_t)h[(size_t)k].id;
@@ -534,6 +539,27 @@ static int run_batch_chunk(mcg_ctx* ctx, std::vector<BatchRow>& h, BatchArgs a, 
         if (bad && priced) priced[i] = 0;
     }
     return MCG_OK;
+}
+
+// inf / nan anywhere among the n_paths columns of a step-major matrix (the driver's scan, PredictionGen.cpp:752-777) for the rows
+// that are priced singly: *flag != 0 afterwards (any number of threads may say so)
+__global__ __launch_bounds__(256) void k_scan_finite(const double* data, int64_t ld, int64_t n_paths, int n_rows, unsigned* flag) {
+    bool bad = false;
+    for (int64_t j = blockIdx.y; j < n_rows; j += gridDim.y)
+        for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < n_paths; p += (int64_t)gridDim.x * 256) bad = bad || !isfinite(data[j * ld + p]);
+    if (bad) *flag = 1u;
+}
+
+// true: the matrix holds a non-finite price (or the scan itself failed: such a row is zeroed, like one whose generation failed)
+static bool paths_hold_non_finite(mcg_ctx* ctx, const mcg_paths* P) {
+    unsigned* flag = reinterpret_cast<unsigned*>(ctx->scalars + SC_BARRIER) + 1;   // (the second word of the hand-shake's slot: free between sweeps)
+    unsigned* h_flag = reinterpret_cast<unsigned*>(ctx->h_scalars + SC_BARRIER) + 1;
+    if (hipMemsetAsync(flag, 0, sizeof(unsigned), ctx->stream) != hipSuccess) return true;
+    const unsigned gx = (unsigned)std::min<int64_t>((P->n_paths + 255) / 256, 1024), gy = (unsigned)std::min(P->n_steps + 1, 1024);
+    hipLaunchKernelGGL(k_scan_finite, dim3(gx, gy), dim3(256), 0, ctx->stream, (const double*)P->data, P->ld, P->n_paths, P->n_steps + 1, flag);
+    if (hipMemcpyAsync(h_flag, flag, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return true;
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) return true;
+    return *h_flag != 0u;
 }
 
 #ifdef MCG_BATCH_TRACE   // (A/B builds: where the host time of a call goes, printed to stderr)
@@ -626,6 +652,15 @@ int run_batch_rows(mcg_ctx* ctx, const mcg_row* rows, int64_t n_rows, int n_path
             pool_release(ctx, S, max_S);
             return rc;
         }
+        struct Release {   // both buffers go back to the pool on every way out (a bad_alloc in a chunk included)
+            mcg_ctx* c;
+            void *S, *small;
+            size_t bS, bsmall;
+            ~Release() {
+                pool_release(c, S, bS);
+                pool_release(c, small, bsmall);
+            }
+        } release{ctx, S, small, max_S, max_small * sizeof(double)};
         int64_t peak = (int64_t)(max_S + max_small * sizeof(double)), seen = g_stats.batch_peak_workspace_bytes.load(std::memory_order_relaxed);
         while (peak > seen && !g_stats.batch_peak_workspace_bytes.compare_exchange_weak(seen, peak, std::memory_order_relaxed)) {
         }
@@ -682,8 +717,6 @@ int run_batch_rows(mcg_ctx* ctx, const mcg_row* rows, int64_t n_rows, int n_path
             g_stats.batch_chunks.fetch_add(1, std::memory_order_relaxed);
             g_stats.batch_rows.fetch_add((int64_t)h.size(), std::memory_order_relaxed);
         }
-        pool_release(ctx, S, max_S);
-        pool_release(ctx, small, max_small * sizeof(double));
         if (rc) return rc;
     }
 #ifdef MCG_BATCH_TRACE
@@ -695,8 +728,18 @@ int run_batch_rows(mcg_ctx* ctx, const mcg_row* rows, int64_t n_rows, int n_path
         const mcg_row& s = rows[i];
         double* o = out + 4 * i;
         mcg_paths* P = nullptr;
-        if (mcg_paths_rbergomi(ctx, seed, s.S0, r, s.xi, s.H, s.eta, s.rho, dt, s.n_steps, (uint64_t)i << 32, n_paths, &P) != MCG_OK)
-            continue;  // (the driver logs a failing row and writes zeros, :792-805)
+        // A row whose generation fails, or whose paths hold an inf / nan, is the driver's ",0,0,0,0,0,0" (PredictionGen.cpp:739-777):
+        // zeros AND priced[i] = 0, so that mcg_batch_price_rows6 zeroes its feature columns too -- exactly like a row the row
+        // kernels flag (this route used to keep priced[i] = 1 and hand NaN prices through).
+        if (mcg_paths_rbergomi(ctx, seed, s.S0, r, s.xi, s.H, s.eta, s.rho, dt, s.n_steps, (uint64_t)i << 32, n_paths, &P) != MCG_OK) {
+            if (priced) priced[i] = 0;
+            continue;
+        }
+        if (paths_hold_non_finite(ctx, P)) {
+            if (priced) priced[i] = 0;
+            mcg_paths_free(P);
+            continue;
+        }
         std::vector<int> ex((size_t)s.n_steps);
         for (int t = 0; t < s.n_steps; ++t) ex[(size_t)t] = t;  // :780-783
         double v = 0.0;

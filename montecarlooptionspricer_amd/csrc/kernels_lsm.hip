@@ -1553,10 +1553,13 @@ int run_lsm(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double maturit
     MCG_HIP(hipMemsetD32Async((hipDeviceptr_t)a.partials, (int)LSM_SENTINEL32, 2 * ((size_t)grid + LSM_DATE_MAX_GROUPS) * (size_t)nm, ctx->stream));
 
     // Exactly M launches when no date asks for a re-fit, one more per date that does (orders >= 4: every date with a path
-    // in the money).  The host queues M, reads the state back and queues what is left -- one launch per remaining date plus
-    // the share of second launches the dates behind it took -- until the sweep is through (a batch advances the sweep by at
-    // least half its launches); at order 2 no launch, and sharded no collective, is spent on a sweep that is already over, at
-    // higher orders at most the few the estimate overshoots by.
+    // in the money; at lower orders only near-degenerate dates).  The host queues M, reads the state back and queues what is
+    // left -- one launch per remaining date plus the share of second launches the dates behind it took -- until the sweep is
+    // through (a batch advances the sweep by at least half its launches).  A batch may overshoot the end by the few launches
+    // its estimate is off by -- at ANY order once a date has re-fitted: such a launch returns at once (k_lsm_date: j < 0), and
+    // sharded it is still preceded by its all-reduce of a.msg, which then re-sums moments nobody reads: a.msg is DEAD after
+    // the last date (nothing below this loop touches it; k_lsm_final reads V only) -- keep it that way.  Launches and
+    // collectives stay paired on every rank (launches = collectives + 1), so the ranks never disagree about a collective.
     int dates_left = M, progress = 2 * M + 1;  // progress: launches the sweep still needs at least, x 2 (must fall with every batch)
     int64_t batch = M;
     bool first = true;

@@ -152,3 +152,9 @@ def test_a_communicator_that_never_forms_costs_the_collective_not_the_run():
     assert out["config"]["collective"].startswith("torch (built-in RCCL init failed")
     assert [out["ids_counted"], out["ids_summed"]] == _ids(world * 250_000)
     assert "did not form within 3 s" in err
+    # ... and when it is RANK 0 whose formation hangs: the line says so, and the rank leaves through os._exit after the
+    # barrier instead of a tear-down that could block on the stuck thread -- the job still ends with exit code 0
+    t0 = time.time()
+    out, err = _run(world, fail="rccl_hang:0", extra=("--c5-rows", "off"), env_extra={"MCG_BENCH_RCCL_INIT_LIMIT": "3"}, timeout=120)
+    assert time.time() - t0 < 60
+    assert out["config"].get("rccl_init_abandoned") is True and out["config"]["collective"].startswith("torch (built-in RCCL init failed")

@@ -91,6 +91,17 @@ def test_batch_row_with_non_finite_paths_is_zeroed_like_the_driver(eng):
     assert np.array_equal(alone[0], four[0])              # a flagged neighbour changes nothing
     six = eng.batch_price_rows(rows, seed=5, features=np.array([[0.2, 0.01]] * 3))
     assert np.all(six[1] == 0.0) and six[0][4] == 0.2 and six[2][5] == 0.01
+    # the rows that are priced SINGLY (more than 1020 steps; any call with more than 256 paths or an order above 4)
+    # take the single-contract entry points, which have no such scan of their own: the same rule must hold there
+    long_good = dict(good, n_steps=1100, maturity=1100 / 252.0)
+    long_huge = dict(huge, n_steps=1100, maturity=1100 / 252.0)
+    six = eng.batch_price_rows([long_good, long_huge, good], seed=5, features=np.array([[0.2, 0.01]] * 3))
+    assert np.all(six[1] == 0.0), six[1]                                     # prices AND features
+    assert np.all(np.isfinite(six[0])) and six[0][4] == 0.2 and np.all(six[0][1:4] > 0) and six[2][5] == 0.01
+    wide = eng.batch_price_rows(rows, n_paths=300, seed=5, features=np.array([[0.2, 0.01]] * 3))   # every row singly
+    assert np.all(wide[1] == 0.0) and np.all(np.isfinite(wide)) and wide[0][4] == 0.2 and np.all(wide[2][:4] > 0)
+    high = eng.batch_price_rows(rows, poly_order=5, seed=5)                  # order 5: singly as well
+    assert np.all(high[1] == 0.0) and np.all(np.isfinite(high)) and np.all(high[0] > 0)
 
 
 def test_widened_pricers_match_oracle_on_the_c3_matrix(eng, orc):

@@ -277,3 +277,93 @@ def test_coalesced_calls_of_python_threads_match_sequential_calls(orc):
         assert together[k] == alone[k], (k, [i for i, (x, y) in enumerate(zip(together[k], alone[k])) if x != y][:5])
     assert s1["coalesced_calls"] == s0["coalesced_calls"] and s1["coalesced_rounds"] < s1["coalesced_calls"]
     assert s1["coalesced_peak_calls_per_round"] >= 2
+
+
+def test_rank_thread_contexts_closed_one_after_another_do_not_stall_or_leak(tmp_path):
+    """rank THREADS of one process borrow each other's peer-memory mailbox by pointer.  Closed together after a barrier
+    every owner finds its borrowers gone; closed ONE AFTER ANOTHER by a single thread (engines closed in a loop, the garbage
+    collector, atexit) every owner but the last still has borrowers -- round 5 waited 5 s per owner and then kept the megabyte.
+    Now the mailbox is handed to the last borrower, which frees it: eight sequential closes take well under a second, the
+    hand-overs are counted (mcg_stats.peer_mailbox_kept), and the job's prices are what they are with the ranks closed together."""
+    import json
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    out_file = str(tmp_path / "seq.json")
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="16", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(here, "thread_ranks_worker.py"), "8", "ipc", out_file, "seqclose"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout[-3000:]
+    j = json.load(open(out_file))
+    assert all(r["peer_mailbox"] for r in j["ranks"]), [r["comm"] for r in j["ranks"]]
+    assert len(j["close_seconds"]) == 8 and max(j["close_seconds"]) < 1.0, j["close_seconds"]
+    assert j["stats"]["peer_mailbox_kept"] == 7, j["stats"]            # every owner but the last left its mailbox to a borrower
+    assert all(r["rb_lsm"] == j["ranks"][0]["rb_lsm"] and r["euro"] == j["ranks"][0]["euro"] for r in j["ranks"])
+
+
+def test_sharded_per_date_route_at_order_5_equals_the_single_rank_price():
+    """the per-date LSM route sizes its batches by the share of re-fitted dates it has seen and may overshoot the end
+    of the sweep; sharded, every launch but the first is preceded by one all-reduce of the moments.  Two rank threads (callback
+    all-reduce over the threads), order 5 -- every in-the-money date re-fits --, 200 001 GBM paths x 40 dates: both ranks hold
+    the single-context price (1e-9: the sums are formed in a different order) and the same bits as each other, and on each rank
+    launches = moment all-reduces + 1 (mcg_stats / the callback's own count), overshoot launches included."""
+    import threading
+    import torch
+    from montecarlooptionspricer_amd.sharding import shard_range
+    n, steps, dt, order, world = 200_001, 40, 0.025, 5, 2
+    nm = 3 * (order + 1) - 1
+    with mc.PathEngine(0) as e:
+        e.set_allreduce(lambda ptr, count, stream: None)          # an identity collective selects the per-date route
+        P = e.gbm(SEED, 100.0, 0.04, 0.2, dt, steps, n)
+        want = e.price_lsm(P, 0.04, 100.0, 1.0, dt, False, order)
+        P.free()
+    bar, lock, parts, res, errs = threading.Barrier(world), threading.Lock(), {}, [None] * world, []
+    calls = [[] for _ in range(world)]
+
+    def allreduce(rank):
+        def fn(ptr, count, _stream):
+            t = torch.as_tensor(_DevView(ptr, count), device="cuda:0")
+            h = t.cpu().numpy().copy()
+            with lock:
+                parts[rank] = h
+            bar.wait()
+            tot = sum(parts[r] for r in range(world))
+            bar.wait()
+            t.copy_(torch.from_numpy(tot))
+            calls[rank].append(count)
+        return fn
+
+    def work(rank):
+        try:
+            torch.cuda.set_device(0)
+            e = mc.PathEngine(0, stream=torch.cuda.current_stream().cuda_stream)
+            e.set_allreduce(allreduce(rank))
+            b, c = shard_range(n, rank, world)
+            P = e.gbm(SEED, 100.0, 0.04, 0.2, dt, steps, c, path_begin=b)
+            e.timing_enable(True)
+            e.timing_reset()
+            res[rank] = (e.price_lsm(P, 0.04, 100.0, 1.0, dt, False, order), e.timing_get(N.K_LSM_SWEEP)[1])
+            P.free()
+            e.synchronize()
+            bar.wait()
+            e.close()
+        except BaseException as ex:   # noqa: BLE001
+            errs.append(ex)
+            bar.abort()
+
+    mc.stats(reset=True)
+    th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(300)
+    assert not errs, errs
+    assert not any(t.is_alive() for t in th)
+    (p0, launches0), (p1, launches1) = res
+    assert p0 == p1
+    assert abs(p0[0] - want[0]) <= 1e-9 * want[0] and abs(p0[1] - want[1]) <= 1e-7 * want[1], (p0, want)
+    for rank, launches in ((0, launches0), (1, launches1)):
+        moment_allreduces = calls[rank].count(nm)
+        # timing_get counts the per-date launches + k_lsm_final; every per-date launch but the first follows one all-reduce
+        assert launches - 1 == moment_allreduces + 1, (rank, launches, moment_allreduces, calls[rank][:8])
+        assert moment_allreduces >= steps + 1          # one per date at least; the re-fits' second launches on top

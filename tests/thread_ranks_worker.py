@@ -25,7 +25,7 @@ JOBS = dict(euro_paths=300_001, lsm_paths=200_001, lsm_steps=50, rb_paths=100_00
 C5_FULL = dict(rb_paths=64_000_000, rb_steps=252)
 
 
-def run_rank_threads(world, mode, tag, c5_full=False):
+def run_rank_threads(world, mode, tag, c5_full=False, keep_engines=None):
     """Every rank a thread with a ctx of its own; returns (per-rank result dicts, per-rank all-reduce counts) or raises
     the first rank's error."""
     import numpy as np
@@ -117,6 +117,9 @@ def run_rank_threads(world, mode, tag, c5_full=False):
             res[rank] = out
             e.synchronize()
             bar.wait()                                    # nobody leaves (and frees its mailbox) while a peer may still push into it
+            if keep_engines is not None:                  # seqclose: the caller closes the contexts itself, one after another
+                keep_engines[rank] = e
+                return
             e.close()
         except BaseException as ex:   # noqa: BLE001
             errs.append((rank, ex))
@@ -136,11 +139,22 @@ def run_rank_threads(world, mode, tag, c5_full=False):
 
 def main():
     world, mode, out_path = int(sys.argv[1]), sys.argv[2], sys.argv[3]
+    import time
+
     import montecarlooptionspricer_amd as mc
-    ranks, calls = run_rank_threads(world, mode, f"{mode}{world}", c5_full=len(sys.argv) > 4 and sys.argv[4] == "c5full")
+    what = sys.argv[4] if len(sys.argv) > 4 else ""
+    engines = [None] * world if what == "seqclose" else None
+    ranks, calls = run_rank_threads(world, mode, f"{mode}{world}", c5_full=what == "c5full", keep_engines=engines)
+    close_seconds = None
+    if engines is not None:   # ONE thread closes the rank threads' contexts one after another (a loop over engines, the garbage
+        close_seconds = []    # collector, atexit): every owner but the last still has borrowers when it goes
+        for e in engines:
+            t0 = time.perf_counter()
+            e.close()
+            close_seconds.append(time.perf_counter() - t0)
     with open(out_path, "w") as f:
         json.dump({"ranks": ranks, "calls": [{"1": c.count(1), "3": c.count(3), "8": c.count(8)} for c in calls], "stats": mc.stats(),
-                   "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES")}, f)
+                   "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "close_seconds": close_seconds}, f)
 
 
 if __name__ == "__main__":

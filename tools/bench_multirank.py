@@ -120,6 +120,11 @@ class LastWill:
             print(json.dumps(out), file=self._out, flush=True)
 
 
+# Set when a scratch context was left inside ncclCommInitRank by rccl_forms_in_time: the daemon thread still holds a GPU context
+# and a half-formed communicator, and library destructors at interpreter exit could block on it -- bench.py then says so in its
+# line (config.rccl_init_abandoned) and leaves through os._exit once the line is out.
+ABANDONED = {"rccl_init": False}
+
 GPU_PROCESS_GUARD = 6   # what the pool's process guard allowed on the builder's one-GPU box; a node's is not stated
 
 
@@ -164,6 +169,7 @@ def rccl_forms_in_time(make_scratch, rank: int, world: int, bcast, limit_s: floa
     uid_back.set()
     t.join(limit_s)
     if t.is_alive():
+        ABANDONED["rccl_init"] = True
         print(f"bench: rank {rank}: the built-in RCCL communicator did not form within {limit_s:.0f} s; falling back to torch.distributed",
               file=sys.stderr, flush=True)
         return False
