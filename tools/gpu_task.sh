@@ -30,7 +30,7 @@ tests)
 bench)
   timeout -k 10 900 python3 bench.py "$@" > $O/${T}_bench.json 2> $O/${T}_bench.err; rc=$?; echo "bench rc=$rc"; tail -3 $O/${T}_bench.err; head -c 1500 $O/${T}_bench.json; exit $rc ;;
 limiter)
-  timeout -k 10 1100 python3 tools/pmc_passes.py --tag ${T}_c2lim --kernels k_gbm_paths,k_probe_write \
+  timeout -k 10 1100 python3 tools/pmc_passes.py --tag ${T}_c2lim --kernels "k_gbm_paths<true,k_probe_write" \
     --group "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" \
     --group "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_FLAT GRBM_GUI_ACTIVE" \
     --group "SQ_INST_CYCLES_VMEM_WR SQ_INST_CYCLES_SALU SQ_INST_CYCLES_SMEM SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS GRBM_GUI_ACTIVE" \
