@@ -378,6 +378,92 @@ __global__ __launch_bounds__(256, 3) void k_branch_date_binned(BranchArgs a, int
     }
 }
 
+// ---- XCD-AFFINE per-date gathers (round 6; a STUDY route: MCG_BRANCH_XCD in A/B builds) ---------------------
+// The binned kernel above pulls every slice of the row through the L2 of every XCD once per generation of resident paths.  Here
+// the row is dealt out to the XCDs in granules of 2^granule_shift paths: workgroup w (XCD w & 7 -- workgroups are handed to the
+// XCDs round-robin) draws ALL the indices of its tile's paths and gathers ONLY those whose granule belongs to its XCD, so an
+// XCD's L2 only ever sees its eighth of the row; every tile is worked on by eight workgroups, one per XCD, each leaving its
+// partial sum per path in a cell of its own (cells[xcd][path]); k_branch_date_xcd_finish adds the eight cells in XCD order
+// (deterministic) and updates the bounds.  Costs: the Philox draws eight times over, 64 B of cells written and read per path
+// and date.
+constexpr int BRX_PPT = 2;
+template <int QUADS>
+__global__ __launch_bounds__(256) void k_branch_date_xcd(BranchArgs a, int e, double* cells, int64_t ldc, int granule_shift) {
+    __shared__ uint32_t buf[4 * QUADS * BRX_PPT][256];  // [branch slot][thread]: a thread only ever reads its own column
+    const unsigned tid = threadIdx.x;
+    const uint32_t xcd = blockIdx.x & 7u;
+    const int64_t tile = (int64_t)(blockIdx.x >> 3);
+    const uint32_t n32 = (uint32_t)a.n;
+    const int t_idx = a.ex[e];
+    const double* rowF = a.F + (int64_t)(t_idx + 1) * a.ld;
+    uint32_t m = 0;
+    int64_t p[BRX_PPT];
+#pragma unroll
+    for (int q = 0; q < BRX_PPT; ++q) {
+        p[q] = tile * (256 * BRX_PPT) + tid + q * 256;
+        if (p[q] < a.n) {
+            const PhiloxLane rng = philox_lane_setup(a.path_begin + (uint64_t)p[q], STREAM_BRANCH, a.k1);
+#pragma unroll
+            for (int k = 0; k < QUADS; ++k) {
+                const Philox4 w = philox4x32_10_lane(rng, (uint32_t)(e * QUADS + k), a.k0, a.k1);
+                const uint32_t ws[4] = {w.w0, w.w1, w.w2, w.w3};
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const int b = 4 * k + s;
+                    const uint32_t idx = __umulhi(ws[s], n32);
+                    buf[q * 4 * QUADS + b][tid] = idx;
+                    if (b < a.num_branches && ((idx >> granule_shift) & 7u) == xcd) m |= 1u << (q * 4 * QUADS + b);
+                }
+            }
+        }
+    }
+    double sum[BRX_PPT];
+#pragma unroll
+    for (int q = 0; q < BRX_PPT; ++q) sum[q] = 0.0;
+    while (__builtin_amdgcn_ballot_w64(m != 0u) != 0ull) {  // two of the thread's own gathers per trip, in branch order
+        const bool h0 = m != 0u;
+        const uint32_t i0 = h0 ? (uint32_t)__builtin_ctz(m) : 0u;
+        m &= m - (h0 ? 1u : 0u);
+        const bool h1 = m != 0u;
+        const uint32_t i1 = h1 ? (uint32_t)__builtin_ctz(m) : 0u;
+        m &= m - (h1 ? 1u : 0u);
+        const double v0 = h0 ? rowF[buf[i0][tid]] : 0.0;
+        const double v1 = h1 ? rowF[buf[i1][tid]] : 0.0;
+        if (i0 < 4u * QUADS) sum[0] += v0;
+        else sum[BRX_PPT - 1] += v0;
+        if (i1 < 4u * QUADS) sum[0] += v1;
+        else sum[BRX_PPT - 1] += v1;
+    }
+#pragma unroll
+    for (int q = 0; q < BRX_PPT; ++q)
+        if (p[q] < a.n) __builtin_nontemporal_store(sum[q], cells + (int64_t)xcd * ldc + p[q]);
+}
+
+__global__ __launch_bounds__(256) void k_branch_date_xcd_finish(BranchArgs a, int e, const double* cells, int64_t ldc, double2* state, int first_date,
+                                                                int branch) {
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    const bool call = a.is_call != 0;
+    const double inv_b = 1.0 / (double)a.num_branches;
+    const int t_idx = a.ex[e];
+    const double* rowS = a.S + (int64_t)t_idx * a.ld;
+    const double dsc = a.disc[t_idx];
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < a.n; p += (int64_t)gridDim.x * 256) {
+        v2d st = first_date ? v2d{0.0, 0.0} : __builtin_nontemporal_load(reinterpret_cast<const v2d*>(state) + p);
+        const double now = dsc * payoff_of(call, __builtin_nontemporal_load(rowS + p), a.K);
+        double better = now;
+        if (branch) {
+            double c = 0.0;
+#pragma unroll
+            for (int x = 0; x < 8; ++x) c += __builtin_nontemporal_load(cells + (int64_t)x * ldc + p);  // XCD order: the same bits every run
+            const double cont = c * inv_b;
+            if (cont > better) better = cont;
+        }
+        if (!(st.x > 0.0) && now > 0.0) st.x = now;
+        if (better > st.y) st.y = better;
+        __builtin_nontemporal_store(st, reinterpret_cast<v2d*>(state) + p);
+    }
+}
+
 // sum of {lower, upper} over the paths -> partials[grid][2]
 __global__ __launch_bounds__(256) void k_branch_finish(const double2* state, int64_t n, double* partials) {
     __shared__ double red[2 * 4];
@@ -521,7 +607,45 @@ int run_branching(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double m
     const int b_slices = (int)((((P->n_paths > 0 ? P->n_paths : 1) - 1) >> bshift) + 1);
     const bool binned = b_slices > study_switch("MCG_BRANCH_BINNED_ABOVE", BR_DATE_MAX_SLICES) && quads >= 1 && quads <= 3 && !ex.empty() && P->n_paths < ((int64_t)1 << 30) - 1 &&
                         study_switch("MCG_BRANCH_BINNED", 1) != 0;
-    if (binned) {
+    if (binned && study_switch("MCG_BRANCH_XCD", 0) != 0) {
+        // STUDY route (A/B builds only): XCD-affine gathers, see k_branch_date_xcd
+        const int64_t ldc = (P->n_paths + 511) / 512 * 512;
+        const int gshift = study_switch("MCG_BRANCH_XCD_SHIFT", 15);
+        void* cells = nullptr;
+        state_bytes = (size_t)P->n_paths * sizeof(double2);
+        rc = pool_alloc(ctx, state_bytes, &state);
+        if (!rc) rc = pool_alloc(ctx, (size_t)8 * ldc * sizeof(double), &cells);
+        if (rc) {
+            pool_release(ctx, Fbuf, P->bytes);
+            if (state) pool_release(ctx, state, state_bytes);
+            return rc;
+        }
+        const int64_t tiles = (P->n_paths + 256 * BRX_PPT - 1) / (256 * BRX_PPT);
+        {
+            TimedLaunch t(ctx, MCG_K_BRANCHING, 2 * (int64_t)ex.size() + 1);
+            for (int e = 0; e < (int)ex.size(); ++e) {
+                const int t_idx = ex[(size_t)e];
+                const bool branch = t_idx < ex_last && t_idx + 1 < n_cols;
+                if (branch) {
+                    const dim3 g((unsigned)(tiles * 8)), b(256);
+                    if (quads == 1) hipLaunchKernelGGL(k_branch_date_xcd<1>, g, b, 0, ctx->stream, a, e, (double*)cells, ldc, gshift);
+                    else if (quads == 2) hipLaunchKernelGGL(k_branch_date_xcd<2>, g, b, 0, ctx->stream, a, e, (double*)cells, ldc, gshift);
+                    else hipLaunchKernelGGL(k_branch_date_xcd<3>, g, b, 0, ctx->stream, a, e, (double*)cells, ldc, gshift);
+                }
+                hipLaunchKernelGGL(k_branch_date_xcd_finish, dim3(grid), dim3(256), 0, ctx->stream, a, e, (const double*)cells, ldc, (double2*)state,
+                                   e == 0, branch ? 1 : 0);
+            }
+            hipLaunchKernelGGL(k_branch_finish, dim3(grid), dim3(256), 0, ctx->stream, (const double2*)state, P->n_paths, ctx->partials);
+        }
+        n_partials = grid;
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) {
+            pool_release(ctx, Fbuf, P->bytes);
+            pool_release(ctx, state, state_bytes);
+            pool_release(ctx, cells, (size_t)8 * ldc * sizeof(double));
+            return fail(MCG_ERR_HIP, "BranchingProcesses: kernel launch failed");
+        }
+        pool_release(ctx, cells, (size_t)8 * ldc * sizeof(double));
+    } else if (binned) {
         // Paths per thread: a generation is three resident workgroups per CU of 256 x PPT paths, and a launch that is nearly
         // empty still walks -- and pulls through every XCD's L2 -- the whole row.  A/B on one board (round 5): 4M x 50
         // 21.4 ms at three paths per thread (6.8 generations) against 23.4 at four (5.1); 2M x 50 8.76 against 8.12
