@@ -378,60 +378,100 @@ __global__ __launch_bounds__(256, 3) void k_branch_date_binned(BranchArgs a, int
     }
 }
 
-// ---- XCD-AFFINE per-date gathers (round 6; a STUDY route: MCG_BRANCH_XCD in A/B builds) ---------------------
-// The binned kernel above pulls every slice of the row through the L2 of every XCD once per generation of resident paths.  Here
-// the row is dealt out to the XCDs in granules of 2^granule_shift paths: workgroup w (XCD w & 7 -- workgroups are handed to the
-// XCDs round-robin) draws ALL the indices of its tile's paths and gathers ONLY those whose granule belongs to its XCD, so an
-// XCD's L2 only ever sees its eighth of the row; every tile is worked on by eight workgroups, one per XCD, each leaving its
-// partial sum per path in a cell of its own (cells[xcd][path]); k_branch_date_xcd_finish adds the eight cells in XCD order
-// (deterministic) and updates the bounds.  Costs: the Philox draws eight times over, 64 B of cells written and read per path
-// and date.
+// ---- XCD-AFFINE per-date gathers (round 6): rows of F beyond ~14 MB (more than 1.8M paths) ------------------
+// The binned kernel above pulls every slice of the row through the L2 of every XCD once per generation of resident paths
+// (4M x 50: 200 MB beyond L2 per launch, 53 % hits, profiles/r05_branching_binned_counters.json).  Here the row is dealt out to
+// the XCDs in sixteen equal chunks: workgroup w (XCD w & 7 -- workgroups are handed to the XCDs round-robin) draws ALL the
+// indices of its tile's paths and gathers ONLY those whose chunk belongs to its XCD, so an XCD's L2 only ever sees its eighth
+// of the row (92 % hits at 4M paths: a 4 MB share in a 4 MB L2); every tile is worked on by eight workgroups, one per XCD,
+// each leaving its partial sum per path in a cell of its own (cells[xcd][path]); k_branch_date_xcd_finish adds the eight
+// cells in XCD order (deterministic: the same bits every run) and updates the bounds.  Costs: the Philox draws eight times
+// over -- the gather kernel is VALU-bound, 0.83 busy --, 64 B of cells written and 64 + 40 B read per path and date.
+// 4M x 50: 21.8 -> 15.1 ms, 3M x 50: 16.0 -> 11.1, 8M x 20: 21.4 -> 16.9, 2M x 50: 7.9 -> 7.5; 1.2M x 50 LOSES (4.19 -> 4.61:
+// its row fits two L2s), hence the threshold (gpurun_out/r6o_branch_xcd.log; counters: profiles/r06_branching_xcd_counters.json).
+// Tried on the way: the finishing pass folded into the next date's gather launch (an eighth of the tile per workgroup, first
+// wave): 15.7 -> 17.1 ms, dropped; chunks of 2^13 / 2^15 / 2^18 paths taken from the INDEX instead of the word's top bits:
+// 17.3 / 16.6 / 15.7 ms, and unbalanced whenever n is not a multiple of eight chunks (gpurun_out/r6n_branch_xcd.log).
 constexpr int BRX_PPT = 2;
+
+// bounds of path p after exercise date e: its eight cells added in XCD order (the same bits every run), then :62-65 and :123-127
+__device__ __forceinline__ void brx_finish_path(const BranchArgs& a, int e, const double* cells, int64_t ldc, double2* state, int first_date,
+                                                int branch, int64_t p) {
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    const bool call = a.is_call != 0;
+    const int t_idx = a.ex[e];
+    v2d st = first_date ? v2d{0.0, 0.0} : __builtin_nontemporal_load(reinterpret_cast<const v2d*>(state) + p);
+    const double now = a.disc[t_idx] * payoff_of(call, __builtin_nontemporal_load(a.S + (int64_t)t_idx * a.ld + p), a.K);
+    double better = now;
+    if (branch) {
+        double c = 0.0;
+#pragma unroll
+        for (int x = 0; x < 8; ++x) c += __builtin_nontemporal_load(cells + (int64_t)x * ldc + p);
+        const double cont = c * (1.0 / (double)a.num_branches);
+        if (cont > better) better = cont;
+    }
+    if (!(st.x > 0.0) && now > 0.0) st.x = now;
+    if (better > st.y) st.y = better;
+    __builtin_nontemporal_store(st, reinterpret_cast<v2d*>(state) + p);
+}
+
+// A tile = 512 paths; workgroup w works on tile w >> 3 for XCD w & 7.  Which XCD a draw belongs to is read off the TOP bits of its
+// Philox word (index = umulhi(word, n): the word's top four bits cut the row into sixteen equal chunks, chunk c to XCD c & 7 --
+// two chunks of n / 16 paths per XCD whatever n is), so a draw that is not this XCD's costs a bit-field extract, a compare and one
+// add-with-carry into the thread's mask; the words go to LDS four at a time and only the few that are kept are turned into indices.
 template <int QUADS>
-__global__ __launch_bounds__(256) void k_branch_date_xcd(BranchArgs a, int e, double* cells, int64_t ldc, int granule_shift) {
-    __shared__ uint32_t buf[4 * QUADS * BRX_PPT][256];  // [branch slot][thread]: a thread only ever reads its own column
+__global__ __launch_bounds__(256) void k_branch_date_xcd(BranchArgs a, int e, double* cells, int64_t ldc) {
+    __shared__ uint4 buf[QUADS * BRX_PPT][256];  // [Philox block of the thread][thread]: a thread only ever reads its own column
+    constexpr int DRAWS = 4 * QUADS * BRX_PPT;
     const unsigned tid = threadIdx.x;
     const uint32_t xcd = blockIdx.x & 7u;
     const int64_t tile = (int64_t)(blockIdx.x >> 3);
     const uint32_t n32 = (uint32_t)a.n;
     const int t_idx = a.ex[e];
     const double* rowF = a.F + (int64_t)(t_idx + 1) * a.ld;
+    // draws that exist: branch b < num_branches of either path; draw i (in drawing order) sits at bit DRAWS - 1 - i of the mask
+    uint32_t exists = 0;
+#pragma unroll
+    for (int i = 0; i < DRAWS; ++i) exists |= ((i % (4 * QUADS)) < a.num_branches ? 1u : 0u) << (DRAWS - 1 - i);
     uint32_t m = 0;
     int64_t p[BRX_PPT];
 #pragma unroll
     for (int q = 0; q < BRX_PPT; ++q) {
         p[q] = tile * (256 * BRX_PPT) + tid + q * 256;
-        if (p[q] < a.n) {
-            const PhiloxLane rng = philox_lane_setup(a.path_begin + (uint64_t)p[q], STREAM_BRANCH, a.k1);
+        const bool live = p[q] < a.n;
+        const PhiloxLane rng = philox_lane_setup(a.path_begin + (uint64_t)(live ? p[q] : a.n - 1), STREAM_BRANCH, a.k1);
 #pragma unroll
-            for (int k = 0; k < QUADS; ++k) {
-                const Philox4 w = philox4x32_10_lane(rng, (uint32_t)(e * QUADS + k), a.k0, a.k1);
-                const uint32_t ws[4] = {w.w0, w.w1, w.w2, w.w3};
+        for (int k = 0; k < QUADS; ++k) {
+            const Philox4 w = philox4x32_10_lane(rng, (uint32_t)(e * QUADS + k), a.k0, a.k1);
+            buf[q * QUADS + k][tid] = make_uint4(w.w0, w.w1, w.w2, w.w3);
+            const uint32_t ws[4] = {w.w0, w.w1, w.w2, w.w3};
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const int b = 4 * k + s;
-                    const uint32_t idx = __umulhi(ws[s], n32);
-                    buf[q * 4 * QUADS + b][tid] = idx;
-                    if (b < a.num_branches && ((idx >> granule_shift) & 7u) == xcd) m |= 1u << (q * 4 * QUADS + b);
-                }
-            }
+            for (int s = 0; s < 4; ++s) m = m + m + ((((ws[s] >> 28) & 7u) == xcd && live) ? 1u : 0u);
         }
     }
+    m &= exists;
     double sum[BRX_PPT];
 #pragma unroll
     for (int q = 0; q < BRX_PPT; ++q) sum[q] = 0.0;
-    while (__builtin_amdgcn_ballot_w64(m != 0u) != 0ull) {  // two of the thread's own gathers per trip, in branch order
+    const uint32_t* words = reinterpret_cast<const uint32_t*>(&buf[0][0]);
+    auto word_of = [&](uint32_t bit) {  // the Philox word of the draw at mask bit `bit`
+        const uint32_t i = (uint32_t)(DRAWS - 1) - bit;
+        return words[((i >> 2) * 256u + tid) * 4u + (i & 3u)];
+    };
+    while (__builtin_amdgcn_ballot_w64(m != 0u) != 0ull) {  // two of the thread's own gathers per trip
         const bool h0 = m != 0u;
-        const uint32_t i0 = h0 ? (uint32_t)__builtin_ctz(m) : 0u;
+        const uint32_t b0 = h0 ? (uint32_t)__builtin_ctz(m) : 0u;
         m &= m - (h0 ? 1u : 0u);
         const bool h1 = m != 0u;
-        const uint32_t i1 = h1 ? (uint32_t)__builtin_ctz(m) : 0u;
+        const uint32_t b1 = h1 ? (uint32_t)__builtin_ctz(m) : 0u;
         m &= m - (h1 ? 1u : 0u);
-        const double v0 = h0 ? rowF[buf[i0][tid]] : 0.0;
-        const double v1 = h1 ? rowF[buf[i1][tid]] : 0.0;
-        if (i0 < 4u * QUADS) sum[0] += v0;
+        const uint32_t w0 = word_of(b0), w1 = word_of(b1);
+        const double v0 = h0 ? rowF[__umulhi(w0, n32)] : 0.0;
+        const double v1 = h1 ? rowF[__umulhi(w1, n32)] : 0.0;
+        // (bits >= 4 QUADS belong to the thread's FIRST path: it was drawn first)
+        if (b0 >= 4u * QUADS) sum[0] += v0;
         else sum[BRX_PPT - 1] += v0;
-        if (i1 < 4u * QUADS) sum[0] += v1;
+        if (b1 >= 4u * QUADS) sum[0] += v1;
         else sum[BRX_PPT - 1] += v1;
     }
 #pragma unroll
@@ -441,27 +481,8 @@ __global__ __launch_bounds__(256) void k_branch_date_xcd(BranchArgs a, int e, do
 
 __global__ __launch_bounds__(256) void k_branch_date_xcd_finish(BranchArgs a, int e, const double* cells, int64_t ldc, double2* state, int first_date,
                                                                 int branch) {
-    typedef double v2d __attribute__((ext_vector_type(2)));
-    const bool call = a.is_call != 0;
-    const double inv_b = 1.0 / (double)a.num_branches;
-    const int t_idx = a.ex[e];
-    const double* rowS = a.S + (int64_t)t_idx * a.ld;
-    const double dsc = a.disc[t_idx];
-    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < a.n; p += (int64_t)gridDim.x * 256) {
-        v2d st = first_date ? v2d{0.0, 0.0} : __builtin_nontemporal_load(reinterpret_cast<const v2d*>(state) + p);
-        const double now = dsc * payoff_of(call, __builtin_nontemporal_load(rowS + p), a.K);
-        double better = now;
-        if (branch) {
-            double c = 0.0;
-#pragma unroll
-            for (int x = 0; x < 8; ++x) c += __builtin_nontemporal_load(cells + (int64_t)x * ldc + p);  // XCD order: the same bits every run
-            const double cont = c * inv_b;
-            if (cont > better) better = cont;
-        }
-        if (!(st.x > 0.0) && now > 0.0) st.x = now;
-        if (better > st.y) st.y = better;
-        __builtin_nontemporal_store(st, reinterpret_cast<v2d*>(state) + p);
-    }
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < a.n; p += (int64_t)gridDim.x * 256)
+        brx_finish_path(a, e, cells, ldc, state, first_date, branch, p);
 }
 
 // sum of {lower, upper} over the paths -> partials[grid][2]
@@ -607,14 +628,16 @@ int run_branching(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double m
     const int b_slices = (int)((((P->n_paths > 0 ? P->n_paths : 1) - 1) >> bshift) + 1);
     const bool binned = b_slices > study_switch("MCG_BRANCH_BINNED_ABOVE", BR_DATE_MAX_SLICES) && quads >= 1 && quads <= 3 && !ex.empty() && P->n_paths < ((int64_t)1 << 30) - 1 &&
                         study_switch("MCG_BRANCH_BINNED", 1) != 0;
-    if (binned && study_switch("MCG_BRANCH_XCD", 0) != 0) {
-        // STUDY route (A/B builds only): XCD-affine gathers, see k_branch_date_xcd
+    constexpr int64_t BRX_MIN_PATHS = (int64_t)7 << 18;   // 1.835M paths = rows of 14 MB: below, the binned kernel is at least as fast
+    const int xcd_switch = study_switch("MCG_BRANCH_XCD", -1);   // (A/B builds: 0 never, 1 always)
+    if (binned && (xcd_switch < 0 ? P->n_paths >= BRX_MIN_PATHS : xcd_switch != 0)) {
+        // XCD-affine gathers (k_branch_date_xcd): a gather launch and a finishing pass per exercise date
         const int64_t ldc = (P->n_paths + 511) / 512 * 512;
-        const int gshift = study_switch("MCG_BRANCH_XCD_SHIFT", 15);
         void* cells = nullptr;
+        const size_t cells_bytes = (size_t)8 * ldc * sizeof(double);
         state_bytes = (size_t)P->n_paths * sizeof(double2);
         rc = pool_alloc(ctx, state_bytes, &state);
-        if (!rc) rc = pool_alloc(ctx, (size_t)8 * ldc * sizeof(double), &cells);
+        if (!rc) rc = pool_alloc(ctx, cells_bytes, &cells);
         if (rc) {
             pool_release(ctx, Fbuf, P->bytes);
             if (state) pool_release(ctx, state, state_bytes);
@@ -628,9 +651,9 @@ int run_branching(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double m
                 const bool branch = t_idx < ex_last && t_idx + 1 < n_cols;
                 if (branch) {
                     const dim3 g((unsigned)(tiles * 8)), b(256);
-                    if (quads == 1) hipLaunchKernelGGL(k_branch_date_xcd<1>, g, b, 0, ctx->stream, a, e, (double*)cells, ldc, gshift);
-                    else if (quads == 2) hipLaunchKernelGGL(k_branch_date_xcd<2>, g, b, 0, ctx->stream, a, e, (double*)cells, ldc, gshift);
-                    else hipLaunchKernelGGL(k_branch_date_xcd<3>, g, b, 0, ctx->stream, a, e, (double*)cells, ldc, gshift);
+                    if (quads == 1) hipLaunchKernelGGL(k_branch_date_xcd<1>, g, b, 0, ctx->stream, a, e, (double*)cells, ldc);
+                    else if (quads == 2) hipLaunchKernelGGL(k_branch_date_xcd<2>, g, b, 0, ctx->stream, a, e, (double*)cells, ldc);
+                    else hipLaunchKernelGGL(k_branch_date_xcd<3>, g, b, 0, ctx->stream, a, e, (double*)cells, ldc);
                 }
                 hipLaunchKernelGGL(k_branch_date_xcd_finish, dim3(grid), dim3(256), 0, ctx->stream, a, e, (const double*)cells, ldc, (double2*)state,
                                    e == 0, branch ? 1 : 0);
@@ -641,10 +664,10 @@ int run_branching(mcg_ctx* ctx, const mcg_paths* P, double r, double K, double m
         if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) {
             pool_release(ctx, Fbuf, P->bytes);
             pool_release(ctx, state, state_bytes);
-            pool_release(ctx, cells, (size_t)8 * ldc * sizeof(double));
+            pool_release(ctx, cells, cells_bytes);
             return fail(MCG_ERR_HIP, "BranchingProcesses: kernel launch failed");
         }
-        pool_release(ctx, cells, (size_t)8 * ldc * sizeof(double));
+        pool_release(ctx, cells, cells_bytes);
     } else if (binned) {
         // Paths per thread: a generation is three resident workgroups per CU of 256 x PPT paths, and a launch that is nearly
         // empty still walks -- and pulls through every XCD's L2 -- the whole row.  A/B on one board (round 5): 4M x 50

@@ -308,13 +308,15 @@ def test_eight_rank_threads_equal_single_rank(tmp_path, mode):
     (524_289, 6, 7, "sparse"),      # 3 slices, two Philox blocks per path and date, a sparse exercise list
     (300_001, 6, 3, "shuffled"),    # a list that is not ascending: its LAST entry, not its largest, ends the branching
     (1_100_000, 5, 10, "all"),      # 5 slices: beyond k_branch_date's range -- round 5: k_branch_date_binned (indices sorted by slice per thread)
-    (4_000_001, 4, 10, "all"),      # 16 slices of 2 MB (the shape VERDICT r4 names, fewer dates): binned, six launches per date
+    (4_000_001, 4, 10, "all"),      # rows of 32 MB (the shape VERDICT r4 / r5 name, fewer dates) -- round 6: the XCD-affine route
+    #                                 (k_branch_date_xcd: every XCD gathers from its eighth of the row, eight cells per path summed in order)
     (1_300_000, 4, 7, "sparse4"),   # binned with two Philox blocks per path and date, a sparse list
-    (2_500_000, 3, 3, "all"),       # binned with one block (three of its four indices used)
+    (2_500_000, 3, 3, "all"),       # XCD-affine with one block (three of its four indices used)
+    (2_000_001, 3, 7, "all"),       # XCD-affine with two blocks, a ragged last tile
     (300_001, 5, 13, "all"),        # more than twelve branches: indices are not kept, no slices
 ])
 def test_branching_rows_beyond_one_slice_match_oracle(n_paths, steps, branches, ex_kind):
-    """k_branch_date / k_branch_date_binned / the sliced k_branch_bounds against the oracle in philox mode (the same
+    """k_branch_date / k_branch_date_binned / k_branch_date_xcd / the sliced k_branch_bounds against the oracle in philox mode (the same
     resampling draws): the slices only change WHEN an index is gathered, and the order in which a path's branch values are
     summed."""
     from oracle.binding import Oracle

@@ -213,9 +213,9 @@ def widening_configs(eng, N, mc, baselines=None) -> list:
         if baselines and key in baselines:
             out[-1]["cpu_baseline"] = dict(baselines[key], gpu_comparable="Mpaths_per_s_of_device_time")
     P.free()
-    # BranchingProcesses on rows of F beyond one L2: 4M paths x 50 dates, rows of 32 MB, the binned
-    # per-date kernel (k_branch_date_binned).  What bounds it is stated with the row: every generation of resident paths
-    # pulls the whole row through the L2 of every XCD.
+    # BranchingProcesses on rows of F beyond one L2: 4M paths x 50 dates, rows of 32 MB.  Round 6: the XCD-affine route
+    # (k_branch_date_xcd + k_branch_date_xcd_finish: every XCD gathers only from its eighth of the row); what bounds it is stated
+    # with the row.
     n4 = 4_000_000
     P4 = eng.gbm(SEED, 100.0, 0.04, 0.2, dt, steps, n4)
     eng.price_branching(P4, 0.04, 100.0, 1.0, dt, False, 10, ex, SEED)
@@ -226,13 +226,15 @@ def widening_configs(eng, N, mc, baselines=None) -> list:
     eng.synchronize()
     ms4, cnt4 = eng.timing_get(N.K_BRANCHING)
     P4.free()
-    moved4 = 3.0 * 8.0 * (steps + 1) * n4 + 8.0 * 10 * steps * n4
+    moved4 = 3.0 * 8.0 * (steps + 1) * n4 + 8.0 * 10 * steps * n4 + (64.0 + 64.0 + 40.0) * steps * n4
     out.append({"config": "BranchingProcesses::PredictOptionPrice (put, 10 branches, 50 exercise dates) on a 4M x 50 GBM matrix (rows of F: 32 MB, 16 slices)",
                 "paths": n4, "price": price4, "kernel_ms_per_call": ms4 / reps, "launches_per_call": cnt4 // reps,
-                "bytes_moved_per_call": moved4, "bytes_moved": "as the C3-matrix row above: S read twice, F written, 10 gathers of 8 B per path and date",
+                "bytes_moved_per_call": moved4, "bytes_moved": "as the C3-matrix row above (S read twice, F written, 10 gathers of 8 B per path and date) + per path and date 64 B of "
+                               "per-XCD cells written and read and 40 B of bounds and prices in the finishing pass",
                 "hbm_frac": moved4 / (ms4 / reps * 1e-3) / 1e9 / HBM_PEAK_GBS, "Mpaths_per_s_of_device_time": n4 / (ms4 / reps) / 1e3,
-                "bound": "L2 fill: the gathers of a generation of resident paths (590k-786k) touch every line of the 32 MB row in every XCD's L2 "
-                         "(counters: profiles/r05_branching_binned_counters.json)"})
+                "bound": "VALU issue of the gather launches (every tile's Philox draws are made by eight workgroups, one per XCD, each keeping "
+                         "its XCD's eighth of the row: 92 % L2 hits, 0.83 VALU busy) + the finishing pass's 104 B per path and date "
+                         "(counters: profiles/r06_branching_xcd_counters.json; round 5's binned kernel: 21.4 ms, 53 % hits)"})
     rs = np.random.RandomState(0)   # the row mix of tools/bench_rows.py: 5..126 steps, calls and puts around the money
     rows = []
     for _ in range(20_000):
