@@ -261,9 +261,13 @@ int mcg_compat_set_seed(uint64_t seed, int enabled); /* default: std::random_dev
  * matrix), the reference's driver unchanged (src/core/PredictionGen.cpp:542-570, :736-737, :788-791: one row per OpenMP
  * thread, five calls per row).  Shapes the row kernels serve -- at most 256 paths, 1 .. 1020 steps, polynomial order <= 4,
  * BranchingProcesses with the driver's exercise dates 0 .. steps - 1; anything else, or everything after
- * mcg_compat_set_coalescing(0), runs on the calling thread's own context as before.  On by default; a lone caller is a round
- * of one.  mcg_stats counts rounds, calls and fall-backs. */
-int mcg_compat_set_coalescing(int enabled);
+ * mcg_compat_set_coalescing(0), runs on the calling thread's own context as before.  Mode 1 (the default) also PREFETCHES: the
+ * first pricer call on a matrix the library already holds on the device queues the driver's other three pricers with the driver's
+ * arguments (:788-791: the same r, strike, maturity, dt, isCall; 10 branches, order 2, 5 iterations), each in the lane of its kind,
+ * so that the four run side by side; a later call is answered from that only if it asks for exactly what was computed on exactly
+ * that matrix.  Mode 2: coalescing without the prefetch.  A lone caller is a round of one.  mcg_stats counts rounds, calls,
+ * prefetches, hits and fall-backs. */
+int mcg_compat_set_coalescing(int mode);
 int mcg_compat_generate_paths(const double* hist, size_t n, int forward_steps, int path_num,
                               double* row_major_out);
 int mcg_compat_lsm_price(const double* row_major, int64_t n_paths, int n_cols, double r,
@@ -329,7 +333,9 @@ typedef struct mcg_stats_t {
     int64_t coalesced_fallbacks;       /* class-API calls that took the calling thread's own context instead (shape beyond the row kernels, coalescing off) */
     int64_t coalesced_round_us;        /* wall time of the rounds, summed (packing + upload + launches + synchronisation), microseconds */
     int64_t coalesced_device_wait_us;  /* ... of which inside hipStreamSynchronize                                          */
-    int64_t coalesced_wake_us;         /* time the leaders spent waking the callers they had answered (overlaps the next round) */
+    int64_t coalesced_wake_us;         /* time the lanes' service threads spent waking the callers they had answered         */
+    int64_t coalesced_prefetched;      /* pricer calls made ahead of the caller asking (the other pricers of a row, with the driver's arguments) */
+    int64_t coalesced_prefetch_hits;   /* ... whose answer the caller then took (its call matched): no device round trip of its own */
 } mcg_stats_t;
 int mcg_stats(mcg_stats_t* out, int reset);
 

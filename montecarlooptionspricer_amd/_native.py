@@ -30,7 +30,8 @@ class Stats(C.Structure):
         "lsm_per_date_refits", "lsm_per_date_faults", "shm_barrier_failures", "peer_mailbox_enabled", "peer_mailbox_refused",
         "batch_calls", "batch_chunks", "batch_rows", "batch_rows_singly", "batch_peak_workspace_bytes",
         "peer_mailbox_kept", "coalesced_rounds", "coalesced_calls", "coalesced_peak_calls_per_round", "coalesced_fallbacks",
-        "coalesced_round_us", "coalesced_device_wait_us", "coalesced_wake_us")]
+        "coalesced_round_us", "coalesced_device_wait_us", "coalesced_wake_us", "coalesced_prefetched",
+        "coalesced_prefetch_hits")]
 
 
 class McgError(RuntimeError):

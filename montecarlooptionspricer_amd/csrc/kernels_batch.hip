@@ -1024,8 +1024,9 @@ int run_round(mcg_ctx* ctx, RoundBuffers& rb, double* arena_base, Request** reqs
     if (n_gen) hipLaunchKernelGGL(k_co_gather, dim3((unsigned)(n_gen * (size_t)gen_tiles)), dim3(256), 0, ctx->stream, d_x, (const double*)arena_base, gen_tiles);
     MCG_HIP(hipGetLastError());
     const auto t_sync = std::chrono::steady_clock::now();
-    // (a blocking event instead of this spinning wait, and 0 / 200 / 2000 spins of the callers before they sleep, were
-    // measured on the 16-CPU GPU box at 128 and 16 threads: no difference beyond noise, gpurun_out/r6h_co_sweep.log)
+    // (a blocking event instead of this spinning wait, 100 / 1000 spins of the callers before they sleep and 200 / 4000 of an idle
+    // lane were measured on the 16-CPU GPU box at 128 and 16 threads: no difference beyond the run-to-run noise of +-10 %,
+    // gpurun_out/r6h_co_sweep.log, r6s_co_sweep.log)
     MCG_HIP(hipStreamSynchronize(ctx->stream));
     const auto t_end = std::chrono::steady_clock::now();
     g_stats.coalesced_round_us.fetch_add((int64_t)std::chrono::duration<double, std::micro>(t_end - t_begin).count(), std::memory_order_relaxed);

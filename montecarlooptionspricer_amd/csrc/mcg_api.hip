@@ -706,7 +706,7 @@ int mcg_stats(mcg_stats_t* out, int reset) {
                                    &g_stats.batch_peak_workspace_bytes, &g_stats.peer_mailbox_kept,
                                    &g_stats.coalesced_rounds, &g_stats.coalesced_calls, &g_stats.coalesced_peak_calls_per_round,
                                    &g_stats.coalesced_fallbacks, &g_stats.coalesced_round_us, &g_stats.coalesced_device_wait_us,
-                                   &g_stats.coalesced_wake_us};
+                                   &g_stats.coalesced_wake_us, &g_stats.coalesced_prefetched, &g_stats.coalesced_prefetch_hits};
     static_assert(sizeof(mcg_stats_t) == sizeof(src) / sizeof(src[0]) * sizeof(int64_t), "mcg_stats_t lists the counters in this order");
     int64_t* dst = reinterpret_cast<int64_t*>(out);
     for (size_t k = 0; k < sizeof(src) / sizeof(src[0]); ++k) {

@@ -37,7 +37,7 @@ struct Stats {
         lsm_per_date_refits{0}, lsm_per_date_faults{0}, shm_barrier_failures{0}, peer_mailbox_enabled{0}, peer_mailbox_refused{0},
         batch_calls{0}, batch_chunks{0}, batch_rows{0}, batch_rows_singly{0}, batch_peak_workspace_bytes{0}, peer_mailbox_kept{0},
         coalesced_rounds{0}, coalesced_calls{0}, coalesced_peak_calls_per_round{0}, coalesced_fallbacks{0},
-        coalesced_round_us{0}, coalesced_device_wait_us{0}, coalesced_wake_us{0};
+        coalesced_round_us{0}, coalesced_device_wait_us{0}, coalesced_wake_us{0}, coalesced_prefetched{0}, coalesced_prefetch_hits{0};
 };
 extern Stats g_stats;
 

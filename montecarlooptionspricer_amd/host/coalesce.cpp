@@ -1,20 +1,21 @@
-// The combiner behind the reference's class API (csrc/coalesce.hpp has the why): request queue, leader election, the
-// per-thread matrix slots of the device arena and the per-thread pinned host buffers.
+// The combiner behind the reference's class API (csrc/coalesce.hpp has the why): one LANE per kind of call -- its request queue,
+// its service thread, its context (stream) and round buffers --, the per-thread matrix slots of the device arena and the
+// per-thread pinned host buffers.
 //
-// Protocol.  A caller pushes its request and, if nobody leads, becomes the leader: it takes EVERYTHING queued (its own
-// request included), runs one round (co::execute_round: one upload, one launch per kind of call, one synchronisation),
-// marks the requests done, hands the lead to the first caller that queued up meanwhile, and only then wakes the others --
-// so the wake-ups overlap the next round.  While a round is on the device the other threads' calls pile up: that pile IS
-// the next batch (group commit); nobody waits on a timer, and a lone caller is a round of one with no added latency.
-// Waiting is a short spin, then a futex sleep on the waiter's own state word; the leader touches a waiter for the last
-// time when it stores that word (a wake-up on an address whose owner has already left is harmless by futex semantics).
-// Every request of a round that fails carries the failure; nothing throws across the leader.
+// Protocol.  A caller pushes its request into the lane of its kind and waits (a short spin, then a futex sleep on the waiter's own
+// state word).  The lane's SERVICE THREAD takes EVERYTHING queued, runs one round (co::execute_round: one upload, one launch per
+// group of calls, one synchronisation), marks the requests done and wakes their owners; while a round is on the device the other
+// threads' calls pile up: that pile IS the next batch (group commit) -- nobody waits on a timer, and a lone caller is a round of
+// one.  The service thread touches a waiter for the last time when it stores its state word (a wake-up on an address whose owner
+// has already left is harmless by futex semantics).  Every request of a round that fails carries the failure.
 //
-// One such queue PER KIND of call (generate, AsymptoticAnalysis, BranchingProcesses, LSM, MartingaleOptimization), each with
-// its own context (stream) and round buffers: the kinds' row kernels differ tenfold in latency (a row's LSM sweep walks its
-// dates one after another: ~360 us at 126 steps; its MartingaleOptimization takes 20 us) and a caller of a short kind must
-// not sit out a round of the long one -- with ONE queue a round cost the sum of its kinds' kernels (~570 us), a call waited
-// one and a half rounds, a row five calls (measured, gpurun_out/r6e_unchanged.log).  The lanes' kernels overlap on the device.
+// One lane per kind (generate, AsymptoticAnalysis, BranchingProcesses, LSM, MartingaleOptimization): the kinds' row kernels differ
+// tenfold in latency (a row's LSM sweep walks its dates one after another: ~360 us at 126 steps; its MartingaleOptimization
+// takes 20 us) and a caller of a short kind must not sit out a round of the long one -- with ONE queue a round cost the sum of its
+// kinds' kernels (~570 us) and a row five such waits (measured, gpurun_out/r6e_unchanged.log).  The lanes' kernels overlap on the
+// device.  Service threads instead of "the first caller leads" (the first version of this file, 37-43 k rows/s at 128 threads): a
+// caller can then have requests in SEVERAL lanes at once without owing any of them its attention -- which is what the prefetch of a
+// row's other pricers needs (host/dropin.cpp: co_price) -- and no caller's own work waits behind the round it happened to lead.
 #include "../csrc/coalesce.hpp"
 
 #include <linux/futex.h>
@@ -27,6 +28,7 @@
 #include <climits>
 #include <cstring>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "../csrc/mcg_internal.hpp"
@@ -36,21 +38,16 @@ namespace mcg {
 namespace co {
 namespace {
 
-enum : int { WAITING = 0, SLEEPING = 1, DONE = 2, LEAD = 3 };
-
-struct Waiter {
-    Request* req;
-    std::atomic<int> state{WAITING};
-};
+enum : int { WAITING = 0, SLEEPING = 1, DONE = 2 };
 
 void futex_wake(std::atomic<int>* w) { syscall(SYS_futex, reinterpret_cast<int*>(w), FUTEX_WAKE_PRIVATE, 1, nullptr, nullptr, 0); }
 void futex_sleep(std::atomic<int>* w, int expected) {
     syscall(SYS_futex, reinterpret_cast<int*>(w), FUTEX_WAIT_PRIVATE, expected, nullptr, nullptr, 0);
 }
-
-// Publish a state; wake the owner if it went to sleep.
-void publish(Waiter* w, int s) {
-    if (w->state.exchange(s, std::memory_order_acq_rel) == SLEEPING) futex_wake(&w->state);
+inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#endif
 }
 
 constexpr int SLOTS_PER_CHUNK = 32;  // 32 x 2.09 MB = 67 MB of HBM per chunk, allocated when the 1st, 33rd, ... thread arrives
@@ -58,7 +55,8 @@ constexpr int MAX_CHUNKS = 16;       // 512 calling threads hold a slot; later o
 
 class Combiner {
 public:
-    int submit(Request& r);
+    void enqueue(Waiter* w);
+    static void wait(Waiter* w);
     int acquire_slot(int64_t* off);
     void release_slot(int idx);
     int device() const { return device_; }
@@ -67,28 +65,36 @@ public:
         if (init_rc_ != MCG_OK) return fail(init_rc_, "%s", init_err_.c_str());
         return MCG_OK;
     }
+    void stop();
 
 private:
-    struct Lane {  // one kind of call: its queue, its lead, its stream
+    struct Lane {  // one kind of call: its queue, its service thread, its stream
         mcg_ctx* ctx = nullptr;
         RoundBuffers rb;
-        std::mutex mu;  // the queue and the lead
+        std::mutex mu;
         std::vector<Waiter*> queue;
-        bool leader_active = false;
+        std::atomic<int> idle{0};  // 1 while the service thread sleeps (futex word)
+        std::thread th;
     };
     void init();
-    void lead(Lane& L, std::unique_lock<std::mutex>& lk, Waiter* self);
+    void serve(Lane& L);
 
     std::once_flag once_;
     int init_rc_ = MCG_OK;
     std::string init_err_;
     int device_ = 0;
     Lane lanes_[N_KINDS];
+    std::atomic<bool> stopping_{false};
 
     std::mutex slot_mu_;  // the arena
     std::vector<double*> chunks_;
     std::vector<int> free_slots_;
 };
+
+Combiner& combiner() {
+    static Combiner* c = new Combiner;  // never destroyed: threads may still be leaving when the process ends
+    return *c;
+}
 
 void Combiner::init() {
     if (const char* e = std::getenv("MCG_DEVICE")) device_ = std::atoi(e);
@@ -100,6 +106,86 @@ void Combiner::init() {
             L.ctx = nullptr;
             return;
         }
+    }
+    for (Lane& L : lanes_) L.th = std::thread([this, &L] { serve(L); });
+    // the service threads leave before the HIP runtime's own tear-down (handlers run in reverse order of registration, and
+    // the runtime registered its when the library was loaded)
+    std::atexit([] { combiner().stop(); });
+}
+
+void Combiner::stop() {
+    stopping_.store(true, std::memory_order_release);
+    for (Lane& L : lanes_) {
+        if (L.idle.exchange(0, std::memory_order_acq_rel) == 1) futex_wake(&L.idle);
+        if (L.th.joinable()) L.th.join();
+    }
+}
+
+void Combiner::serve(Lane& L) {
+    (void)hipSetDevice(device_);
+    std::vector<Waiter*> batch;
+    std::vector<Request*> reqs;
+    for (;;) {
+        for (int spins = 0;;) {  // wait for work: a short spin, then sleep until an enqueuer wakes us
+            {
+                std::lock_guard<std::mutex> g(L.mu);
+                if (!L.queue.empty()) {
+                    batch.swap(L.queue);
+                    break;
+                }
+            }
+            if (stopping_.load(std::memory_order_acquire)) return;
+            if (++spins < 4000) {
+                cpu_relax();
+                continue;
+            }
+            L.idle.store(1, std::memory_order_release);
+            bool work;
+            {
+                std::lock_guard<std::mutex> g(L.mu);  // (an enqueuer that pushed before this sees idle = 1 after it, or we see its push)
+                work = !L.queue.empty();
+            }
+            if (!work && !stopping_.load(std::memory_order_acquire)) futex_sleep(&L.idle, 1);
+            L.idle.store(0, std::memory_order_release);
+            spins = 0;
+        }
+        reqs.resize(batch.size());
+        for (size_t i = 0; i < batch.size(); ++i) reqs[i] = batch[i]->req;
+        double* base;
+        {
+            std::lock_guard<std::mutex> g(slot_mu_);
+            base = chunks_.empty() ? nullptr : chunks_[0];
+        }
+        (void)execute_round(L.ctx, L.rb, base, reqs.data(), (int)reqs.size());  // every request now carries its status
+        const auto t0 = std::chrono::steady_clock::now();
+        for (Waiter* w : batch)
+            if (w->state.exchange(DONE, std::memory_order_acq_rel) == SLEEPING) futex_wake(&w->state);
+        g_stats.coalesced_wake_us.fetch_add((int64_t)std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(),
+                                            std::memory_order_relaxed);
+        batch.clear();
+    }
+}
+
+void Combiner::enqueue(Waiter* w) {
+    Lane& L = lanes_[w->req->kind >= 0 && w->req->kind < N_KINDS ? w->req->kind : 0];
+    w->state.store(WAITING, std::memory_order_relaxed);
+    {
+        std::lock_guard<std::mutex> g(L.mu);
+        L.queue.push_back(w);
+    }
+    if (L.idle.load(std::memory_order_acquire) == 1 && L.idle.exchange(0, std::memory_order_acq_rel) == 1) futex_wake(&L.idle);
+}
+
+void Combiner::wait(Waiter* w) {
+    for (int spins = 0;;) {
+        const int s = w->state.load(std::memory_order_acquire);
+        if (s == DONE) return;
+        if (++spins < 1000) {
+            cpu_relax();
+            continue;
+        }
+        int expect = WAITING;
+        if (w->state.compare_exchange_strong(expect, SLEEPING, std::memory_order_acq_rel) || expect == SLEEPING) futex_sleep(&w->state, SLEEPING);
     }
 }
 
@@ -129,90 +215,19 @@ void Combiner::release_slot(int idx) {
     free_slots_.push_back(idx);
 }
 
-void Combiner::lead(Lane& L, std::unique_lock<std::mutex>& lk, Waiter* self) {
-    // (this thread's own: the previous leader may still be walking ITS batch, waking callers, when this round starts)
-    thread_local std::vector<Waiter*> batch_;
-    thread_local std::vector<Request*> reqs_;
-    batch_.clear();
-    batch_.swap(L.queue);
-    lk.unlock();
-    reqs_.resize(batch_.size());
-    for (size_t i = 0; i < batch_.size(); ++i) reqs_[i] = batch_[i]->req;
-    double* base;
-    {
-        std::lock_guard<std::mutex> g(slot_mu_);
-        base = chunks_.empty() ? nullptr : chunks_[0];
-    }
-    (void)execute_round(L.ctx, L.rb, base, reqs_.data(), (int)reqs_.size());  // every request now carries its status
-    lk.lock();
-    Waiter* next = nullptr;
-    if (!L.queue.empty()) next = L.queue.front();
-    else L.leader_active = false;
-    lk.unlock();
-    if (next) publish(next, LEAD);  // the next round starts while this thread wakes the answered callers
-    const auto t0 = std::chrono::steady_clock::now();
-    for (Waiter* w : batch_)
-        if (w != self) publish(w, DONE);
-    self->state.store(DONE, std::memory_order_release);
-    g_stats.coalesced_wake_us.fetch_add((int64_t)std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(),
-                                        std::memory_order_relaxed);
-    lk.lock();
-}
-
-int Combiner::submit(Request& r) {
-    int rc = ready();
-    if (rc) {
-        r.status = rc;
-        std::snprintf(r.err, sizeof r.err, "%s", mcg_last_error());
-        return rc;
-    }
-    Waiter w;
-    w.req = &r;
-    Lane& L = lanes_[r.kind >= 0 && r.kind < N_KINDS ? r.kind : 0];
-    std::unique_lock<std::mutex> lk(L.mu);
-    L.queue.push_back(&w);
-    if (!L.leader_active) {
-        L.leader_active = true;
-        w.state.store(LEAD, std::memory_order_relaxed);
-    }
-    lk.unlock();
-    for (int spins = 0;;) {
-        int s = w.state.load(std::memory_order_acquire);
-        if (s == DONE) break;
-        if (s == LEAD) {
-            lk.lock();
-            lead(L, lk, &w);
-            lk.unlock();
-            continue;
-        }
-        if (++spins < 1000) {
-#if defined(__x86_64__) || defined(__i386__)
-            __builtin_ia32_pause();
-#endif
-            continue;
-        }
-        int expect = WAITING;
-        if (w.state.compare_exchange_strong(expect, SLEEPING, std::memory_order_acq_rel)) futex_sleep(&w.state, SLEEPING);
-        else if (expect == SLEEPING) futex_sleep(&w.state, SLEEPING);  // (woken without a new state: sleep again)
-    }
-    return r.status;
-}
-
-Combiner& combiner() {
-    static Combiner* c = new Combiner;  // never destroyed: threads may still be leaving when the process ends
-    return *c;
-}
-
 }  // namespace
 
 // ---- the calling thread's side --------------------------------------------------------------------------------------
 
 ThreadState::~ThreadState() {
+    drain();  // nothing of ours may still be on the device when the buffers go
     if (pinned) (void)hipHostFree(pinned);
     if (slot >= 0) combiner().release_slot(slot);
 }
 
 int ThreadState::prepare(int n_paths, int n_cols) {
+    drain();
+    forget_prefetched();
     valid = false;
     Combiner& c = combiner();
     int rc = c.ready();
@@ -243,10 +258,20 @@ bool ThreadState::holds(const std::vector<std::vector<double>>& rows, size_t col
 }
 
 int ThreadState::submit(Request& r) {
+    Combiner& c = combiner();
+    int rc = c.ready();
+    if (rc) {
+        r.status = rc;
+        return rc;
+    }
     r.slot_off = slot_off;
     r.host = pinned;
     r.host_dev = pinned_dev;
-    const int rc = combiner().submit(r);
+    Waiter w;
+    w.req = &r;
+    c.enqueue(&w);
+    Combiner::wait(&w);
+    rc = r.status;
     if (rc == MCG_OK) {
         valid = true;
         n = r.n_paths;
@@ -256,6 +281,53 @@ int ThreadState::submit(Request& r) {
         set_error("%s", r.err[0] ? r.err : "coalesced call failed");
     }
     return rc;
+}
+
+void ThreadState::prefetch(const Request& r) {
+    Combiner& c = combiner();
+    if (r.kind < 0 || r.kind >= N_KINDS || c.ready() != MCG_OK) return;
+    Prefetched& p = ahead[r.kind];
+    if (p.in_flight) Combiner::wait(&p.w);
+    p.req = r;
+    p.req.slot_off = slot_off;
+    p.req.host = pinned;
+    p.req.host_dev = pinned_dev;
+    p.req.upload = false;
+    p.w.req = &p.req;
+    p.in_flight = true;
+    p.usable = true;
+    c.enqueue(&p.w);
+    g_stats.coalesced_prefetched.fetch_add(1, std::memory_order_relaxed);
+}
+
+bool ThreadState::take_prefetched(int kind, double* price) {
+    Prefetched& p = ahead[kind];
+    if (!p.usable) return false;
+    if (p.in_flight) {
+        Combiner::wait(&p.w);
+        p.in_flight = false;
+    }
+    if (p.req.status != MCG_OK) {  // the ordinary call will say why
+        p.usable = false;
+        return false;
+    }
+    *price = p.req.price;
+    g_stats.coalesced_prefetch_hits.fetch_add(1, std::memory_order_relaxed);
+    return true;
+}
+
+void ThreadState::drain() {
+    for (Prefetched& p : ahead) {
+        if (p.in_flight) {
+            Combiner::wait(&p.w);
+            p.in_flight = false;
+        }
+    }
+}
+
+void ThreadState::forget_prefetched() {
+    for (Prefetched& p : ahead) p.usable = false;
+    prefetched_for_this_matrix = false;
 }
 
 ThreadState& thread_state() {

@@ -73,8 +73,9 @@ struct ThreadCtx {
 };
 thread_local ThreadCtx t_ctx;
 
-// Calls of different host threads are answered together (csrc/coalesce.hpp) unless mcg_compat_set_coalescing(0) said otherwise.
-std::atomic<bool> g_coalesce{true};
+// Calls of different host threads are answered together (csrc/coalesce.hpp) unless mcg_compat_set_coalescing(0) said otherwise;
+// mode 1 (the default) also makes a row's other pricer calls AHEAD of the driver asking for them (co_price), mode 2 does not.
+std::atomic<int> g_coalesce{1};
 
 std::atomic<bool> g_seed_fixed{false};
 std::atomic<uint64_t> g_seed{0};
@@ -123,14 +124,35 @@ mcg_paths* device_matrix(const std::vector<std::vector<double>>& pricePaths, con
 
 // ---- the coalesced route (csrc/coalesce.hpp): shapes the row kernels serve -- at most 256 paths, 1..1020 steps ----------
 bool co_shape(size_t n_paths, size_t n_cols) {
-    return g_coalesce.load(std::memory_order_relaxed) && n_paths >= 1 && n_paths <= (size_t)mcg::co::MAX_PATHS && n_cols >= 2 &&
+    return g_coalesce.load(std::memory_order_relaxed) != 0 && n_paths >= 1 && n_paths <= (size_t)mcg::co::MAX_PATHS && n_cols >= 2 &&
            n_cols <= (size_t)mcg::co::MAX_STEPS + 1;
 }
 
 void took_own_context() { mcg::g_stats.coalesced_fallbacks.fetch_add(1, std::memory_order_relaxed); }
 
+// Do two requests ask the same pricer for the same thing?  (MartingaleOptimization: every iteration count >= 2 is the same
+// computation, kernels_martingale.hip.)
+bool same_call(const mcg::co::Request& a, const mcg::co::Request& b) {
+    if (a.kind != b.kind || a.r != b.r || a.strike != b.strike || a.maturity != b.maturity || a.dt != b.dt || a.is_call != b.is_call) return false;
+    switch (a.kind) {
+        case mcg::co::BRANCH: return a.num_branches == b.num_branches;  // (the resampling seed is drawn with the call that is made first)
+        case mcg::co::LSM: return a.poly_order == b.poly_order;
+        case mcg::co::MART: return a.poly_order == b.poly_order && (a.max_iterations >= 2) == (b.max_iterations >= 2);
+        default: return a.sigma == b.sigma && a.dividend == b.dividend;
+    }
+}
+
 // A pricer call through the combiner: the thread's slot when it holds exactly this matrix (compared element by element),
 // otherwise the matrix goes up with the request.  q carries the pricer's own arguments.
+//
+// PREFETCH.  The reference's driver calls its four pricers one after another on the matrix it has just generated, with the same
+// (r, strike, maturity, dt, isCall) and its literals for the rest: 10 branches over the dates 0 .. steps - 1, polynomial order 2,
+// five iterations (PredictionGen.cpp:788-791).  So the FIRST pricer call on a matrix the slot already holds also queues the
+// other three with those arguments, each in the lane of its kind, without waiting for them: the four row kernels run side by
+// side, and when the driver asks for the next price the answer is there or on its way -- a row costs two waits (its paths, its
+// slowest pricer) instead of five.  An answer is handed out only to a call that asks for exactly what was computed (same_call) on
+// exactly the matrix it was computed on (the slot's element-by-element comparison); any other call is made in the ordinary way.
+// The resampling seed of BranchingProcesses is drawn when its request is queued -- "a fresh seed per call", as before.
 double co_price(const std::vector<std::vector<double>>& pricePaths, const char* ragged_msg, mcg::co::Request& q) {
     const size_t N = pricePaths.size(), M = pricePaths[0].size();
     for (const auto& row : pricePaths)
@@ -139,8 +161,31 @@ double co_price(const std::vector<std::vector<double>>& pricePaths, const char* 
     q.n_paths = (int)N;
     q.n_steps = (int)M - 1;
     q.upload = false;
-    if (!t.holds(pricePaths, M)) {
-        if (t.prepare((int)N, (int)M) != MCG_OK) raise_last();
+    if (t.holds(pricePaths, M)) {
+        double price;
+        if (same_call(t.ahead[q.kind].req, q) && t.take_prefetched(q.kind, &price)) return price;
+        if (!t.prefetched_for_this_matrix && g_coalesce.load(std::memory_order_relaxed) == 1 && q.strike > 0.0 && q.dt > 0.0) {
+            t.prefetched_for_this_matrix = true;
+            for (int kind : {mcg::co::BRANCH, mcg::co::LSM, mcg::co::MART}) {
+                if (kind == q.kind) continue;
+                mcg::co::Request a;
+                a.kind = kind;
+                a.n_paths = q.n_paths;
+                a.n_steps = q.n_steps;
+                a.r = q.r;
+                a.strike = q.strike;
+                a.maturity = q.maturity;
+                a.dt = q.dt;
+                a.is_call = q.is_call;
+                a.num_branches = 10;   // PredictionGen.cpp:789
+                a.poly_order = 2;      // :790-791
+                a.max_iterations = 5;  // MartingaleOptimizationPricer.h: maxIterations = 5
+                if (kind == mcg::co::BRANCH) a.seed = next_seed();
+                t.prefetch(a);
+            }
+        }
+    } else {
+        if (t.prepare((int)N, (int)M) != MCG_OK) raise_last();   // (waits for whatever is still in flight on the old matrix)
         for (size_t i = 0; i < N; ++i) std::memcpy(t.pinned + i * M, pricePaths[i].data(), M * sizeof(double));
         q.upload = true;
     }
@@ -397,8 +442,8 @@ int mcg_compat_asymptotic_price(const double* row_major, int64_t n_paths, int n_
     }
 }
 
-int mcg_compat_set_coalescing(int enabled) {
-    g_coalesce.store(enabled != 0);
+int mcg_compat_set_coalescing(int mode) {
+    g_coalesce.store(mode < 0 || mode > 2 ? 1 : mode);
     return MCG_OK;
 }
 

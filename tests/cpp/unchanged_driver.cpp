@@ -14,7 +14,7 @@
 // 8 .. 183 (5 .. 126 steps), strikes 0.8 .. 1.2 of spot, calls and puts, three spot histories of 400 .. 1826 prices -- and a
 // few rows are built to throw the way the reference's classes throw (a one-price history; sigma = 0).
 //
-//   unchanged_driver <n_rows> <coalesce 0|1> [prices_out.txt] [seed]
+//   unchanged_driver <n_rows> <coalesce 0|1|2> [prices_out.txt] [seed]      (0: per-thread contexts, 1: coalesced + prefetch, 2: coalesced)
 // prints one JSON line: rows, threads, seconds, rows_per_s, priced, threw, checksum.  With a seed (default 20251031) the
 // prices of a row do not depend on the thread that priced it or on what else was in flight: prices_out.txt of two runs compare equal.
 #include <omp.h>
@@ -157,11 +157,11 @@ int main(int argc, char** argv) {
         }
     }
     long long st[64] = {0};
-    mcg_stats(st, 0);   // counters 15.. = coalesced rounds, calls, peak calls per round, fall-backs, round us, device-wait us, wake us
+    mcg_stats(st, 0);   // counters 15.. = coalesced rounds, calls, peak calls per round, fall-backs, round us, device-wait us, wake us, prefetched, hits
     std::printf("{\"rows\": %d, \"threads\": %d, \"coalescing\": %d, \"seconds\": %.6f, \"rows_per_s\": %.1f, \"priced\": %d, \"threw\": %d, "
                 "\"checksum\": %.10f, \"rounds\": %lld, \"calls\": %lld, \"peak_calls_per_round\": %lld, \"own_context_calls\": %lld, "
-                "\"round_us\": %lld, \"device_wait_us\": %lld, \"wake_us\": %lld, \"cpu_seconds\": %.3f}\n",
+                "\"round_us\": %lld, \"device_wait_us\": %lld, \"wake_us\": %lld, \"prefetched\": %lld, \"prefetch_hits\": %lld, \"cpu_seconds\": %.3f}\n",
                 n_rows, omp_get_max_threads(), coalesce, sec, n_rows / sec, n_priced, n_threw, checksum, st[15], st[16], st[17], st[18], st[19],
-                st[20], st[21], cpu);
+                st[20], st[21], st[22], st[23], cpu);
     return 0;
 }

@@ -264,6 +264,9 @@ def test_coalesced_calls_of_python_threads_match_sequential_calls(orc):
         work(k, alone)
     s0 = mc.stats(reset=True)
     assert s0["coalesced_calls"] > 0 and s0["coalesced_peak_calls_per_round"] == 1 and s0["coalesced_fallbacks"] > 0
+    # the first pricer call on a generated matrix queued the driver's other three ahead of time; those whose arguments the later
+    # calls repeated (BranchingProcesses always; LSM at order 2; MartingaleOptimization at >= 2 iterations) were answered from that
+    assert s0["coalesced_prefetched"] >= 3 * 16 and 16 <= s0["coalesced_prefetch_hits"] < s0["coalesced_prefetched"]
     together = {}
     threads = [threading.Thread(target=work, args=(k, together)) for k in range(16)]
     for t in threads:
@@ -276,6 +279,7 @@ def test_coalesced_calls_of_python_threads_match_sequential_calls(orc):
     for k in range(16):
         assert together[k] == alone[k], (k, [i for i, (x, y) in enumerate(zip(together[k], alone[k])) if x != y][:5])
     assert s1["coalesced_calls"] == s0["coalesced_calls"] and s1["coalesced_rounds"] < s1["coalesced_calls"]
+    assert s1["coalesced_prefetch_hits"] == s0["coalesced_prefetch_hits"]
     assert s1["coalesced_peak_calls_per_round"] >= 2
 
 
