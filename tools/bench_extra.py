@@ -275,9 +275,9 @@ def unchanged_driver_row(baselines=None) -> dict:
     loop of src/core/PredictionGen.cpp:542-570 / :736-737 / :788-791 written against the reference's own headers (include/models/*.h)
     -- one option row per OpenMP thread, the five classes constructed per row, GenerateStockPricePaths then the four pricers, 250
     paths x 5..126 steps, exceptions caught per row -- compiled with g++ and linked against libmcgpu.so.  Run in child processes at
-    omp_get_max_threads(), 128 and 16 threads with the class API's cross-thread coalescing on (the default: csrc/coalesce.hpp),
-    and at 128 and 16 threads with it off (every call a launch + a synchronisation on the calling thread's own context: the
-    route of rounds 1-5).  rows_per_s = the best coalesced run; every run is listed with its CPU seconds (the GPU boxes of this
+    omp_get_max_threads(), 128 and 16 threads with the class API's cross-thread coalescing on (the default: csrc/coalesce.hpp; once
+    more at 128 threads without its prefetch of a row's other pricers), and at 128 and 16 threads with it off (every call a launch
+    + a synchronisation on the calling thread's own context: the route of rounds 1-5).  rows_per_s = the best coalesced run; every run is listed with its CPU seconds (the GPU boxes of this
     pool give a job 16 CPUs' worth of time whatever its thread count: cpu_quota_cores)."""
     import subprocess
     row = {"config": "the reference driver's row loop UNCHANGED through the drop-in classes (tests/cpp/unchanged_driver.cpp = PredictionGen.cpp:542-570, "
@@ -305,10 +305,12 @@ def unchanged_driver_row(baselines=None) -> dict:
             if p.returncode != 0:
                 raise RuntimeError(f"unchanged_driver exited {p.returncode}: {p.stderr[-400:]}")
             j = json.loads(p.stdout.strip().splitlines()[-1])
-            j["route"] = "coalesced (default)" if coalesce else "per-thread contexts (mcg_compat_set_coalescing(0): rounds 1-5)"
+            j["route"] = {1: "coalesced + the row's other pricers prefetched (default)", 2: "coalesced, no prefetch (mcg_compat_set_coalescing(2))",
+                          0: "per-thread contexts (mcg_compat_set_coalescing(0): rounds 1-5)"}[coalesce]
             row["runs"].append(j)
             return j
         co = [run(t, 1, 16000) for t in (0, 128, 16)]
+        run(128, 2, 16000)   # (listed under runs: what the prefetch is worth)
         own = [run(128, 0, 2000), run(16, 0, 4000)]
         best, old = max(co, key=lambda j: j["rows_per_s"]), max(own, key=lambda j: j["rows_per_s"])
         at128 = [j for j in co if j["threads"] == 128][0]
@@ -321,8 +323,10 @@ def unchanged_driver_row(baselines=None) -> dict:
                     "per_thread_route_cpu_microseconds_per_row": old["cpu_seconds"] / old["rows"] * 1e6,
                     "speedup_at_128_threads": at128["rows_per_s"] / own[0]["rows_per_s"],
                     "speedup_best_vs_best": best["rows_per_s"] / old["rows_per_s"],
-                    "bound": "host round trips: five calls per row, each answered by the next round of its kind (a row's LSM sweep alone is "
-                             "~0.36 ms of dependent dates at 126 steps) -- and, on this pool's boxes, the 16-CPU quota (cpu_seconds / seconds of the runs)",
+                    "prefetch_hits_per_row": best.get("prefetch_hits", 0) / best["rows"],
+                    "bound": "host round trips: a row waits for its paths and then for its slowest pricer (the first pricer call queues the other "
+                             "three beside itself; a row's LSM sweep alone is ~0.36 ms of dependent dates at 126 steps), each answered by the next round "
+                             "of its kind -- and, on this pool's boxes, the 16-CPU quota (cpu_seconds / seconds of the runs)",
                     "checksums_equal": len({round(j["checksum"] / j["rows"], 6) for j in co}) == 1})
     except Exception as e:   # noqa: BLE001 -- a reported row, never required for the headline
         row["error"] = f"{type(e).__name__}: {e}"
