@@ -184,6 +184,39 @@ def test_committed_round5_line_fractions_are_fractions_and_rows_carry_cpu_baseli
     assert j["config"]["untimed_ramp_launches"] == 12 and j["extra"]["c2_cold_first_launch_ms"] > j["roofline"]["kernel_avg_ms"]
 
 
+def test_committed_round6_line_carries_the_unchanged_driver_row_and_agrees_with_its_profile():
+    """The line bench.py printed on the GPU box in round 6 (profiles/r06_bench_n1.json): fractions are fractions; the row of the
+    reference's driver UNCHANGED is there with every run listed -- coalesced at omp max / 128 / 16 threads,
+    without the prefetch, per-thread contexts at 128 / 16 --, >= 10 x the per-thread route at 128 threads, the same checksum per row
+    whatever the thread count, and a CPU baseline beside it; the 4M-path BranchingProcesses row is the XCD-affine route's (<= 16 ms).
+    And the profiled run of the same command (r06_bench_n1_profiled_run.json) agrees with rocprofv3's average for the timed kernel
+    variant (r06_bench_kernel_stats.csv) to 1 %."""
+    import csv
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    j = json.load(open(os.path.join(root, "profiles", "r06_bench_n1.json")))
+    for where, v in _fractions(j):
+        assert 0.0 <= v <= 1.05 and (v <= 1.0 or where.endswith("frac_of_board_ceiling")), (where, v)
+    assert j["roofline"]["kernel"] == "k_gbm_paths" and 0.55 < j["roofline"]["frac"] < 0.72 and j["cpu_baseline"]["kind"] == "reference"
+    assert "k_gbm_paths<true, 3, 2>" in json.load(open(os.path.join(root, "profiles", "pmc_traffic.json")))["kernel"]   # the TIMED variant
+    rows = j["extra"]["configs"]
+    un = next(r for r in rows if "UNCHANGED" in r["config"])
+    assert "error" not in un and un["checksums_equal"] is True and un["cpu_baseline"]["unit"] == "rows/s"
+    assert un["speedup_at_128_threads"] >= 10.0 and un["rows_per_s"] > 10 * un["per_thread_route_rows_per_s_at_128_threads"]
+    modes = sorted((r["threads"], r["coalescing"]) for r in un["runs"])
+    assert (128, 0) in modes and (128, 1) in modes and (128, 2) in modes and (16, 0) in modes and (16, 1) in modes and len(modes) == 6
+    assert all(r["priced"] + r["threw"] == r["rows"] and r["threw"] > 0 for r in un["runs"])       # rows that throw, throw per row
+    assert 2.5 < un["prefetch_hits_per_row"] <= 3.0                                                   # the driver's three later pricer calls
+    b4 = next(r for r in rows if r["config"].startswith("BranchingProcesses") and r["paths"] == 4_000_000)
+    assert b4["kernel_ms_per_call"] <= 16.0 and "XCD" in b4["bound"]
+    p = json.load(open(os.path.join(root, "profiles", "r06_bench_n1_profiled_run.json")))
+    st = {r["Name"]: r for r in csv.DictReader(open(os.path.join(root, "profiles", "r06_bench_kernel_stats.csv")))}
+    timed = st["void mcg::k_gbm_paths<true, 3, 2>(mcg::GbmArgs)"]
+    assert int(timed["Calls"]) == p["steps"] + p["warmup"]
+    assert abs(float(timed["AverageNs"]) * 1e-6 - p["roofline"]["kernel_avg_ms"]) <= 0.01 * p["roofline"]["kernel_avg_ms"]
+
+
 def test_committed_c5_bench_lines():
     """The C5 lines (bench.py --config c5): one launch of the LSM sweep without a collective, the per-date kernels with
     one all-reduce of 8 moments per exercise date when the built-in RCCL communicator is installed; same price."""
