@@ -4,14 +4,15 @@
 // (/root/reference/src/core/PredictionGen.cpp:542-570): RoughVolatility::GenerateStockPricePaths (:736-737), then
 // AsymptoticAnalysis, BranchingProcesses, LSM, MartingaleOptimization in turn (:788-791).  Through the drop-in classes every
 // one of those five calls used to be a launch + a host synchronisation on the calling thread's own stream: ~0.7 ms per
-// row and thread, 8.6 k rows/s at 16 threads, against 2.6 M rows/s for mcg_batch_price_rows -- which needs the driver's loop
-// rewritten.  Here calls that arrive from DIFFERENT host threads while one round is on the device are handed to a leader
-// (the first caller that finds no leader) which issues ONE launch per kind of call over all of them -- the row kernels of
-// kernels_batch.hip, one workgroup per row -- and hands the results back; a lone caller is a round of one.  No source
-// change in the driver.
+// row and thread, 880 rows/s at 128 threads (the HIP runtime serialises them), against 2.6 M rows/s for mcg_batch_price_rows --
+// which needs the driver's loop rewritten.  Here calls that arrive from DIFFERENT host threads while one round is on the device
+// are answered together: each kind of call has a lane (queue + service thread + stream); the service thread issues ONE launch
+// per group of queued calls -- the row kernels of kernels_batch.hip, one workgroup per row -- and hands the results back; a lone
+// caller is a round of one.  No source change in the driver.
 //
-//   host/coalesce.cpp   the combiner: request queue, leader election, per-thread matrix slots and pinned buffers
-//   kernels_batch.hip   co_execute_round: one round = one upload of the round's descriptors, <= 8 launches, one
+//   host/coalesce.cpp   the combiner: lanes, service threads, per-thread matrix slots and pinned buffers, prefetched calls
+//   host/dropin.cpp     co_price: which calls take this route, and the prefetch of a row's other pricers
+//   kernels_batch.hip   co::execute_round: one round = one upload of the round's descriptors, its launches and one
 //                       synchronisation; paths and prices come back through device-visible pinned host memory
 #pragma once
 #include <cstddef>
@@ -28,8 +29,8 @@ constexpr size_t SLOT_DOUBLES = (size_t)MAX_PATHS * (size_t)(MAX_STEPS + 1);  //
 
 enum Kind { GEN = 0, ASYM = 1, BRANCH = 2, LSM = 3, MART = 4, N_KINDS = 5 };
 
-// One call of one thread.  The requester fills it, submits it and sleeps until `done`; the leader of the round it falls
-// into reads the inputs and writes price / status / err.  Everything it points to belongs to the requester and stays
+// One call of one thread.  The requester fills it, queues it and waits; the service thread of its lane reads the inputs and
+// writes price / status / err.  Everything it points to belongs to the requester and stays
 // alive until done.
 struct Request {
     int kind = GEN;

@@ -42,7 +42,10 @@ enum : int { WAITING = 0, SLEEPING = 1, DONE = 2 };
 
 void futex_wake(std::atomic<int>* w) { syscall(SYS_futex, reinterpret_cast<int*>(w), FUTEX_WAKE_PRIVATE, 1, nullptr, nullptr, 0); }
 void futex_sleep(std::atomic<int>* w, int expected) {
-    syscall(SYS_futex, reinterpret_cast<int*>(w), FUTEX_WAIT_PRIVATE, expected, nullptr, nullptr, 0);
+    // (bounded: a sleeper looks at the world again every 100 ms whatever happens -- cheap insurance against a wake-up lost to a
+    //  process that is ending)
+    const struct timespec ts = {0, 100 * 1000 * 1000};
+    syscall(SYS_futex, reinterpret_cast<int*>(w), FUTEX_WAIT_PRIVATE, expected, &ts, nullptr, 0);
 }
 inline void cpu_relax() {
 #if defined(__x86_64__) || defined(__i386__)
@@ -86,6 +89,11 @@ private:
     Lane lanes_[N_KINDS];
     std::atomic<bool> stopping_{false};
 
+public:
+    std::atomic<bool> stopped_{false};  // the service threads have been joined (process exit)
+
+private:
+
     std::mutex slot_mu_;  // the arena
     std::vector<double*> chunks_;
     std::vector<int> free_slots_;
@@ -119,6 +127,7 @@ void Combiner::stop() {
         if (L.idle.exchange(0, std::memory_order_acq_rel) == 1) futex_wake(&L.idle);
         if (L.th.joinable()) L.th.join();
     }
+    stopped_.store(true, std::memory_order_release);
 }
 
 void Combiner::serve(Lane& L) {
@@ -180,6 +189,12 @@ void Combiner::wait(Waiter* w) {
     for (int spins = 0;;) {
         const int s = w->state.load(std::memory_order_acquire);
         if (s == DONE) return;
+        // (the process is ending and the service threads have left: a thread that is only now running its destructors must not
+        //  wait for an answer nobody will give -- its request is abandoned, unread)
+        if (combiner().stopped_.load(std::memory_order_acquire)) {
+            w->req->status = MCG_ERR_INVALID;
+            return;
+        }
         if (++spins < 1000) {
             cpu_relax();
             continue;
