@@ -266,7 +266,12 @@ int mcg_compat_set_seed(uint64_t seed, int enabled); /* default: std::random_dev
  * arguments (:788-791: the same r, strike, maturity, dt, isCall; 10 branches, order 2, 5 iterations), each in the lane of its kind,
  * so that the four run side by side; a later call is answered from that only if it asks for exactly what was computed on exactly
  * that matrix.  Mode 2: coalescing without the prefetch.  A lone caller is a round of one.  mcg_stats counts rounds, calls,
- * prefetches, hits and fall-backs. */
+ * prefetches, hits and fall-backs.
+ * Resources: the first class-API call that takes this route creates five contexts on device MCG_DEVICE (default 0) and starts
+ * five service threads inside the library (one per kind of call; they sleep while nothing is queued and are joined by an atexit
+ * handler before the HIP runtime shuts down); every calling thread gets a 2 MB slot of device memory (allocated 32 slots at a
+ * time) and a pinned host buffer of its matrix's size, both released when the thread ends.  A process that forks must do so
+ * before its first call, like any user of the HIP runtime. */
 int mcg_compat_set_coalescing(int mode);
 int mcg_compat_generate_paths(const double* hist, size_t n, int forward_steps, int path_num,
                               double* row_major_out);
