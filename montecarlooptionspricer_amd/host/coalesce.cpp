@@ -240,6 +240,14 @@ ThreadState::~ThreadState() {
     if (slot >= 0) combiner().release_slot(slot);
 }
 
+bool ThreadState::have_slot() {
+    if (slot >= 0) return true;
+    Combiner& c = combiner();
+    if (c.ready() != MCG_OK) return false;
+    slot = c.acquire_slot(&slot_off);   // (512 threads hold one; the 513th prices on a context of its own, like every caller used to)
+    return slot >= 0;
+}
+
 int ThreadState::prepare(int n_paths, int n_cols) {
     drain();
     forget_prefetched();
@@ -247,10 +255,7 @@ int ThreadState::prepare(int n_paths, int n_cols) {
     Combiner& c = combiner();
     int rc = c.ready();
     if (rc) return rc;
-    if (slot < 0) {
-        slot = c.acquire_slot(&slot_off);
-        if (slot < 0) return fail(MCG_ERR_OOM, "no matrix slot left for this thread");
-    }
+    if (!have_slot()) return fail(MCG_ERR_OOM, "no matrix slot left for this thread");
     const size_t need = (size_t)n_paths * (size_t)n_cols;
     if (need > pinned_cap) {
         if (pinned) (void)hipHostFree(pinned);

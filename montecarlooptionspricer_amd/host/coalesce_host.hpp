@@ -38,6 +38,7 @@ struct ThreadState {
     Prefetched ahead[N_KINDS];     // by kind
     bool prefetched_for_this_matrix = false;
     ~ThreadState();
+    bool have_slot();                      // this thread owns (or now gets) a slot of the arena; false: none left, or no combiner -- take the own-context route
     int prepare(int n_paths, int n_cols);  // slot + a pinned buffer of n_paths x n_cols doubles; drains what is in flight, invalidates `valid`; 0 or a status
     bool holds(const std::vector<std::vector<double>>& rows, size_t cols) const;
     int submit(Request& r);                // fills slot_off / host, blocks until answered; on failure mcg_last_error() holds r.err

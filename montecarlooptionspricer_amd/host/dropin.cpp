@@ -125,7 +125,7 @@ mcg_paths* device_matrix(const std::vector<std::vector<double>>& pricePaths, con
 // ---- the coalesced route (csrc/coalesce.hpp): shapes the row kernels serve -- at most 256 paths, 1..1020 steps ----------
 bool co_shape(size_t n_paths, size_t n_cols) {
     return g_coalesce.load(std::memory_order_relaxed) != 0 && n_paths >= 1 && n_paths <= (size_t)mcg::co::MAX_PATHS && n_cols >= 2 &&
-           n_cols <= (size_t)mcg::co::MAX_STEPS + 1;
+           n_cols <= (size_t)mcg::co::MAX_STEPS + 1 && mcg::co::thread_state().have_slot();   // (no slot left, no device: the own-context route says why)
 }
 
 void took_own_context() { mcg::g_stats.coalesced_fallbacks.fetch_add(1, std::memory_order_relaxed); }

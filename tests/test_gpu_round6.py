@@ -225,6 +225,11 @@ def test_unchanged_driver_128_threads_equals_the_single_thread_run(tmp_path):
     _legacy, c = _run_unchanged_driver(300, 8, 0, str(tmp_path / "legacy.txt"))
     assert np.array_equal(c[:, :2], a[:300, :2])
     assert np.allclose(c[:, 2:], a[:300, 2:], rtol=1e-9, atol=1e-12), np.max(np.abs(c[:, 2:] - a[:300, 2:]))
+    # more calling threads than the arena has slots (512): the threads that get none price on a context of their own -- no error,
+    # no dead-lock, the same prices
+    crowd, d = _run_unchanged_driver(1100, 540, 1, str(tmp_path / "crowd.txt"))
+    assert crowd["threads"] == 540 and crowd["own_context_calls"] > 0 and crowd["calls"] > 0
+    assert np.array_equal(d[:, :2], a[:1100, :2]) and np.allclose(d[:, 2:], a[:1100, 2:], rtol=1e-9, atol=1e-12)
 
 
 def test_coalesced_calls_of_python_threads_match_sequential_calls(orc):
