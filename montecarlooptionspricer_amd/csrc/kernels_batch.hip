@@ -435,10 +435,11 @@ __global__ __launch_bounds__(256) void k_batch_martingale(BatchArgs a) {
     }
 }
 
+// LSM on `lsm_stream`, MartingaleOptimization on `mo_stream` (run_batch_chunk: the same stream, or the auxiliary one)
 template <int NB>
-static void launch_row_regressions(mcg_ctx* ctx, const BatchArgs& a, size_t smem_cols) {
-    hipLaunchKernelGGL(k_batch_lsm<NB>, dim3((unsigned)a.n_rows), dim3(64), 0, ctx->stream, a);
-    hipLaunchKernelGGL(k_batch_martingale<NB>, dim3((unsigned)a.n_rows), dim3(256), smem_cols, ctx->stream, a);
+static void launch_row_regressions(const BatchArgs& a, size_t smem_cols, hipStream_t lsm_stream, hipStream_t mo_stream) {
+    hipLaunchKernelGGL(k_batch_lsm<NB>, dim3((unsigned)a.n_rows), dim3(64), 0, lsm_stream, a);
+    hipLaunchKernelGGL(k_batch_martingale<NB>, dim3((unsigned)a.n_rows), dim3(256), smem_cols, mo_stream, a);
 }
 
 namespace {
@@ -517,14 +518,43 @@ static int run_batch_chunk(mcg_ctx* ctx, std::vector<BatchRow>& h, BatchArgs a, 
         const PathsKernel pk = paths_kernel[lds_class(m_max)];  // (a chunk holds rows of one class, run_batch_rows)
         if (smem_p > 48 * 1024) (void)hipFuncSetAttribute((const void*)pk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_p);
         hipLaunchKernelGGL(pk, dim3((unsigned)wg_map.size()), dim3(256), smem_p, ctx->stream, a);
-        hipLaunchKernelGGL(k_batch_asym, dim3((unsigned)n), dim3(256), 2 * smem_c, ctx->stream, a);
+        // The four pricers only read the row blocks and write columns of their own, so two of them run on a second stream beside the
+        // other two, forked and joined by events: LSM + MartingaleOptimization (one wavefront per row walking its dates; chains of
+        // dependent loads: 0.79 / 0.42 VALU busy at 20 000 rows) beside AsymptoticAnalysis + BranchingProcesses (0.53 / 0.85) -- one
+        // pair's latencies hide behind the other's issue.  20 000 rows, same board, three alternations: device span 6.7 -> 6.2-6.3 ms,
+        // 2.63 -> 2.80 M rows/s through the entry point (the other split -- Asymptotic + Martingale aside -- 6.4 ms);
+        // gpurun_out/r6z2_batch_aux.log.  (A/B builds: MCG_BATCH_AUX_STREAM = 0 one stream, 1 the other split.)
+        hipStream_t aux = ctx->stream;
+        const int aux_mode = study_switch("MCG_BATCH_AUX_STREAM", 2);
+        if (aux_mode != 0) {
+            if (!ctx->batch_aux) {
+                if (hipStreamCreateWithFlags(&ctx->batch_aux, hipStreamNonBlocking) != hipSuccess ||
+                    hipEventCreateWithFlags(&ctx->batch_fork, hipEventDisableTiming) != hipSuccess ||
+                    hipEventCreateWithFlags(&ctx->batch_join, hipEventDisableTiming) != hipSuccess) {
+                    (void)hipGetLastError();
+                    if (ctx->batch_aux) (void)hipStreamDestroy(ctx->batch_aux);
+                    ctx->batch_aux = nullptr;
+                }
+            }
+            if (ctx->batch_aux && ctx->batch_fork && ctx->batch_join && hipEventRecord(ctx->batch_fork, ctx->stream) == hipSuccess &&
+                hipStreamWaitEvent(ctx->batch_aux, ctx->batch_fork, 0) == hipSuccess)
+                aux = ctx->batch_aux;
+        }
+        const hipStream_t s_asym = aux_mode == 2 ? ctx->stream : aux, s_lsm = aux_mode == 2 ? aux : ctx->stream;
+        hipLaunchKernelGGL(k_batch_asym, dim3((unsigned)n), dim3(256), 2 * smem_c, s_asym, a);
         hipLaunchKernelGGL(k_batch_branching, dim3((unsigned)n), dim3(256), smem_c, ctx->stream, a);
         switch (poly_order + 1) {
-            case 1: launch_row_regressions<1>(ctx, a, smem_c); break;
-            case 2: launch_row_regressions<2>(ctx, a, smem_c); break;
-            case 3: launch_row_regressions<3>(ctx, a, smem_c); break;
-            case 4: launch_row_regressions<4>(ctx, a, smem_c); break;
-            default: launch_row_regressions<5>(ctx, a, smem_c); break;
+            case 1: launch_row_regressions<1>(a, smem_c, s_lsm, aux); break;
+            case 2: launch_row_regressions<2>(a, smem_c, s_lsm, aux); break;
+            case 3: launch_row_regressions<3>(a, smem_c, s_lsm, aux); break;
+            case 4: launch_row_regressions<4>(a, smem_c, s_lsm, aux); break;
+            default: launch_row_regressions<5>(a, smem_c, s_lsm, aux); break;
+        }
+        if (aux != ctx->stream) {   // join: nothing behind this point on the main stream starts before the auxiliary stream's kernels are done
+            if (hipEventRecord(ctx->batch_join, aux) != hipSuccess || hipStreamWaitEvent(ctx->stream, ctx->batch_join, 0) != hipSuccess) {
+                (void)hipGetLastError();
+                (void)hipStreamSynchronize(aux);
+            }
         }
     }
     e = hipGetLastError();

@@ -303,6 +303,9 @@ int mcg_finalize(mcg_ctx* ctx) {
     if (ctx->weights) (void)hipFree(ctx->weights);
     if (ctx->lsm_v) (void)hipFree(ctx->lsm_v);
     if (ctx->log_tab) (void)hipFree(ctx->log_tab);
+    if (ctx->batch_fork) (void)hipEventDestroy(ctx->batch_fork);
+    if (ctx->batch_join) (void)hipEventDestroy(ctx->batch_join);
+    if (ctx->batch_aux) (void)hipStreamDestroy(ctx->batch_aux);
     if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return MCG_OK;

@@ -79,6 +79,9 @@ struct mcg_ctx {
     long long lsm_date_spin_limit = -1;  // mcg_debug_lsm_date_fault: polls before a consumer of k_lsm_date gives a slot up (< 0: default)
     int lsm_date_hook[4] = {0, 0, 0, 0}; //   {mode, date, workgroup, delay}: that workgroup's partial moments never land (1) / land late (2)
     size_t batch_budget = 0;             // mcg_debug_batch_budget: workspace bytes of one chunk of mcg_batch_price_rows (0: a quarter of free memory)
+    // batched rows (kernels_batch.hip): the two latency-bound row pricers run beside the two issue-bound ones on a second stream
+    hipStream_t batch_aux = nullptr;
+    hipEvent_t batch_fork = nullptr, batch_join = nullptr;
 
     // cached device buffers (path matrices are tens of GB: never hipMalloc per call in steady state)
     std::vector<mcg::PoolBuf> pool;
