@@ -163,7 +163,10 @@ double co_price(const std::vector<std::vector<double>>& pricePaths, const char* 
     q.upload = false;
     if (t.holds(pricePaths, M)) {
         double price;
-        if (same_call(t.ahead[q.kind].req, q) && t.take_prefetched(q.kind, &price)) return price;
+        // (BranchingProcesses: under mcg_compat_set_seed the answer must be the one THIS seed gives; unseeded, the seed drawn when the
+        //  request was queued is as fresh as one drawn now)
+        const bool seed_ok = q.kind != mcg::co::BRANCH || !g_seed_fixed.load() || t.ahead[q.kind].req.seed == q.seed;
+        if (seed_ok && same_call(t.ahead[q.kind].req, q) && t.take_prefetched(q.kind, &price)) return price;
         if (!t.prefetched_for_this_matrix && g_coalesce.load(std::memory_order_relaxed) == 1 && q.strike > 0.0 && q.dt > 0.0) {
             t.prefetched_for_this_matrix = true;
             for (int kind : {mcg::co::BRANCH, mcg::co::LSM, mcg::co::MART}) {
