@@ -268,7 +268,8 @@ def test_coalesced_calls_of_python_threads_match_sequential_calls(orc):
     for k in range(16):
         work(k, alone)
     s0 = mc.stats(reset=True)
-    assert s0["coalesced_calls"] > 0 and s0["coalesced_peak_calls_per_round"] == 1 and s0["coalesced_fallbacks"] > 0
+    # (one thread alone: rounds of one call -- or of two, when its own call of a kind meets that kind's prefetched request in the queue)
+    assert s0["coalesced_calls"] > 0 and s0["coalesced_peak_calls_per_round"] <= 2 and s0["coalesced_fallbacks"] > 0
     # the first pricer call on a generated matrix queued the driver's other three ahead of time; those whose arguments the later
     # calls repeated (BranchingProcesses always; LSM at order 2; MartingaleOptimization at >= 2 iterations) were answered from that
     assert s0["coalesced_prefetched"] >= 3 * 16 and 16 <= s0["coalesced_prefetch_hits"] < s0["coalesced_prefetched"]
