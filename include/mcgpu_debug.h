@@ -29,6 +29,9 @@ int mcg_debug_lsm_hooks(mcg_ctx* ctx, long long spin_limit, int poll_delay);
 int mcg_debug_lsm_date_fault(mcg_ctx* ctx, int mode, int date, int workgroup, int delay, long long spin_limit);
 /* Test hook: workspace bytes one chunk of mcg_batch_price_rows* may use (0: the default, a quarter of free memory). */
 int mcg_debug_batch_budget(mcg_ctx* ctx, size_t bytes);
+/* Class-API coalescing (mcg_compat_set_coalescing): at most max_slots calling threads get a matrix slot of the device arena from
+ * now on (< 0: the default, 512); a thread that gets none prices on a context of its own.  For the test of that fall-back. */
+int mcg_debug_coalesce_slots(int max_slots);
 /* Test hook, host-only: the decision whether a rank maps a peer's mailbox (1) or all ranks stay on the host mailbox (0),
  * from what it knows about the peer: same process?, does its PCI bus id resolve to a visible device?, the same device?,
  * is peer access available? */

@@ -97,6 +97,10 @@ private:
     std::mutex slot_mu_;  // the arena
     std::vector<double*> chunks_;
     std::vector<int> free_slots_;
+    int slots_out_ = 0;
+
+public:
+    std::atomic<int> max_slots_{MAX_CHUNKS * SLOTS_PER_CHUNK};  // mcg_debug_coalesce_slots: fewer, so that a test can run out of them
 };
 
 Combiner& combiner() {
@@ -206,6 +210,7 @@ void Combiner::wait(Waiter* w) {
 
 int Combiner::acquire_slot(int64_t* off) {
     std::lock_guard<std::mutex> g(slot_mu_);
+    if (slots_out_ >= max_slots_.load(std::memory_order_relaxed)) return -1;
     if (free_slots_.empty()) {
         if ((int)chunks_.size() >= MAX_CHUNKS) return -1;
         double* p = nullptr;
@@ -219,6 +224,7 @@ int Combiner::acquire_slot(int64_t* off) {
     }
     const int idx = free_slots_.back();
     free_slots_.pop_back();
+    ++slots_out_;
     // offsets are relative to the FIRST chunk (any two device allocations are a whole number of doubles apart)
     double* at = chunks_[(size_t)(idx / SLOTS_PER_CHUNK)] + (size_t)(idx % SLOTS_PER_CHUNK) * SLOT_DOUBLES;
     *off = (int64_t)(at - chunks_[0]);
@@ -228,6 +234,7 @@ int Combiner::acquire_slot(int64_t* off) {
 void Combiner::release_slot(int idx) {
     std::lock_guard<std::mutex> g(slot_mu_);
     free_slots_.push_back(idx);
+    --slots_out_;
 }
 
 }  // namespace
@@ -354,6 +361,8 @@ ThreadState& thread_state() {
     thread_local ThreadState t;
     return t;
 }
+
+void debug_max_slots(int n) { combiner().max_slots_.store(n < 0 ? MAX_CHUNKS * SLOTS_PER_CHUNK : n, std::memory_order_relaxed); }
 
 }  // namespace co
 }  // namespace mcg

@@ -48,6 +48,7 @@ struct ThreadState {
     void forget_prefetched();
 };
 ThreadState& thread_state();
+void debug_max_slots(int n);  // mcg_debug_coalesce_slots
 
 }  // namespace co
 }  // namespace mcg

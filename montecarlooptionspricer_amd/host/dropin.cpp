@@ -445,6 +445,11 @@ int mcg_compat_asymptotic_price(const double* row_major, int64_t n_paths, int n_
     }
 }
 
+int mcg_debug_coalesce_slots(int max_slots) {
+    mcg::co::debug_max_slots(max_slots);
+    return MCG_OK;
+}
+
 int mcg_compat_set_coalescing(int mode) {
     g_coalesce.store(mode < 0 || mode > 2 ? 1 : mode);
     return MCG_OK;

@@ -14,7 +14,7 @@
 // 8 .. 183 (5 .. 126 steps), strikes 0.8 .. 1.2 of spot, calls and puts, three spot histories of 400 .. 1826 prices -- and a
 // few rows are built to throw the way the reference's classes throw (a one-price history; sigma = 0).
 //
-//   unchanged_driver <n_rows> <coalesce 0|1|2> [prices_out.txt] [seed]      (0: per-thread contexts, 1: coalesced + prefetch, 2: coalesced)
+//   unchanged_driver <n_rows> <coalesce 0|1|2> [prices_out.txt] [seed] [max arena slots]      (0: per-thread contexts, 1: coalesced + prefetch, 2: coalesced)
 // prints one JSON line: rows, threads, seconds, rows_per_s, priced, threw, checksum.  With a seed (default 20251031) the
 // prices of a row do not depend on the thread that priced it or on what else was in flight: prices_out.txt of two runs compare equal.
 #include <omp.h>
@@ -37,6 +37,7 @@
 
 extern "C" int mcg_compat_set_seed(unsigned long long seed, int enabled);
 extern "C" int mcg_compat_set_coalescing(int enabled);
+extern "C" int mcg_debug_coalesce_slots(int max_slots);   // include/mcgpu_debug.h (a test hook: argv[5])
 extern "C" int mcg_stats(long long* out, int reset);   // (mcg_stats_t is a block of int64 counters, include/mcgpu.h)
 
 namespace {
@@ -63,6 +64,7 @@ int main(int argc, char** argv) {
     const int coalesce = argc > 2 ? std::atoi(argv[2]) : 1;
     const char* out_path = argc > 3 ? argv[3] : nullptr;
     const unsigned long long seed = argc > 4 ? std::strtoull(argv[4], nullptr, 10) : 20251031ull;
+    if (argc > 5) mcg_debug_coalesce_slots(std::atoi(argv[5]));   // fewer arena slots than threads: the rest price on contexts of their own
     const std::vector<std::vector<double>> hists = {history(400, 100.0, 0.0002, 0.012), history(1001, 166.5, 0.0001, 0.009),
                                                     history(1826, 42.0, -0.0001, 0.015), std::vector<double>{100.0}};
     std::vector<Row> rows((size_t)n_rows);

@@ -189,13 +189,15 @@ def test_device_lsm_and_martingale_match_the_eigen_fixtures(eng):
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run_unchanged_driver(n_rows, threads, coalesce, out_file, timeout=600):
+def _run_unchanged_driver(n_rows, threads, coalesce, out_file, timeout=600, max_slots=None):
     import json
     import subprocess
     subprocess.run(["make", "build/unchanged_driver"], cwd=ROOT, check=True, stdout=subprocess.DEVNULL)
     env = dict(os.environ, OMP_NUM_THREADS=str(threads), OMP_DYNAMIC="false")
-    res = subprocess.run([os.path.join(ROOT, "build", "unchanged_driver"), str(n_rows), str(coalesce), out_file], capture_output=True,
-                         text=True, env=env, timeout=timeout)
+    cmd = [os.path.join(ROOT, "build", "unchanged_driver"), str(n_rows), str(coalesce), out_file]
+    if max_slots is not None:
+        cmd += ["20251031", str(max_slots)]
+    res = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=timeout)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     line = json.loads(res.stdout.strip().splitlines()[-1])
     rows = np.loadtxt(out_file)
@@ -225,11 +227,11 @@ def test_unchanged_driver_128_threads_equals_the_single_thread_run(tmp_path):
     _legacy, c = _run_unchanged_driver(300, 8, 0, str(tmp_path / "legacy.txt"))
     assert np.array_equal(c[:, :2], a[:300, :2])
     assert np.allclose(c[:, 2:], a[:300, 2:], rtol=1e-9, atol=1e-12), np.max(np.abs(c[:, 2:] - a[:300, 2:]))
-    # more calling threads than the arena has slots (512): the threads that get none price on a context of their own -- no error,
-    # no dead-lock, the same prices
-    crowd, d = _run_unchanged_driver(1100, 540, 1, str(tmp_path / "crowd.txt"))
-    assert crowd["threads"] == 540 and crowd["own_context_calls"] > 0 and crowd["calls"] > 0
-    assert np.array_equal(d[:, :2], a[:1100, :2]) and np.allclose(d[:, 2:], a[:1100, 2:], rtol=1e-9, atol=1e-12)
+    # more calling threads than the arena has slots (512 by default; 6 here, mcg_debug_coalesce_slots, with 24 threads): the threads
+    # that get none price on a context of their own -- no error, no dead-lock, the same prices
+    crowd, d = _run_unchanged_driver(600, 24, 1, str(tmp_path / "crowd.txt"), max_slots=6)
+    assert crowd["threads"] == 24 and crowd["own_context_calls"] > 0 and crowd["calls"] > 0
+    assert np.array_equal(d[:, :2], a[:600, :2]) and np.allclose(d[:, 2:], a[:600, 2:], rtol=1e-9, atol=1e-12)
 
 
 def test_coalesced_calls_of_python_threads_match_sequential_calls(orc):
