@@ -32,6 +32,11 @@ int mcg_debug_batch_budget(mcg_ctx* ctx, size_t bytes);
 /* Class-API coalescing (mcg_compat_set_coalescing): at most max_slots calling threads get a matrix slot of the device arena from
  * now on (< 0: the default, 512); a thread that gets none prices on a context of its own.  For the test of that fall-back. */
 int mcg_debug_coalesce_slots(int max_slots);
+/* The combiner's protocol -- one queue and service thread per kind of call, sleeps and wake-ups, requests queued ahead and taken
+ * later or drained, slots, thread exit -- WITHOUT a GPU: n_threads host threads make calls_per_thread calls each, answered by a
+ * stand-in for the device that takes ~50 us per round.  *wrong = wrong or missing answers.  Call it in a process that has not
+ * used the class API (it switches the combiner to the stand-in for the life of the process). */
+int mcg_debug_coalesce_selftest(int n_threads, int calls_per_thread, int* wrong);
 /* Test hook, host-only: the decision whether a rank maps a peer's mailbox (1) or all ranks stay on the host mailbox (0),
  * from what it knows about the peer: same process?, does its PCI bus id resolve to a visible device?, the same device?,
  * is peer access available? */

@@ -142,6 +142,7 @@ def load_library():
     L.mcg_compat_set_seed.argtypes = [C.c_uint64, C.c_int]
     L.mcg_compat_set_coalescing.argtypes = [C.c_int]
     L.mcg_debug_coalesce_slots.argtypes = [C.c_int]
+    L.mcg_debug_coalesce_selftest.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int)]
     L.mcg_compat_generate_paths.argtypes = [dp, C.c_size_t, C.c_int, C.c_int, dp]
     L.mcg_compat_lsm_price.argtypes = [dp, C.c_int64, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double,
                                        C.c_int, C.c_int, dp]

@@ -26,6 +26,7 @@
 #include <atomic>
 #include <chrono>
 #include <climits>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <thread>
@@ -52,6 +53,12 @@ inline void cpu_relax() {
     __builtin_ia32_pause();
 #endif
 }
+
+// mcg_debug_coalesce_selftest: the protocol of this file -- queues, service threads, sleeps and wake-ups, prefetched requests,
+// slots, thread exit -- on a host WITHOUT a GPU: rounds are answered by this function instead of co::execute_round (no context,
+// no device memory, malloc'ed "pinned" buffers).  Set before the combiner's first use, for the life of the process.
+typedef int (*RehearsalRound)(Request** reqs, int n);
+std::atomic<RehearsalRound> g_rehearsal{nullptr};
 
 constexpr int SLOTS_PER_CHUNK = 32;  // 32 x 2.09 MB = 67 MB of HBM per chunk, allocated when the 1st, 33rd, ... thread arrives
 constexpr int MAX_CHUNKS = 16;       // 512 calling threads hold a slot; later ones take their own context
@@ -111,6 +118,7 @@ Combiner& combiner() {
 void Combiner::init() {
     if (const char* e = std::getenv("MCG_DEVICE")) device_ = std::atoi(e);
     for (Lane& L : lanes_) {
+        if (g_rehearsal.load()) break;
         if (mcg_init(&L.ctx, device_) != MCG_OK) {
             init_rc_ = MCG_ERR_NO_DEVICE;
             const char* m = mcg_last_error();
@@ -135,7 +143,8 @@ void Combiner::stop() {
 }
 
 void Combiner::serve(Lane& L) {
-    (void)hipSetDevice(device_);
+    const RehearsalRound rehearsal = g_rehearsal.load();
+    if (!rehearsal) (void)hipSetDevice(device_);
     std::vector<Waiter*> batch;
     std::vector<Request*> reqs;
     for (;;) {
@@ -169,7 +178,8 @@ void Combiner::serve(Lane& L) {
             std::lock_guard<std::mutex> g(slot_mu_);
             base = chunks_.empty() ? nullptr : chunks_[0];
         }
-        (void)execute_round(L.ctx, L.rb, base, reqs.data(), (int)reqs.size());  // every request now carries its status
+        if (rehearsal) (void)rehearsal(reqs.data(), (int)reqs.size());
+        else (void)execute_round(L.ctx, L.rb, base, reqs.data(), (int)reqs.size());  // every request now carries its status
         const auto t0 = std::chrono::steady_clock::now();
         for (Waiter* w : batch)
             if (w->state.exchange(DONE, std::memory_order_acq_rel) == SLEEPING) futex_wake(&w->state);
@@ -214,7 +224,9 @@ int Combiner::acquire_slot(int64_t* off) {
     if (free_slots_.empty()) {
         if ((int)chunks_.size() >= MAX_CHUNKS) return -1;
         double* p = nullptr;
-        if (hipSetDevice(device_) != hipSuccess || hipMalloc((void**)&p, SLOT_DOUBLES * sizeof(double) * SLOTS_PER_CHUNK) != hipSuccess) {
+        if (g_rehearsal.load()) {
+            p = reinterpret_cast<double*>(((uintptr_t)chunks_.size() + 1) << 32);   // (never dereferenced: offsets only)
+        } else if (hipSetDevice(device_) != hipSuccess || hipMalloc((void**)&p, SLOT_DOUBLES * sizeof(double) * SLOTS_PER_CHUNK) != hipSuccess) {
             (void)hipGetLastError();
             return -1;
         }
@@ -243,7 +255,8 @@ void Combiner::release_slot(int idx) {
 
 ThreadState::~ThreadState() {
     drain();  // nothing of ours may still be on the device when the buffers go
-    if (pinned) (void)hipHostFree(pinned);
+    if (pinned && g_rehearsal.load()) std::free(pinned);
+    else if (pinned) (void)hipHostFree(pinned);
     if (slot >= 0) combiner().release_slot(slot);
 }
 
@@ -265,13 +278,20 @@ int ThreadState::prepare(int n_paths, int n_cols) {
     if (!have_slot()) return fail(MCG_ERR_OOM, "no matrix slot left for this thread");
     const size_t need = (size_t)n_paths * (size_t)n_cols;
     if (need > pinned_cap) {
-        if (pinned) (void)hipHostFree(pinned);
+        const bool rehearsal = g_rehearsal.load() != nullptr;
+        if (pinned && rehearsal) std::free(pinned);
+        else if (pinned) (void)hipHostFree(pinned);
         pinned = nullptr;
         pinned_cap = 0;
         const size_t cap = std::max<size_t>((need + 32767) & ~(size_t)32767, (size_t)1 << 15);  // whole 256 KiB
-        MCG_HIP(hipSetDevice(c.device()));
-        MCG_HIP(hipHostMalloc((void**)&pinned, cap * sizeof(double), hipHostMallocDefault));
-        MCG_HIP(hipHostGetDevicePointer((void**)&pinned_dev, pinned, 0));
+        if (rehearsal) {
+            pinned = pinned_dev = static_cast<double*>(std::malloc(cap * sizeof(double)));
+            if (!pinned) return fail(MCG_ERR_OOM, "host allocation failed");
+        } else {
+            MCG_HIP(hipSetDevice(c.device()));
+            MCG_HIP(hipHostMalloc((void**)&pinned, cap * sizeof(double), hipHostMallocDefault));
+            MCG_HIP(hipHostGetDevicePointer((void**)&pinned_dev, pinned, 0));
+        }
         pinned_cap = cap;
     }
     return MCG_OK;
@@ -360,6 +380,76 @@ void ThreadState::forget_prefetched() {
 ThreadState& thread_state() {
     thread_local ThreadState t;
     return t;
+}
+
+// ---- mcg_debug_coalesce_selftest -----------------------------------------------------------------------------------------------
+namespace {
+
+// the rehearsal's "device": a round takes ~50 us; a call's answer is a function of its arguments that no other call shares
+double rehearsal_answer(const Request& q) { return q.strike * 2.0 + (double)q.kind + 0.25 * q.poly_order + 1e-3 * q.n_steps; }
+int rehearsal_round(Request** reqs, int n) {
+    usleep(50);
+    for (int i = 0; i < n; ++i) {
+        reqs[i]->price = rehearsal_answer(*reqs[i]);
+        reqs[i]->status = MCG_OK;
+    }
+    g_stats.coalesced_rounds.fetch_add(1, std::memory_order_relaxed);
+    g_stats.coalesced_calls.fetch_add(n, std::memory_order_relaxed);
+    int64_t seen = g_stats.coalesced_peak_calls_per_round.load(std::memory_order_relaxed);
+    while (n > seen && !g_stats.coalesced_peak_calls_per_round.compare_exchange_weak(seen, n, std::memory_order_relaxed)) {
+    }
+    return MCG_OK;
+}
+
+}  // namespace
+
+// n_threads host threads, each making calls_per_thread calls of all five kinds through the combiner -- answered by
+// rehearsal_round instead of the GPU --, every third one with two other kinds queued ahead and taken later (or left to be drained
+// when the thread's matrix changes, or when the thread ends).  Returns the number of wrong or missing answers.
+int selftest(int n_threads, int calls_per_thread) {
+    g_rehearsal.store(rehearsal_round);
+    std::atomic<int> wrong{0};
+    auto work = [&](int tid) {
+        ThreadState& t = thread_state();
+        for (int c = 0; c < calls_per_thread; ++c) {
+            Request q;
+            q.kind = c % N_KINDS;
+            q.n_paths = 250;
+            q.n_steps = 5 + (tid + c) % 120;
+            q.strike = 1000.0 * tid + c;
+            q.poly_order = c % 5;
+            if (q.kind == GEN || c % 7 == 0) {  // a new matrix: everything in flight is waited for first
+                if (t.prepare(q.n_paths, q.n_steps + 1) != MCG_OK) {
+                    ++wrong;
+                    continue;
+                }
+            } else if (!t.have_slot()) {
+                ++wrong;
+                continue;
+            }
+            if (c % 3 == 0) {  // two requests ahead, in other lanes
+                for (int k = 1; k <= 2; ++k) {
+                    Request a = q;
+                    a.kind = (q.kind + k) % N_KINDS;
+                    a.strike = q.strike + 0.5 * k;
+                    t.prefetch(a);
+                }
+            }
+            if (t.submit(q) != MCG_OK || q.price != rehearsal_answer(q)) ++wrong;
+            if (c % 6 == 0) {  // ... one of them taken, the other left for drain()
+                const int k1 = (q.kind + 1) % N_KINDS;
+                double price = -1.0;
+                Request a = q;
+                a.kind = k1;
+                a.strike = q.strike + 0.5;
+                if (!t.take_prefetched(k1, &price) || price != rehearsal_answer(a)) ++wrong;
+            }
+        }
+    };
+    std::vector<std::thread> th;
+    for (int i = 0; i < n_threads; ++i) th.emplace_back(work, i);
+    for (auto& x : th) x.join();  // (their ThreadState destructors have drained what they left in flight)
+    return wrong.load();
 }
 
 void debug_max_slots(int n) { combiner().max_slots_.store(n < 0 ? MAX_CHUNKS * SLOTS_PER_CHUNK : n, std::memory_order_relaxed); }

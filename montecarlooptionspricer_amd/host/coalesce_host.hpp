@@ -49,6 +49,7 @@ struct ThreadState {
 };
 ThreadState& thread_state();
 void debug_max_slots(int n);  // mcg_debug_coalesce_slots
+int selftest(int n_threads, int calls_per_thread);  // mcg_debug_coalesce_selftest
 
 }  // namespace co
 }  // namespace mcg

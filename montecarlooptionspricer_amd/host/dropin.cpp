@@ -445,6 +445,16 @@ int mcg_compat_asymptotic_price(const double* row_major, int64_t n_paths, int n_
     }
 }
 
+int mcg_debug_coalesce_selftest(int n_threads, int calls_per_thread, int* wrong) {
+    if (n_threads < 1 || n_threads > 512 || calls_per_thread < 1 || !wrong) return mcg::fail(MCG_ERR_INVALID, "bad arguments");
+    try {
+        *wrong = mcg::co::selftest(n_threads, calls_per_thread);
+    } catch (const std::exception& e) {
+        return mcg::fail(MCG_ERR_OOM, "self-test: %s", e.what());
+    }
+    return MCG_OK;
+}
+
 int mcg_debug_coalesce_slots(int max_slots) {
     mcg::co::debug_max_slots(max_slots);
     return MCG_OK;
