@@ -379,3 +379,32 @@ def test_sharded_per_date_route_at_order_5_equals_the_single_rank_price():
         # timing_get counts the per-date launches + k_lsm_final; every per-date launch but the first follows one all-reduce
         assert launches - 1 == moment_allreduces + 1, (rank, launches, moment_allreduces, calls[rank][:8])
         assert moment_allreduces >= steps + 1          # one per date at least; the re-fits' second launches on top
+
+
+@pytest.mark.parametrize("steps,n_paths", [(1, 1), (2, 3), (15, 2), (16, 255), (17, 256), (33, 7), (130, 250), (1020, 64)])
+def test_coalesced_route_at_the_edges_of_its_shapes(eng, orc, steps, n_paths):
+    """The class API through the combiner at the corners of what its row kernels serve (1 .. 256 paths, 1 .. 1020 steps; Mz < 32 takes
+    the direct transform, 1020 steps the widest tables): the generated matrix equals mcg_paths_rbergomi's bit for bit, and the four
+    pricers on it equal the oracle on the same numbers."""
+    from oracle.binding import synthetic_history
+    hist = synthetic_history(400, seed=11)
+    mc.stats(reset=True)
+    mc.set_compat_seed(SEED)
+    a = mc.RoughVolatility().GenerateStockPricePaths(hist, steps, n_paths)
+    p = orc.estimate_params(hist)
+    P = eng.rbergomi(SEED, p["S0"], 0.04, p["xi"], p["H"], p["eta"], p["rho"], DT, steps, n_paths)
+    assert a.shape == (n_paths, steps + 1) and np.array_equal(P.to_host(), a)
+    P.free()
+    K, T = float(hist[-1]) * 1.02, steps * DT
+    got = [mc.AsymptoticAnalysis().PredictOptionPrice(a, 0.04, K, T, DT, False, 0.25, 0.08),
+           mc.BranchingProcesses().PredictOptionPrice(a, 0.04, K, T, DT, False, 10, list(range(steps))),
+           mc.LSM().PredictOptionPrice(a, 0.04, K, T, DT, False, 2),
+           mc.MartingaleOptimization().PredictOptionPrice(a, 0.04, K, T, DT, False, 2)]
+    mc.set_compat_seed(None)
+    want = [orc.asymptotic_price(a, 0.04, K, T, DT, False, 0.25, 0.08, step_major=False),
+            orc.branching_price(a, 0.04, K, T, DT, False, 10, np.arange(steps, dtype=np.int32), SEED, mode="philox", step_major=False)[0],
+            orc.lsm_price(a, 0.04, K, T, DT, False, 2, step_major=False),
+            orc.martingale_price(a, 0.04, K, T, DT, False, 2, 5, step_major=False)[0]]
+    assert np.allclose(got, want, rtol=1e-7, atol=1e-12), (got, want)
+    s = mc.stats()
+    assert s["coalesced_fallbacks"] == 0 and s["coalesced_calls"] >= 5      # all five calls took the coalesced route
